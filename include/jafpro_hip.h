@@ -1,0 +1,278 @@
+/*
+ * jafpro_hip.h -- C ABI of libjafpro_hip.so: the MI355X (gfx950) kernels behind the JAFPro
+ * stage-4 train step (BASELINE.json north_star).
+ *
+ * The reference has exactly one FFI on this path, the neural_renderer pybind module
+ * (third_party/neural_renderer/neural_renderer/cuda/rasterize_cuda.cpp:70-95,194-200); every
+ * other op reaches cuDNN/ATen through torch.nn.  This header is what a native replacement of
+ * those call sites binds: plain pointers and sizes, no torch types.  Conventions (modelled on,
+ * and stricter than, rasterize_cuda.cpp:66-95):
+ *   - all buffers are caller-allocated device memory, dense fp32 NCHW unless stated
+ *     (int32 face-index maps, uint8 HWC IUV maps), 16-byte aligned;
+ *   - work is enqueued on the hipStream_t passed in (the reference kernels use the legacy
+ *     default stream, rasterize_cuda_kernel.cu:616,630);
+ *   - return 0 on success, JAF_E* (<0) for rejected arguments, a hipError_t (>0) for a failed
+ *     launch; nothing throws; no hidden global state; re-entrant across devices/streams.
+ */
+#ifndef JAFPRO_HIP_H
+#define JAFPRO_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* jaf_stream_t; /* == hipStream_t */
+
+#define JAF_OK 0
+#define JAF_EINVAL (-1)
+#define JAF_EUNSUPPORTED (-2)
+
+enum { JAF_ACT_NONE = 0, JAF_ACT_LRELU = 1, JAF_ACT_RELU = 2, JAF_ACT_SIGMOID = 3, JAF_ACT_TANH = 4 };
+
+int jaf_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family.  Replaces nn.Conv2d (+ fused bias / LeakyReLU / ReLU / sigmoid) at
+ * src/networks.py:868-878,900-903 (Downsampler / Upsampler_SE), src/crn_model.py:98-100
+ * (ConvBlock conv), src/flow_net.py:13-51, src/networks.py:361-417 (discriminators), VGG19
+ * (src/networks.py:70-94), and the ConvLSTM gate conv (src/convLSTM.py:43-45).
+ *
+ * One call convolves G independent groups (the 24 body-part networks of
+ * src/networks.py:1649-1652 run as ONE grouped launch) and reads its input as the channel
+ * concatenation of up to three source tensors, so torch.cat at src/convLSTM.py:43,
+ * src/networks.py:907,1164 and src/crn_model.py:276-299 is never materialised.
+ * Source i is [N, src_ctot[i], H, W]; group g reads channels
+ *   src_coff[i] + g*src_gstride[i] + [0, src_c[i]).
+ * Weights are the reference tensor [G, Cout_w, w_cin_tot, KH, KW]; this call uses input
+ * channels [w_cin_off, w_cin_off+Cin).  Output is [N, out_ctot, OH, OW], group g writes
+ * channels out_coff + g*Cout + [0, Cout).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct jaf_conv_desc {
+    int32_t N, G;
+    int32_t Cin, Cout;          /* per group; Cin == sum(src_c[0..nsrc)) */
+    int32_t H, W, OH, OW;
+    int32_t KH, KW, stride;
+    int32_t pad_t, pad_l;       /* zero padding on top/left; bottom/right follow from OH/OW */
+    int32_t dil_in;             /* 1; 2 = read the source as if zero-dilated by 2 (stride-2 dgrad) */
+    int32_t nsrc;
+    int32_t src_c[3], src_ctot[3], src_coff[3], src_gstride[3];
+    int32_t w_cin_tot, w_cin_off;
+    int32_t out_ctot, out_coff;
+    int32_t act;                /* JAF_ACT_* applied after bias */
+    float slope;                /* LeakyReLU negative slope */
+} jaf_conv_desc;
+
+/* Tiling chosen by the library for a descriptor (jaf_conv2d_plan). */
+typedef struct jaf_conv_plan {
+    int32_t MT;                 /* 16-row MFMA tiles per workgroup along Cout */
+    int32_t NT;                 /* 16-pixel MFMA tiles per wave */
+    int32_t CK;                 /* input channels staged per LDS chunk (multiple of 4) */
+    int32_t TWIN;               /* pixel-window width (== OW for small images) */
+    int32_t tiles_x, tiles_p;   /* windows across / pixel blocks down */
+    int32_t PH, PW, PWp, PS;    /* LDS patch rows, cols, row pitch, channel pitch (floats) */
+    int32_t MRp;                /* LDS pitch of a weight row group */
+    int32_t nchunks, mblocks;
+    int32_t lds_bytes;
+    int64_t packed_floats;      /* size of the packed-weight buffer for this plan */
+} jaf_conv_plan;
+
+enum { JAF_PACK_FWD = 0, JAF_PACK_DGRAD = 1, JAF_PACK_LSTM = 2 };
+
+int jaf_conv2d_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
+
+/* Re-lays a weight tensor out in the LDS image order of the plan ([G][mblock][chunk][tap][c][row]).
+ * JAF_PACK_FWD: rows = Cout.  JAF_PACK_LSTM: rows = 4*hidden, gate-interleaved so that one
+ * accumulator tile holds i,f,o,g of a channel (src/convLSTM.py:46 split order i,f,o,g).
+ * JAF_PACK_DGRAD: rows = forward input channels [w_cin_off, +Cout of the dgrad desc), reduction
+ * over forward output channels, taps flipped (the transposed convolution).                     */
+int jaf_conv2d_pack(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode,
+                    const float* w, int32_t w_rows_tot, float* packed);
+
+int jaf_conv2d_fwd(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                   const float* src0, const float* src1, const float* src2,
+                   const float* packed_w, const float* bias, float* out);
+
+/* Reference implementation of the same contract with one thread per output element and the
+ * unpacked weights; used by the GPU tests to cross-check the MFMA kernel. */
+int jaf_conv2d_fwd_direct(jaf_stream_t s, const jaf_conv_desc* d,
+                          const float* src0, const float* src1, const float* src2,
+                          const float* w, const float* bias, float* out);
+
+/* dW[G][Cout][w_cin_tot][KH][KW] (+)= sum over n,pixels of dz * input patch; dz is laid out as
+ * the forward output (out_ctot/out_coff).  accumulate=0 zeroes the touched slice first.        */
+int jaf_conv2d_wgrad(jaf_stream_t s, const jaf_conv_desc* d,
+                     const float* src0, const float* src1, const float* src2,
+                     const float* dz, float* dw, int accumulate);
+
+/* db[c] (+)= sum over n,h,w of x[n, coff + c, h, w] for c in [0, C). */
+int jaf_channel_sum(jaf_stream_t s, const float* x, int32_t N, int32_t ctot, int32_t coff,
+                    int32_t C, int32_t HW, float* out, int accumulate);
+
+/* ConvLSTM cell, src/convLSTM.py:41-56 in one kernel: gates = conv3x3(cat[x, h_prev]) + b,
+ * i,f,o = sigmoid, g = tanh, c = f*c_prev + i*g, h = o*tanh(c).  d->Cout == 4*hidden.
+ * h_prev == NULL and c_prev == NULL mean the zero state of init_hidden (:58-63) and skip the
+ * zero half of the reduction.  gates_out (nullable) receives the post-activation gates
+ * [N, G*4*hidden, H, W] (order i,f,o,g per group) for the backward pass.                         */
+int jaf_convlstm_cell_fwd(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                          const float* x, const float* h_prev, const float* packed_w,
+                          const float* bias, const float* c_prev,
+                          float* h_out, float* c_out, float* gates_out);
+
+/* Backward of the gate math: given dh, dc_next (nullable), gates (i,f,o,g), c_prev (nullable),
+ * c_cur: writes the pre-activation gate gradients in place of `gates` and dc_prev.               */
+int jaf_convlstm_gates_bwd(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW,
+                           const float* dh, const float* dc_next, float* gates,
+                           const float* c_prev, const float* c_cur, float* dc_prev);
+
+/* ------------------------------------------------------------------------------------------
+ * Activations and normalisation.
+ * ------------------------------------------------------------------------------------------ */
+/* dz = dy * act'(y) given the activation OUTPUT y (lrelu/relu/sigmoid/tanh). */
+int jaf_act_bwd(jaf_stream_t s, const float* dy, const float* y, float* dz, int64_t n, int act,
+                float slope);
+
+/* CRN LayerNorm (src/crn_model.py:78-87) + LeakyReLU(0.01) (:100): per sample mean and
+ * Bessel-corrected std over C*H*W, y = lrelu(gamma_c*(x-mean)/(std+eps)+beta_c).
+ * stats[n] = {mean, 1/(std+eps)} (float2).                                                      */
+int jaf_layernorm_stats(jaf_stream_t s, const float* x, int32_t N, int64_t chw, float eps,
+                        double* workspace /* 2*N doubles */, float* stats /* 2*N */);
+int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
+                            const float* beta, float* y, int32_t N, int32_t C, int32_t HW,
+                            float slope);
+/* Backward through lrelu + affine + normalisation.  x is the conv output (pre-norm).
+ * dgamma/dbeta are accumulated (+=).                                                            */
+int jaf_layernorm_lrelu_bwd(jaf_stream_t s, const float* dy, const float* x, const float* stats,
+                            const float* gamma, const float* beta, float* dx, float* dgamma,
+                            float* dbeta, double* workspace /* 2*N doubles */, int32_t N,
+                            int32_t C, int32_t HW, float slope, float eps);
+
+/* BatchNorm2d in training mode (src/flow_net.py:13-51, src/networks.py:369-390; eps 1e-5,
+ * momentum 0.1, biased var for normalisation, unbiased for running_var) + activation
+ * (+ optional residual add: ResnetBlock, src/flow_net.py:139-141).
+ * stats = {mean[C], rstd[C]} (2*C floats).  training=0 normalises with running stats.          */
+int jaf_batchnorm_stats(jaf_stream_t s, const float* x, int32_t N, int32_t C, int32_t HW,
+                        float eps, float momentum, float* running_mean, float* running_var,
+                        float* stats, int training);
+int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float* stats, const float* weight,
+                          const float* bias, const float* residual, float* y, int32_t N,
+                          int32_t C, int32_t HW, int act, float slope);
+int jaf_batchnorm_act_bwd(jaf_stream_t s, const float* dy, const float* x, const float* y,
+                          const float* stats, const float* weight, float* dx, float* dweight,
+                          float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
+                          int training);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling.
+ * ------------------------------------------------------------------------------------------ */
+/* F.avg_pool2d(3,stride 2,pad 1,count_include_pad) src/crn_model.py:268-273; k=2: VGG AvgPool2d(2,2)
+ * src/networks.py:76-78. */
+int jaf_avgpool_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W,
+                    int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad);
+int jaf_avgpool_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
+                    int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad);
+
+/* Bilinear resize of a crop window [y0,y0+ch) x [x0,x0+cw) of x[NC,H,W] to [NC,OH,OW];
+ * align_corners per call site.  mode 1 = nearest (face IUV, train/4...py:350).
+ * The output may be a channel slice of a larger tensor: y index = ((n*out_ctot + out_coff + c)).*/
+int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t N, int32_t C, int32_t H,
+                   int32_t W, int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH,
+                   int32_t OW, int align_corners, int nearest);
+int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t N, int32_t C, int32_t H,
+                   int32_t W, int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH,
+                   int32_t OW, int align_corners);
+
+/* nn.ReflectionPad2d(p) (src/flow_net.py:13,51,113) and its adjoint. */
+int jaf_reflect_pad_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W,
+                        int32_t p);
+int jaf_reflect_pad_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H,
+                        int32_t W, int32_t p);
+
+/* ------------------------------------------------------------------------------------------
+ * Gathers and blends (HBM-bound wavefront kernels).
+ * ------------------------------------------------------------------------------------------ */
+/* texture_warp_pytorch, train/4.convLSTM_flowpro_interval.py:43-76, all 24 parts and the whole
+ * batch in one pass.  tex: [B, 24*3, TH, TW] (part p = channels 3p..3p+2), iuv: uint8 [B,S,S,3]
+ * HWC (I,U,V), out: [B,3,S,S].  x=((255-V)/255-.5)*2, y=(U/255-.5)*2, bilinear, zeros padding. */
+int jaf_texture_warp_fwd(jaf_stream_t s, const float* tex, const uint8_t* iuv, float* out,
+                         int32_t B, int32_t S, int32_t TH, int32_t TW, int align_corners);
+/* dtex must be zero-filled by the caller; scatter-add of dout at the sampled taps. */
+int jaf_texture_warp_bwd(jaf_stream_t s, const float* dout, const uint8_t* iuv, float* dtex,
+                         int32_t B, int32_t S, int32_t TH, int32_t TW, int align_corners);
+
+/* F.grid_sample(bilinear) of src[B,C,H,W] at grid[B,OH,OW,2]; padding 0 = zeros, 1 = border
+ * (src/cal_flow.py:38). */
+int jaf_grid_sample_fwd(jaf_stream_t s, const float* src, const float* grid, float* out,
+                        int32_t B, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                        int padding_border, int align_corners);
+
+/* out = a*m + b*(1-m), m broadcast over C (train/4...py:321; src/flow_net.py:98). */
+int jaf_blend_fwd(jaf_stream_t s, const float* a, const float* b, const float* m, float* out,
+                  int32_t N, int32_t C, int32_t HW);
+/* da = dout*m, db = dout*(1-m) (either nullable), dm = sum_c dout*(a-b). */
+int jaf_blend_bwd(jaf_stream_t s, const float* dout, const float* a, const float* b,
+                  const float* m, float* da, float* db, float* dm, int32_t N, int32_t C,
+                  int32_t HW);
+/* out[n,c,i] = x[n,c,i] * m[n,(mc==1?0:c),i]  (mask premultiply src/flow_net.py:91; common-area
+ * multiply train/4...py:295-298 through jaf_part_mask_mul). */
+int jaf_mul_bcast(jaf_stream_t s, const float* x, const float* m, float* out, int32_t N, int32_t C,
+                  int32_t MC, int32_t HW);
+/* Common-area mask logic train/4...py:283-298: area = OR_t (mask[b,t] != 0 && used[t]) over the
+ * 800x1200 atlas; out[b, 3p+c, y, x] = tex[b,3p+c,y,x] * area[b, (p/6)*200+y, (p%6)*200+x].
+ * masks: float [B,T,AH,AW]; used: int32 [T].                                                   */
+int jaf_part_mask_mul(jaf_stream_t s, const float* tex, const float* masks, const int32_t* used,
+                      float* out, int32_t B, int32_t T, int32_t AH, int32_t AW, int32_t P,
+                      int32_t PS_);
+/* list[24] of (B,3,200,200) parts <-> atlas [B,T,3,800,1200] (train/4...py:269-276). */
+int jaf_atlas_to_parts(jaf_stream_t s, const float* atlas, float* parts, int32_t B, int32_t T,
+                       int32_t AH, int32_t AW, int32_t PSZ);
+
+/* ------------------------------------------------------------------------------------------
+ * Renderer path (src/cal_flow.py:28-35, src/nmr.py:263-278,617-659; NMR kernels
+ * rasterize_cuda_kernel.cu:24-169).
+ * ------------------------------------------------------------------------------------------ */
+/* proj + y-flip + look_at (eye (0,0,-(1/tan30+1)), identity rotation) + vertices_to_faces:
+ * verts[B,NV,3], cam[B,3], faces_idx int32[NF,3] -> faces[B,NF,3,3]. */
+int jaf_project_faces(jaf_stream_t s, const float* verts, const float* cam,
+                      const int32_t* faces_idx, float* faces, int32_t B, int32_t NV, int32_t NF,
+                      float eye_z);
+/* Face-index / weight map of `faces` at S x S, outputs vertically flipped as rasterize.py:334-338.
+ * fim int32 [B,S,S] (-1 background), wim [B,S,S,3].  workspace: see jaf_rasterize_workspace. */
+int64_t jaf_rasterize_workspace(int32_t B, int32_t NF, int32_t S);
+int jaf_rasterize_fim_wim(jaf_stream_t s, const float* faces, int32_t* fim, float* wim,
+                          void* workspace, int32_t B, int32_t NF, int32_t S, float near_, float far_);
+/* cal_bc_transform fused with the y re-flip of src/cal_flow.py:30-31: T[B,S,S,2]. */
+int jaf_bc_transform(jaf_stream_t s, const float* src_faces /*[B,NF,3,3]*/, const int32_t* fim,
+                     const float* wim, float* T, int32_t B, int32_t NF, int32_t S);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses, classifier head, optimiser.
+ * ------------------------------------------------------------------------------------------ */
+/* vgg_preprocess src/networks.py:109-116: y = 255*(x+1)/2 - mean[c]. */
+int jaf_vgg_preprocess(jaf_stream_t s, const float* x, float* y, int32_t N, int32_t HW);
+/* loss[0] += w * mean|a-b|;  da (nullable) = w*sign(a-b)/n  (L1Loss, src/networks.py:99,122). */
+int jaf_l1_loss_fwd(jaf_stream_t s, const float* a, const float* b, int64_t n, float w,
+                    float* loss_accum);
+int jaf_l1_loss_bwd(jaf_stream_t s, const float* a, const float* b, int64_t n, float w,
+                    const float* dloss, float* da, int accumulate);
+/* BCELoss(mean) on probabilities p vs constant target t (train/4...py:179,365-404);
+ * log clamped at -100 like torch. */
+int jaf_bce_fwd(jaf_stream_t s, const float* p, int32_t n, float target, float* loss);
+int jaf_bce_bwd(jaf_stream_t s, const float* p, int32_t n, float target, const float* dloss,
+                float* dp);
+/* nn.Linear (+ act): y[N,O] = act(x[N,I] @ W[O,I]^T + b) (src/networks.py:408-410). */
+int jaf_linear_fwd(jaf_stream_t s, const float* x, const float* w, const float* b, float* y,
+                   int32_t N, int32_t I, int32_t O, int act, float slope);
+int jaf_linear_bwd(jaf_stream_t s, const float* dz, const float* x, const float* w, float* dx,
+                   float* dw, float* db, int32_t N, int32_t I, int32_t O);
+/* torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay, train/4...py:169-175)
+ * over one flat parameter buffer. step is the 1-based step count. */
+int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int32_t step);
+/* y = a*x + b*y elementwise (gradient accumulation, scaling). */
+int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float* y, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAFPRO_HIP_H */

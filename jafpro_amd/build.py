@@ -1,0 +1,70 @@
+"""Builds libjafpro_hip.so (gfx950) in-tree with hipcc.
+
+Run as ``python -m jafpro_amd.build`` or through ``__graft_entry__.build()``.  hipcc
+cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libjafpro_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+SOURCES = ["conv.hip", "wgrad.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
+           "raster.hip", "linear.hip"]
+# raster.hip must keep the reference's fp32 expression trees (no FMA contraction): see its header.
+EXTRA = {"raster.hip": ["-ffp-contract=off"]}
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+
+
+def _digest(path: str, flags) -> str:
+    h = hashlib.sha256()
+    for p in (path, os.path.join(CSRC, "jaf_common.h"), os.path.join(HERE, "..", "include", "jafpro_hip.h")):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(flags).encode())
+    return h.hexdigest()
+
+
+def _compile(src: str) -> str:
+    path = os.path.join(CSRC, src)
+    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    flags = COMMON + EXTRA.get(src, [])
+    stamp = obj + ".sha"
+    dig = _digest(path, flags)
+    if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return obj
+    cmd = [HIPCC] + flags + ["-c", path, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return obj
+
+
+def build(force: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for f in os.listdir(OBJ):
+            os.remove(os.path.join(OBJ, f))
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    newest = max(os.path.getmtime(o) for o in objs)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < newest:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

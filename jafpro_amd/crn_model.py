@@ -1,0 +1,113 @@
+"""CRN refinement / background network on the HIP kernels.  Mirrors src/crn_model.py:
+LayerNorm (:67-87), ConvBlock (:90-106), CRN_smaller (:243-308) -- same constructor arguments,
+``forward(label, sp)`` contract and state_dict keys (``conv1_encoder.conv_block.{0,3}.weight|bias``,
+``.{1,4}.gamma|beta``, ``out_conv``, ``fg_conv``).
+
+The decoder inputs ``cat[label_down, pool_k, net_up]`` (:276-299) are never materialised: the
+conv kernel reads its three sources directly.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_SIGMOID
+
+
+class _Conv2d(nn.Module):
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        bound = 1.0 / math.sqrt(cin * k * k)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class LayerNorm(nn.Module):
+    """Per-sample mean / Bessel-corrected std over C*H*W, eps added to the std, per-channel
+    gamma (init U(0,1)) and beta; fused with the following LeakyReLU(0.01) by ConvBlock."""
+
+    def __init__(self, num_features, eps=1e-5, affine=True):
+        super().__init__()
+        self.num_features = num_features
+        self.affine = affine
+        self.eps = eps
+        if not affine:
+            raise NotImplementedError("the stage-4 CRN always uses the affine LayerNorm")
+        self.gamma = nn.Parameter(torch.Tensor(num_features).uniform_())
+        self.beta = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x, slope: float = 1.0):
+        """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01."""
+        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope)
+
+
+class ConvBlock(nn.Module):
+    def __init__(self, n_repeats, c_in, c_out, kernel_size, pad):
+        super().__init__()
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        layers = []
+        for _ in range(n_repeats):
+            layers += [_Conv2d(c_in, c_out, k), LayerNorm(c_out), nn.Identity()]   # Identity = LeakyReLU slot
+            c_in = c_out
+        self.conv_block = nn.Sequential(*layers)
+        self.n_repeats, self.pad = n_repeats, pad
+
+    def forward(self, x):
+        """x: tensor or list of tensors (read as their channel concatenation)."""
+        for r in range(self.n_repeats):
+            conv, ln = self.conv_block[3 * r], self.conv_block[3 * r + 1]
+            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE)
+            x = ln(x, 0.01)
+        return x
+
+
+class CRN_smaller(nn.Module):
+    def __init__(self, input_channel=6, fg=False):
+        super().__init__()
+        ic = input_channel
+        self.conv1_encoder = ConvBlock(2, ic, 64, (3, 3), 1)
+        self.conv2_encoder = ConvBlock(2, 64, 128, (3, 3), 1)
+        self.conv3_encoder = ConvBlock(2, 128, 128, (3, 3), 1)
+        self.conv4_encoder = ConvBlock(2, 128, 256, (3, 3), 1)
+        self.conv5_encoder = ConvBlock(2, 256, 256, (3, 3), 1)
+        self.conv6_encoder = ConvBlock(2, 256, 512, (3, 3), 1)
+        self.conv6_decoder = ConvBlock(2, ic + 512, 512, (3, 3), 1)
+        self.conv5_decoder = ConvBlock(2, ic + 512 + 256, 512, (3, 3), 1)
+        self.conv4_decoder = ConvBlock(2, ic + 512 + 256, 512, (3, 3), 1)
+        self.conv3_decoder = ConvBlock(2, ic + 512 + 128, 512, (3, 3), 1)
+        self.conv2_decoder = ConvBlock(2, ic + 512 + 128, 512, (3, 3), 1)
+        self.conv1_decoder = ConvBlock(2, ic + 512 + 64, 256, (3, 3), 1)
+        self.decoder = ConvBlock(2, ic + 256, 256, (3, 3), 1)
+        self.out_conv = _Conv2d(256, 3, 1)
+        self.fg = fg
+        if fg:
+            self.fg_conv = _Conv2d(256, 1, 1)
+
+    def forward(self, label, sp):
+        label = label.contiguous()
+        pool = lambda t: ops.avg_pool(t, 3, 2, 1)
+        down = lambda s: ops.resize(label, (s, s), align_corners=True)
+        up = lambda t, s: ops.resize(t, (s, s), align_corners=True)
+        pool1 = pool(self.conv1_encoder(label))
+        pool2 = pool(self.conv2_encoder(pool1))
+        pool3 = pool(self.conv3_encoder(pool2))
+        pool4 = pool(self.conv4_encoder(pool3))
+        pool5 = pool(self.conv5_encoder(pool4))
+        pool6 = pool(self.conv6_encoder(pool5))
+        net_6 = up(self.conv6_decoder([down(sp // 64), pool6]), sp // 32)
+        net_5 = up(self.conv5_decoder([down(sp // 32), pool5, net_6]), sp // 16)
+        net_4 = up(self.conv4_decoder([down(sp // 16), pool4, net_5]), sp // 8)
+        net_3 = up(self.conv3_decoder([down(sp // 8), pool3, net_4]), sp // 4)
+        net_2 = up(self.conv2_decoder([down(sp // 4), pool2, net_3]), sp // 2)
+        net_1 = up(self.conv1_decoder([down(sp // 2), pool1, net_2]), sp)
+        net = self.decoder([label, net_1])
+        net_final = ops.conv2d(net, self.out_conv.weight, self.out_conv.bias, stride=1, pad=0, act=ACT_NONE)
+        if self.fg:
+            fg_mask = ops.conv2d(net, self.fg_conv.weight, self.fg_conv.bias, stride=1, pad=0, act=ACT_SIGMOID)
+            return net_final, fg_mask
+        return net_final

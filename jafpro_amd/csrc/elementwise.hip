@@ -1,0 +1,340 @@
+// HBM-bound elementwise kernels of the stage-4 step: blends, masks, activation backward,
+// ConvLSTM gate backward, losses, Adam.  One pass over each operand, 16 B per lane where the
+// layout allows it, grid capped at 2048 workgroups and strided (cdna_hip_programming.md G11/G13).
+#include "jaf_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ activation backward
+__global__ void act_bwd_kernel(const float* dy, const float* y, float* dz, long n, int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float yv = y[i];
+        float g;
+        switch (act) {
+            case JAF_ACT_LRELU: g = yv > 0.f ? 1.f : slope; break;
+            case JAF_ACT_RELU: g = yv > 0.f ? 1.f : 0.f; break;
+            case JAF_ACT_SIGMOID: g = yv * (1.f - yv); break;
+            case JAF_ACT_TANH: g = 1.f - yv * yv; break;
+            default: g = 1.f;
+        }
+        dz[i] = dy[i] * g;
+    }
+}
+
+extern "C" int jaf_act_bwd(jaf_stream_t s, const float* dy, const float* y, float* dz, int64_t n, int act, float slope) {
+    JAF_REQUIRE(dy && y && dz && n >= 0);
+    if (n == 0) return JAF_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, y, dz, (long)n, act, slope);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ ConvLSTM gate backward
+// gates: [N, G*4C, HW] (i,f,o,g per group), h/c tensors: [N, G*C, HW]  (src/convLSTM.py:48-54)
+__global__ void lstm_gates_bwd_kernel(int N, int G, int C, int HW, const float* dh, const float* dc_next,
+                                      float* gates, const float* c_prev, const float* c_cur, float* dc_prev) {
+    const long total = (long)N * G * C * HW;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int pix = (int)(e % HW);
+        const long nc = e / HW;            // n*G*C + g*C + c
+        const int c = (int)(nc % C);
+        const long ng = nc / C;            // n*G + g
+        float* gp = gates + (ng * 4 * C + c) * HW + pix;
+        const long cs = (long)C * HW;
+        const float gi = gp[0], gf = gp[cs], go = gp[2 * cs], gg = gp[3 * cs];
+        const float cc = c_cur[e];
+        const float tc = jaf_tanh(cc);
+        const float dhv = dh[e];
+        float dc = dhv * go * (1.f - tc * tc);
+        if (dc_next) dc += dc_next[e];
+        const float cp = c_prev ? c_prev[e] : 0.f;
+        gp[0] = dc * gg * gi * (1.f - gi);
+        gp[cs] = dc * cp * gf * (1.f - gf);
+        gp[2 * cs] = dhv * tc * go * (1.f - go);
+        gp[3 * cs] = dc * gi * (1.f - gg * gg);
+        dc_prev[e] = dc * gf;
+    }
+}
+
+extern "C" int jaf_convlstm_gates_bwd(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW,
+                                      const float* dh, const float* dc_next, float* gates,
+                                      const float* c_prev, const float* c_cur, float* dc_prev) {
+    JAF_REQUIRE(dh && gates && c_cur && dc_prev && N >= 1 && G >= 1 && C >= 1 && HW >= 1);
+    const long total = (long)N * G * C * HW;
+    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(jaf_ew_grid(total)), dim3(256), 0, (hipStream_t)s,
+                       N, G, C, HW, dh, dc_next, gates, c_prev, c_cur, dc_prev);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ blends
+// out = a*m + b*(1-m), m [N,1,HW] broadcast over C.
+__global__ void blend_fwd_kernel(const float* a, const float* b, const float* m, float* out, int N, int C, int HW) {
+    const long total = (long)N * C * HW;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int pix = (int)(e % HW);
+        const long n = e / ((long)C * HW);
+        const float mv = m[n * HW + pix];
+        out[e] = a[e] * mv + b[e] * (1.f - mv);
+    }
+}
+
+extern "C" int jaf_blend_fwd(jaf_stream_t s, const float* a, const float* b, const float* m, float* out,
+                             int32_t N, int32_t C, int32_t HW) {
+    JAF_REQUIRE(a && b && m && out && N >= 1 && C >= 1 && HW >= 1);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(jaf_ew_grid((long)N * C * HW)), dim3(256), 0, (hipStream_t)s, a, b, m, out, N, C, HW);
+    return jaf_launch_status();
+}
+
+// one thread per (n, pixel): loops the C channels so dm needs no atomics
+__global__ void blend_bwd_kernel(const float* dout, const float* a, const float* b, const float* m,
+                                 float* da, float* db, float* dm, int N, int C, int HW) {
+    const long total = (long)N * HW;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int pix = (int)(e % HW);
+        const long n = e / HW;
+        const float mv = m[e];
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const long i = (n * C + c) * HW + pix;
+            const float g = dout[i];
+            if (da) da[i] = g * mv;
+            if (db) db[i] = g * (1.f - mv);
+            acc += g * (a[i] - b[i]);
+        }
+        if (dm) dm[e] = acc;
+    }
+}
+
+extern "C" int jaf_blend_bwd(jaf_stream_t s, const float* dout, const float* a, const float* b, const float* m,
+                             float* da, float* db, float* dm, int32_t N, int32_t C, int32_t HW) {
+    JAF_REQUIRE(dout && a && b && m && N >= 1 && C >= 1 && HW >= 1);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(jaf_ew_grid((long)N * HW)), dim3(256), 0, (hipStream_t)s, dout, a, b, m, da, db, dm, N, C, HW);
+    return jaf_launch_status();
+}
+
+__global__ void mul_bcast_kernel(const float* x, const float* m, float* out, int N, int C, int MC, int HW) {
+    const long total = (long)N * C * HW;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int pix = (int)(e % HW);
+        const long nc = e / HW;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        const float mv = (MC == 1) ? m[n * HW + pix] : m[(n * MC + c) * HW + pix];
+        out[e] = x[e] * mv;
+    }
+}
+
+extern "C" int jaf_mul_bcast(jaf_stream_t s, const float* x, const float* m, float* out, int32_t N, int32_t C,
+                             int32_t MC, int32_t HW) {
+    JAF_REQUIRE(x && m && out && N >= 1 && C >= 1 && HW >= 1 && (MC == 1 || MC == C));
+    hipLaunchKernelGGL(mul_bcast_kernel, dim3(jaf_ew_grid((long)N * C * HW)), dim3(256), 0, (hipStream_t)s, x, m, out, N, C, MC, HW);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ texture-atlas helpers
+// parts tensor: [B*T? , P*3, PSZ, PSZ]; atlas [B, T, 3, AH, AW]; part p sits at rows (p/6)*PSZ,
+// cols (p%6)*PSZ (train/4...py:269-276).  Output image index = t*B + b (the reference
+// concatenates the T references on the batch axis, src/networks.py:1317).
+__global__ void atlas_to_parts_kernel(const float* atlas, float* parts, int B, int T, int AH, int AW, int PSZ) {
+    const int pcols = AW / PSZ;
+    const int P = (AH / PSZ) * pcols;
+    const long total = (long)T * B * P * 3 * PSZ * PSZ;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        long t_ = e;
+        const int x = (int)(t_ % PSZ); t_ /= PSZ;
+        const int y = (int)(t_ % PSZ); t_ /= PSZ;
+        const int c = (int)(t_ % 3); t_ /= 3;
+        const int p = (int)(t_ % P); t_ /= P;
+        const int b = (int)(t_ % B); t_ /= B;
+        const int t = (int)t_;
+        const int ay = (p / pcols) * PSZ + y;
+        const int ax = (p % pcols) * PSZ + x;
+        parts[e] = atlas[((((long)b * T + t) * 3 + c) * AH + ay) * AW + ax];
+    }
+}
+
+extern "C" int jaf_atlas_to_parts(jaf_stream_t s, const float* atlas, float* parts, int32_t B, int32_t T,
+                                  int32_t AH, int32_t AW, int32_t PSZ) {
+    JAF_REQUIRE(atlas && parts && B >= 1 && T >= 1 && PSZ >= 1 && AH % PSZ == 0 && AW % PSZ == 0);
+    const long total = (long)T * B * (AH / PSZ) * (AW / PSZ) * 3 * PSZ * PSZ;
+    hipLaunchKernelGGL(atlas_to_parts_kernel, dim3(jaf_ew_grid(total)), dim3(256), 0, (hipStream_t)s, atlas, parts, B, T, AH, AW, PSZ);
+    return jaf_launch_status();
+}
+
+// out[b, 3p+c, y, x] = tex[...] * (OR_t used[t] && masks[b,t,ay,ax] != 0)
+__global__ void part_mask_mul_kernel(const float* tex, const float* masks, const int* used, float* out,
+                                     int B, int T, int AH, int AW, int P, int PSZ) {
+    const int pcols = AW / PSZ;
+    const long total = (long)B * P * PSZ * PSZ;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        long t_ = e;
+        const int x = (int)(t_ % PSZ); t_ /= PSZ;
+        const int y = (int)(t_ % PSZ); t_ /= PSZ;
+        const int p = (int)(t_ % P); t_ /= P;
+        const int b = (int)t_;
+        const int ay = (p / pcols) * PSZ + y;
+        const int ax = (p % pcols) * PSZ + x;
+        bool on = false;
+        for (int t = 0; t < T; ++t)
+            on = on || (used[t] && ((unsigned char)masks[(((long)b * T + t) * AH + ay) * AW + ax] != 0));
+        const float mv = on ? 1.f : 0.f;
+        for (int c = 0; c < 3; ++c) {
+            const long i = ((((long)b * P + p) * 3 + c) * PSZ + y) * PSZ + x;
+            out[i] = tex[i] * mv;
+        }
+    }
+}
+
+extern "C" int jaf_part_mask_mul(jaf_stream_t s, const float* tex, const float* masks, const int32_t* used,
+                                 float* out, int32_t B, int32_t T, int32_t AH, int32_t AW, int32_t P, int32_t PSZ) {
+    JAF_REQUIRE(tex && masks && used && out && B >= 1 && T >= 1 && PSZ >= 1);
+    JAF_REQUIRE(AH % PSZ == 0 && AW % PSZ == 0 && (AH / PSZ) * (AW / PSZ) == P);
+    hipLaunchKernelGGL(part_mask_mul_kernel, dim3(jaf_ew_grid((long)B * P * PSZ * PSZ)), dim3(256), 0, (hipStream_t)s,
+                       tex, masks, used, out, B, T, AH, AW, P, PSZ);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ losses
+__global__ void vgg_preprocess_kernel(const float* x, float* y, int N, int HW) {
+    const long total = (long)N * 3 * HW;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int c = (int)((e / HW) % 3);
+        const float mean = c == 0 ? 103.939f : (c == 1 ? 116.779f : 123.68f);
+        y[e] = 255.0f * (x[e] + 1.0f) / 2.0f - mean;
+    }
+}
+
+extern "C" int jaf_vgg_preprocess(jaf_stream_t s, const float* x, float* y, int32_t N, int32_t HW) {
+    JAF_REQUIRE(x && y && N >= 1 && HW >= 1);
+    hipLaunchKernelGGL(vgg_preprocess_kernel, dim3(jaf_ew_grid((long)N * 3 * HW)), dim3(256), 0, (hipStream_t)s, x, y, N, HW);
+    return jaf_launch_status();
+}
+
+__global__ void l1_loss_fwd_kernel(const float* a, const float* b, long n, float scale, float* loss) {
+    double acc = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) acc += (double)fabsf(a[i] - b[i]);
+    __shared__ double red[4];
+    acc = jaf_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (float)((red[0] + red[1] + red[2] + red[3]) * (double)scale));
+}
+
+extern "C" int jaf_l1_loss_fwd(jaf_stream_t s, const float* a, const float* b, int64_t n, float w, float* loss_accum) {
+    JAF_REQUIRE(a && b && loss_accum && n >= 1);
+    int grid = jaf_ew_grid(n, 4);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(l1_loss_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, a, b, (long)n, w / (float)n, loss_accum);
+    return jaf_launch_status();
+}
+
+__global__ void l1_loss_bwd_kernel(const float* a, const float* b, long n, float scale, const float* dloss,
+                                   float* da, int accumulate) {
+    const float g = scale * dloss[0];
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float dlt = a[i] - b[i];
+        const float sg = dlt > 0.f ? 1.f : (dlt < 0.f ? -1.f : 0.f);
+        da[i] = (accumulate ? da[i] : 0.f) + sg * g;
+    }
+}
+
+extern "C" int jaf_l1_loss_bwd(jaf_stream_t s, const float* a, const float* b, int64_t n, float w,
+                               const float* dloss, float* da, int accumulate) {
+    JAF_REQUIRE(a && b && dloss && da && n >= 1);
+    hipLaunchKernelGGL(l1_loss_bwd_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, a, b, (long)n, w / (float)n, dloss, da, accumulate);
+    return jaf_launch_status();
+}
+
+__global__ void bce_fwd_kernel(const float* p, int n, float target, float* loss) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float lp = fmaxf(__logf(p[i]), -100.f);
+        const float lq = fmaxf(__logf(1.f - p[i]), -100.f);
+        acc += -(target * lp + (1.f - target) * lq);
+    }
+    acc = jaf_wave_sum(acc);
+    if (threadIdx.x == 0) loss[0] = acc / (float)n;
+}
+
+extern "C" int jaf_bce_fwd(jaf_stream_t s, const float* p, int32_t n, float target, float* loss) {
+    JAF_REQUIRE(p && loss && n >= 1);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, p, n, target, loss);
+    return jaf_launch_status();
+}
+
+__global__ void bce_bwd_kernel(const float* p, int n, float target, const float* dloss, float* dp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // d/dp [-(t log p + (1-t) log(1-p))], with torch's clamp: zero gradient where the log is clamped
+    const float pv = p[i];
+    float g = 0.f;
+    if (__logf(pv) > -100.f) g += -target / pv;
+    if (__logf(1.f - pv) > -100.f) g += (1.f - target) / (1.f - pv);
+    dp[i] = g * dloss[0] / (float)n;
+}
+
+extern "C" int jaf_bce_bwd(jaf_stream_t s, const float* p, int32_t n, float target, const float* dloss, float* dp) {
+    JAF_REQUIRE(p && dloss && dp && n >= 1);
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(jaf_cdiv(n, 64)), dim3(64), 0, (hipStream_t)s, p, n, target, dloss, dp);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ optimiser
+__global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                            float eps, float bc1, float bc2_sqrt) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = n >> 2;
+    f32x4* p4 = (f32x4*)p; const f32x4* g4 = (const f32x4*)g; f32x4* m4 = (f32x4*)m; f32x4* v4 = (f32x4*)v;
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = p4[i], gv = g4[i], mv = m4[i], vv = v4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mv[k] = mv[k] + (gv[k] - mv[k]) * (1.f - b1);       // torch: exp_avg.lerp_(grad, 1-beta1)
+            vv[k] = vv[k] * b2 + (1.f - b2) * gv[k] * gv[k];
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pv[k] = pv[k] - step_size * (mv[k] / denom);
+        }
+        p4[i] = pv; m4[i] = mv; v4[i] = vv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float mv = m[i] + (g[i] - m[i]) * (1.f - b1);
+        float vv = v[i] * b2 + (1.f - b2) * g[i] * g[i];
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mv / denom);
+        m[i] = mv; v[i] = vv;
+    }
+}
+
+extern "C" int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n,
+                             float lr, float beta1, float beta2, float eps, int32_t step) {
+    JAF_REQUIRE(p && g && m && v && n >= 1 && step >= 1);
+    JAF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(jaf_ew_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr,
+                       beta1, beta2, eps, bc1, sqrtf(bc2));
+    return jaf_launch_status();
+}
+
+__global__ void axpby_kernel(float a, const float* x, float b, float* y, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = a * x[i] + (b == 0.f ? 0.f : b * y[i]);
+}
+
+extern "C" int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float* y, int64_t n) {
+    JAF_REQUIRE(x && y && n >= 0);
+    if (n == 0) return JAF_OK;
+    hipLaunchKernelGGL(axpby_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, a, x, b, y, (long)n);
+    return jaf_launch_status();
+}

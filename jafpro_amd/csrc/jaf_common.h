@@ -1,0 +1,58 @@
+// Shared device/host helpers for the jafpro_amd HIP library (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/jafpro_hip.h"
+
+#define JAF_WAVE 64
+
+// Every entry point returns 0 on success, a negative JAF_E* on bad arguments, or the
+// (positive) hipError_t of a failed launch.  Nothing throws across the ABI
+// (reference: rasterize_cuda.cpp:66-68 raises from AT_CHECK, launch errors are only
+// printf'd at rasterize_cuda_kernel.cu:624-626 -- here they are returned).
+static inline int jaf_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? JAF_OK : (int)e;
+}
+
+#define JAF_REQUIRE(cond) do { if (!(cond)) return JAF_EINVAL; } while (0)
+
+static inline int jaf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// grid for HBM-bound elementwise kernels: cap at 2048 blocks of 256 and grid-stride
+// the rest (cdna_hip_programming.md Guideline 11).
+static inline int jaf_ew_grid(long n, int per_thread = 1) {
+    long blocks = (n + 256L * per_thread - 1) / (256L * per_thread);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    return (int)blocks;
+}
+
+__device__ __forceinline__ float jaf_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float jaf_tanh(float x) {
+    // tanh via exp; exact enough for fp32 parity (|err| ~1e-7), saturates cleanly.
+    float e = __expf(-2.0f * fabsf(x));
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ float jaf_act(float v, int act, float slope) {
+    switch (act) {
+        case JAF_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case JAF_ACT_RELU: return v > 0.f ? v : 0.f;
+        case JAF_ACT_SIGMOID: return jaf_sigmoid(v);
+        case JAF_ACT_TANH: return jaf_tanh(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ double jaf_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float jaf_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}

@@ -1,0 +1,223 @@
+// Renderer path of float_estimate (src/cal_flow.py:21-39): SMPL projection, the neural_renderer
+// face-index / weight-map rasteriser (rasterize_cuda_kernel.cu:24-169) and cal_bc_transform
+// (src/nmr.py:617-659).
+//
+// The reference rasteriser tests every pixel against all 13 776 faces.  Here a workgroup owns a
+// 16x16 pixel tile, sweeps the face list once with a bounding-box overlap test (256 faces per
+// sweep step, order-preserving wave compaction), stages the survivors (vertices + inverse) in
+// LDS and lets its 256 pixels walk that short list with the reference's exact per-pixel
+// arithmetic.  Faces are visited in ascending index order, so "first strictly smaller z wins"
+// (rasterize_cuda_kernel.cu:142) is preserved.  This file is compiled with -ffp-contract=off so
+// the fp32 expression trees match the C restatement in oracle/ bit for bit.
+#include "jaf_common.h"
+
+#define RT 16        // tile edge
+#define LCAP 768     // LDS face list capacity
+
+struct FaceRec {     // 13 x 4 bytes per face in the workspace
+    float inv[9];
+    int bb[4];       // xmin, xmax, ymin, ymax (pixel units, kernel orientation); xmin>xmax = culled
+};
+
+// verts[B,NV,3], cam[B,3] -> faces[B,NF,3,3]   (src/nmr.py:19-28,269-276 + look_at with
+// eye=(0,0,eye_z), at=0, up=+y, whose rotation is exactly the identity)
+__global__ void project_faces_kernel(const float* verts, const float* cam, const int* fidx, float* faces, int B,
+                                     int NV, int NF, float eye_z) {
+    const long total = (long)B * NF * 3;
+    const long gs = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int k = (int)(e % 3);
+        const int f = (int)((e / 3) % NF);
+        const int b = (int)(e / (3L * NF));
+        const int vi = fidx[f * 3 + k];
+        const float* v = verts + ((long)b * NV + vi) * 3;
+        const float sc = cam[b * 3], tx = cam[b * 3 + 1], ty = cam[b * 3 + 2];
+        float* o = faces + e * 3;
+        o[0] = sc * (v[0] + tx);
+        o[1] = -(sc * (v[1] + ty));
+        o[2] = v[2] - eye_z;
+    }
+}
+
+extern "C" int jaf_project_faces(jaf_stream_t s, const float* verts, const float* cam, const int32_t* faces_idx,
+                                 float* faces, int32_t B, int32_t NV, int32_t NF, float eye_z) {
+    JAF_REQUIRE(verts && cam && faces_idx && faces && B >= 1 && NV >= 1 && NF >= 1);
+    hipLaunchKernelGGL(project_faces_kernel, dim3(jaf_ew_grid((long)B * NF * 3)), dim3(256), 0, (hipStream_t)s, verts, cam, faces_idx, faces, B, NV, NF, eye_z);
+    return jaf_launch_status();
+}
+
+// rasterize_cuda_kernel.cu:24-67 plus a conservative pixel bounding box
+__global__ void raster_setup_kernel(const float* faces, FaceRec* rec, int total, int is) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float* face = faces + (long)i * 9;
+    FaceRec r;
+    for (int k = 0; k < 9; ++k) r.inv[k] = 0.f;
+    r.bb[0] = 1; r.bb[1] = 0; r.bb[2] = 1; r.bb[3] = 0;
+    const bool back = (face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0]);
+    if (!back) {
+        float p[3][2];
+        for (int num = 0; num < 3; num++)
+            for (int dim = 0; dim < 2; dim++) p[num][dim] = (float)(0.5 * (double)(face[3 * num + dim] * is + is - 1));
+        float inv[9] = {
+            p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+            p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+            p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+        const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]));
+        for (int k = 0; k < 9; ++k) r.inv[k] = inv[k] / den;
+        const float xmn = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmx = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
+        const float ymn = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymx = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
+        // clamp before the int conversion; one pixel of slack on every side
+        r.bb[0] = (int)floorf(fmaxf(xmn, -4.f)) - 1;
+        r.bb[1] = (int)ceilf(fminf(xmx, (float)is + 4.f)) + 1;
+        r.bb[2] = (int)floorf(fmaxf(ymn, -4.f)) - 1;
+        r.bb[3] = (int)ceilf(fminf(ymx, (float)is + 4.f)) + 1;
+        if (!(xmn == xmn) || !(xmx == xmx) || !(ymn == ymn) || !(ymx == ymx)) {   // NaN: keep everywhere
+            r.bb[0] = -1; r.bb[1] = is + 1; r.bb[2] = -1; r.bb[3] = is + 1;
+        }
+    }
+    rec[i] = r;
+}
+
+__global__ __launch_bounds__(256) void raster_tile_kernel(const float* faces, const FaceRec* rec, int* fim,
+                                                          float* wim, int NF, int is, float near_, float far_) {
+    __shared__ int s_list[LCAP];
+    __shared__ float s_face[LCAP * 9];
+    __shared__ float s_inv[LCAP * 9];
+    __shared__ int s_wcount[4];
+    __shared__ int s_count;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (is + RT - 1) / RT;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int bn = blockIdx.y;
+    const int xi = tx * RT + (tid % RT);
+    const int yi = ty * RT + (tid / RT);
+    const bool inside_img = xi < is && yi < is;
+    const float yp = (float)((2. * yi + 1 - is) / is);
+    const float xp = (float)((2. * xi + 1 - is) / is);
+    const int tx0 = tx * RT, tx1 = tx * RT + RT - 1, ty0 = ty * RT, ty1 = ty * RT + RT - 1;
+
+    const float* fbase = faces + (long)bn * NF * 9;
+    const FaceRec* rbase = rec + (long)bn * NF;
+
+    float depth_min = far_;
+    int face_index_min = -1;
+    float weight_min[3] = {0.f, 0.f, 0.f};
+
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+
+    for (int base = 0; base < NF; base += 256) {
+        const int f = base + tid;
+        bool ov = false;
+        if (f < NF) {
+            const int* bb = rbase[f].bb;
+            ov = bb[0] <= tx1 && bb[1] >= tx0 && bb[2] <= ty1 && bb[3] >= ty0 && bb[0] <= bb[1];
+        }
+        const unsigned long long m = __ballot(ov);
+        const int wprefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wcount[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_count;
+        for (int w = 0; w < wave; ++w) off += s_wcount[w];
+        if (ov) s_list[off + wprefix] = f;
+        __syncthreads();
+        if (tid == 0) s_count += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
+        __syncthreads();
+        const int cnt = s_count;
+        const bool last = base + 256 >= NF;
+        if (cnt > LCAP - 256 || (last && cnt > 0)) {
+            for (int e = tid; e < cnt * 9; e += 256) {
+                const int i = e / 9, k = e - i * 9;
+                const int ff = s_list[i];
+                s_face[e] = fbase[(long)ff * 9 + k];
+                s_inv[e] = rbase[ff].inv[k];
+            }
+            __syncthreads();
+            if (inside_img) {
+                for (int i = 0; i < cnt; ++i) {
+                    const float* face = s_face + i * 9;
+                    const float* face_inv = s_inv + i * 9;
+                    if (((yp - face[1]) * (face[3] - face[0]) < (xp - face[0]) * (face[4] - face[1])) ||
+                        ((yp - face[4]) * (face[6] - face[3]) < (xp - face[3]) * (face[7] - face[4])) ||
+                        ((yp - face[7]) * (face[0] - face[6]) < (xp - face[6]) * (face[1] - face[7])))
+                        continue;
+                    float w[3];
+                    w[0] = face_inv[0] * xi + face_inv[1] * yi + face_inv[2];
+                    w[1] = face_inv[3] * xi + face_inv[4] * yi + face_inv[5];
+                    w[2] = face_inv[6] * xi + face_inv[7] * yi + face_inv[8];
+                    float w_sum = 0;
+                    for (int k = 0; k < 3; k++) {
+                        w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
+                        w_sum += w[k];
+                    }
+                    for (int k = 0; k < 3; k++) w[k] /= w_sum;
+                    const float zp = (float)(1. / (double)(w[0] / face[2] + w[1] / face[5] + w[2] / face[8]));
+                    if (zp <= near_ || far_ <= zp) continue;
+                    if (zp < depth_min) {
+                        depth_min = zp;
+                        face_index_min = s_list[i];
+                        weight_min[0] = w[0]; weight_min[1] = w[1]; weight_min[2] = w[2];
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) s_count = 0;
+            __syncthreads();
+        }
+    }
+
+    if (inside_img) {
+        // vertical flip of rasterize.py:334-338 folded into the store
+        const long o = ((long)bn * is + (is - 1 - yi)) * is + xi;
+        fim[o] = face_index_min;
+        wim[o * 3 + 0] = weight_min[0];
+        wim[o * 3 + 1] = weight_min[1];
+        wim[o * 3 + 2] = weight_min[2];
+    }
+}
+
+extern "C" int64_t jaf_rasterize_workspace(int32_t B, int32_t NF, int32_t S) {
+    (void)S;
+    return (int64_t)B * NF * (int64_t)sizeof(FaceRec);
+}
+
+extern "C" int jaf_rasterize_fim_wim(jaf_stream_t s_, const float* faces, int32_t* fim, float* wim, void* workspace,
+                                     int32_t B, int32_t NF, int32_t S, float near_, float far_) {
+    JAF_REQUIRE(faces && fim && wim && workspace && B >= 1 && NF >= 1 && S >= 1 && B <= 65535);
+    hipStream_t s = (hipStream_t)s_;
+    FaceRec* rec = (FaceRec*)workspace;
+    hipLaunchKernelGGL(raster_setup_kernel, dim3(jaf_cdiv((long)B * NF, 256)), dim3(256), 0, s, faces, rec, B * NF, S);
+    const int tiles = jaf_cdiv(S, RT);
+    hipLaunchKernelGGL(raster_tile_kernel, dim3(tiles * tiles, B), dim3(256), 0, s, faces, rec, fim, wim, NF, S, near_, far_);
+    return jaf_launch_status();
+}
+
+// src/nmr.py:617-659 with src/cal_flow.py:30-31 folded in (x,y of the SOURCE faces, y negated)
+__global__ void bc_transform_kernel(const float* src_faces, const int* fim, const float* wim, float* T, int B, int NF,
+                                    int S) {
+    const long total = (long)B * S * S;
+    const long gs = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const long b = e / ((long)S * S);
+        const int f = fim[e];
+        float tx = -2.f, ty = -2.f;
+        if (f >= 0 && f < NF) {
+            const float* v = src_faces + (b * NF + f) * 9;
+            const float w0 = wim[e * 3], w1 = wim[e * 3 + 1], w2 = wim[e * 3 + 2];
+            tx = (v[0] * w0 + v[3] * w1) + v[6] * w2;
+            ty = ((-v[1]) * w0 + (-v[4]) * w1) + (-v[7]) * w2;
+        }
+        T[e * 2] = tx;
+        T[e * 2 + 1] = ty;
+    }
+}
+
+extern "C" int jaf_bc_transform(jaf_stream_t s, const float* src_faces, const int32_t* fim, const float* wim, float* T,
+                                int32_t B, int32_t NF, int32_t S) {
+    JAF_REQUIRE(src_faces && fim && wim && T && B >= 1 && NF >= 1 && S >= 1);
+    hipLaunchKernelGGL(bc_transform_kernel, dim3(jaf_ew_grid((long)B * S * S)), dim3(256), 0, (hipStream_t)s, src_faces, fim, wim, T, B, NF, S);
+    return jaf_launch_status();
+}

@@ -1,0 +1,225 @@
+// Pools, bilinear resizes and reflection padding (HBM-bound; lanes walk the contiguous W axis).
+#include "jaf_common.h"
+
+// ------------------------------------------------------------------ average pooling
+// count_include_pad=True semantics (F.avg_pool2d default, src/crn_model.py:268-273): divisor k*k.
+__global__ void avgpool_fwd_kernel(const float* x, float* y, int NC, int H, int W, int OH, int OW, int k,
+                                   int stride, int pad) {
+    const long total = (long)NC * OH * OW;
+    const long gs = (long)gridDim.x * blockDim.x;
+    const float inv = 1.0f / (float)(k * k);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int ox = (int)(e % OW);
+        const int oy = (int)((e / OW) % OH);
+        const long nc = e / ((long)OW * OH);
+        const float* p = x + nc * H * W;
+        float acc = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride - pad + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride - pad + kx;
+                if (ix < 0 || ix >= W) continue;
+                acc += p[iy * W + ix];
+            }
+        }
+        y[e] = acc * inv;
+    }
+}
+
+extern "C" int jaf_avgpool_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W,
+                               int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad) {
+    JAF_REQUIRE(x && y && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
+    JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(jaf_ew_grid((long)NC * OH * OW)), dim3(256), 0, (hipStream_t)s, x, y, NC, H, W, OH, OW, k, stride, pad);
+    return jaf_launch_status();
+}
+
+__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, int k,
+                                   int stride, int pad) {
+    const long total = (long)NC * H * W;
+    const long gs = (long)gridDim.x * blockDim.x;
+    const float inv = 1.0f / (float)(k * k);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int ix = (int)(e % W);
+        const int iy = (int)((e / W) % H);
+        const long nc = e / ((long)W * H);
+        const float* p = dy + nc * OH * OW;
+        // outputs oy with oy*stride - pad <= iy <= oy*stride - pad + k - 1
+        int oy_lo = (iy + pad - k + 1 + stride - 1);
+        oy_lo = oy_lo <= 0 ? 0 : oy_lo / stride;
+        int oy_hi = (iy + pad) / stride;
+        if (oy_hi > OH - 1) oy_hi = OH - 1;
+        int ox_lo = (ix + pad - k + 1 + stride - 1);
+        ox_lo = ox_lo <= 0 ? 0 : ox_lo / stride;
+        int ox_hi = (ix + pad) / stride;
+        if (ox_hi > OW - 1) ox_hi = OW - 1;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += p[oy * OW + ox];
+        dx[e] = acc * inv;
+    }
+}
+
+extern "C" int jaf_avgpool_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
+                               int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad) {
+    JAF_REQUIRE(dy && dx && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
+    JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(jaf_ew_grid((long)NC * H * W)), dim3(256), 0, (hipStream_t)s, dy, dx, NC, H, W, OH, OW, k, stride, pad);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ bilinear / nearest resize
+// Source-index rules of ATen upsample_bilinear2d / upsample_nearest2d (torch 2.x):
+//   align_corners: src = dst * (in-1)/(out-1);   else: src = max((dst+0.5)*in/out - 0.5, 0)
+//   nearest: src = min(floor(dst * in/out), in-1)
+struct ResizeArgs {
+    int N, C, H, W, y0, x0, ch, cw, OH, OW;
+    float sy, sx;
+    int align, nearest;
+};
+
+__device__ __forceinline__ void resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
+    float src = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l = src - (float)i0;
+}
+
+__global__ void resize_fwd_kernel(const float* x, float* y, ResizeArgs a) {
+    const long total = (long)a.N * a.C * a.OH * a.OW;
+    const long gs = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int ox = (int)(e % a.OW);
+        const int oy = (int)((e / a.OW) % a.OH);
+        const long nc = e / ((long)a.OW * a.OH);
+        const float* p = x + nc * a.H * a.W;
+        if (a.nearest) {
+            int iy = (int)floorf((float)oy * a.sy); if (iy > a.ch - 1) iy = a.ch - 1;
+            int ix = (int)floorf((float)ox * a.sx); if (ix > a.cw - 1) ix = a.cw - 1;
+            y[e] = p[(a.y0 + iy) * a.W + a.x0 + ix];
+        } else {
+            int y0, y1, x0, x1; float ly, lx;
+            resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
+            resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const float* r0 = p + (a.y0 + y0) * a.W + a.x0;
+            const float* r1 = p + (a.y0 + y1) * a.W + a.x0;
+            y[e] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        }
+    }
+}
+
+static void resize_scales(ResizeArgs& a) {
+    if (a.nearest) {
+        a.sy = (float)a.ch / (float)a.OH;
+        a.sx = (float)a.cw / (float)a.OW;
+    } else if (a.align) {
+        a.sy = a.OH > 1 ? (float)(a.ch - 1) / (float)(a.OH - 1) : 0.f;
+        a.sx = a.OW > 1 ? (float)(a.cw - 1) / (float)(a.OW - 1) : 0.f;
+    } else {
+        a.sy = (float)a.ch / (float)a.OH;
+        a.sx = (float)a.cw / (float)a.OW;
+    }
+}
+
+extern "C" int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH, int32_t OW,
+                              int align_corners, int nearest) {
+    JAF_REQUIRE(x && y && N >= 1 && C >= 1 && OH >= 1 && OW >= 1 && ch >= 1 && cw >= 1);
+    JAF_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W);
+    ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, nearest};
+    resize_scales(a);
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(jaf_ew_grid((long)N * C * OH * OW)), dim3(256), 0, (hipStream_t)s, x, y, a);
+    return jaf_launch_status();
+}
+
+// scatter form: dx must be zero-filled by the caller.
+__global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
+    const long total = (long)a.N * a.C * a.OH * a.OW;
+    const long gs = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int ox = (int)(e % a.OW);
+        const int oy = (int)((e / a.OW) % a.OH);
+        const long nc = e / ((long)a.OW * a.OH);
+        float* p = dx + nc * a.H * a.W;
+        int y0, y1, x0, x1; float ly, lx;
+        resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
+        resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float g = dy[e];
+        float* r0 = p + (a.y0 + y0) * a.W + a.x0;
+        float* r1 = p + (a.y0 + y1) * a.W + a.x0;
+        atomicAdd(&r0[x0], g * hy * hx);
+        atomicAdd(&r0[x1], g * hy * lx);
+        atomicAdd(&r1[x0], g * ly * hx);
+        atomicAdd(&r1[x1], g * ly * lx);
+    }
+}
+
+extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
+                              int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH, int32_t OW,
+                              int align_corners) {
+    JAF_REQUIRE(dy && dx && N >= 1 && C >= 1 && OH >= 1 && OW >= 1 && ch >= 1 && cw >= 1);
+    JAF_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W);
+    ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, 0};
+    resize_scales(a);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_ew_grid((long)N * C * OH * OW)), dim3(256), 0, (hipStream_t)s, dy, dx, a);
+    return jaf_launch_status();
+}
+
+// ------------------------------------------------------------------ reflection padding
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ void reflect_pad_fwd_kernel(const float* x, float* y, int NC, int H, int W, int p) {
+    const int PH = H + 2 * p, PW = W + 2 * p;
+    const long total = (long)NC * PH * PW;
+    const long gs = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int px = (int)(e % PW);
+        const int py = (int)((e / PW) % PH);
+        const long nc = e / ((long)PW * PH);
+        y[e] = x[(nc * H + reflect_idx(py - p, H)) * W + reflect_idx(px - p, W)];
+    }
+}
+
+extern "C" int jaf_reflect_pad_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W, int32_t p) {
+    JAF_REQUIRE(x && y && NC >= 1 && p >= 0 && p < H && p < W);
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(jaf_ew_grid((long)NC * (H + 2 * p) * (W + 2 * p))), dim3(256), 0, (hipStream_t)s, x, y, NC, H, W, p);
+    return jaf_launch_status();
+}
+
+// gather form of the adjoint: each input pixel sums the padded positions that mirror onto it.
+__global__ void reflect_pad_bwd_kernel(const float* dy, float* dx, int NC, int H, int W, int p) {
+    const int PH = H + 2 * p, PW = W + 2 * p;
+    const long total = (long)NC * H * W;
+    const long gs = (long)gridDim.x * blockDim.x;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const int x = (int)(e % W);
+        const int y = (int)((e / W) % H);
+        const long nc = e / ((long)W * H);
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = p + 2 * (H - 1) - y;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = p + 2 * (W - 1) - x;
+        const float* q = dy + nc * PH * PW;
+        float acc = 0.f;
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) acc += q[ys[i] * PW + xs[j]];
+        dx[e] = acc;
+    }
+}
+
+extern "C" int jaf_reflect_pad_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W, int32_t p) {
+    JAF_REQUIRE(dy && dx && NC >= 1 && p >= 0 && p < H && p < W);
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(jaf_ew_grid((long)NC * H * W)), dim3(256), 0, (hipStream_t)s, dy, dx, NC, H, W, p);
+    return jaf_launch_status();
+}

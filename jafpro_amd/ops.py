@@ -1,0 +1,779 @@
+"""torch.autograd bindings of the C-ABI kernels (include/jafpro_hip.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; every number is
+produced by libjafpro_hip.so.  All ops require contiguous fp32 GPU tensors and raise
+RuntimeError otherwise (the reference extension does the same through CHECK_CUDA /
+CHECK_CONTIGUOUS, rasterize_cuda.cpp:66-68).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch.autograd import Function
+
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DGRAD, PACK_FWD,
+                   PACK_LSTM, ConvDesc, ConvPlan, check, lib)
+
+__all__ = ["conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
+           "reflect_pad", "texture_warp", "grid_sample", "blend", "mul_bcast", "part_mask_mul",
+           "atlas_to_parts", "vgg_preprocess", "l1_loss", "bce_loss", "linear", "adam_step",
+           "project_faces", "rasterize_fim_wim", "bc_transform", "axpby", "ACT_NONE", "ACT_LRELU",
+           "ACT_RELU", "ACT_SIGMOID", "ACT_TANH"]
+
+
+# --------------------------------------------------------------------------------------------
+# plumbing
+# --------------------------------------------------------------------------------------------
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _s():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a GPU tensor (jafpro_amd has no CPU path)" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    return t
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# convolution core
+# --------------------------------------------------------------------------------------------
+_PLAN_CACHE = {}
+_PACK_CACHE = {}
+
+
+def _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, specs, w_cin_tot,
+               w_cin_off, out_ctot, out_coff, act, slope) -> ConvDesc:
+    d = ConvDesc()
+    d.N, d.G, d.Cin, d.Cout = N, G, Cin, Cout
+    d.H, d.W, d.OH, d.OW = H, W, OH, OW
+    d.KH, d.KW, d.stride = KH, KW, stride
+    d.pad_t, d.pad_l, d.dil_in = pad_t, pad_l, dil
+    d.nsrc = len(specs)
+    for i, (c, ctot, coff, gs) in enumerate(specs):
+        d.src_c[i], d.src_ctot[i], d.src_coff[i], d.src_gstride[i] = c, ctot, coff, gs
+    d.w_cin_tot, d.w_cin_off = w_cin_tot, w_cin_off
+    d.out_ctot, d.out_coff = out_ctot, out_coff
+    d.act, d.slope = act, slope
+    return d
+
+
+def _plan(key, d: ConvDesc, lstm: int) -> ConvPlan:
+    k = (key, lstm)
+    pl = _PLAN_CACHE.get(k)
+    if pl is None:
+        pl = ConvPlan()
+        check(lib().jaf_conv2d_plan(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan")
+        _PLAN_CACHE[k] = pl
+    return pl
+
+
+def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mode: int, key) -> torch.Tensor:
+    """Packs `weight` for (desc, plan, mode); cached while the tensor is not modified."""
+    ck = (weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK)
+    hit = _PACK_CACHE.get(ck)
+    if hit is not None:
+        return hit
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
+    check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
+          "jaf_conv2d_pack")
+    _PACK_CACHE[ck] = buf
+    return buf
+
+
+def _out_size(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_tot: int, mode: int,
+              bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
+              w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0):
+    if out is None:
+        out_ctot = G * Cout
+        out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
+    key = (N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, tuple(specs), w_cin_tot, w_cin_off,
+           out_ctot, out_coff, act, float(slope))
+    d = _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, specs, w_cin_tot, w_cin_off,
+                   out_ctot, out_coff, act, slope)
+    pl = _plan(key, d, 0)
+    wpk = _packed(weight, w_rows_tot, d, pl, mode, key[:17])
+    ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+    check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
+                               _p(out)), "jaf_conv2d_fwd")
+    return out
+
+
+class _ConvMeta:
+    __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
+                 "KH", "KW", "cin_tot")
+
+
+class _ConvFn(Function):
+    @staticmethod
+    def forward(ctx, weight, bias, meta: _ConvMeta, *srcs):
+        m = meta
+        y = _conv_raw(srcs, m.specs, weight, m.Cout, PACK_FWD, bias, m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW,
+                      m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope)
+        ctx.meta = m
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(weight, y if m.act != ACT_NONE else None, *srcs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        m: _ConvMeta = ctx.meta
+        weight, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        srcs = ctx.saved_tensors[2:]
+        dy = _c(dy)
+        L = lib()
+        if m.act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
+        else:
+            dz = dy
+        dsrcs: List[Optional[torch.Tensor]] = []
+        pad_d = m.KH - 1 - m.pad
+        coff = 0
+        for i, t in enumerate(srcs):
+            c, ctot, _, gs = m.specs[i]
+            if ctx.needs_input_grad[3 + i]:
+                # transposed convolution: rows = this source's channels, reduction = Cout
+                spec = [(m.Cout, m.G * m.Cout, 0, m.Cout)]
+                g = _conv_raw([dz], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
+                              m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0)
+                if gs == 0:      # source shared by all groups: sum the per-group gradients
+                    g = g.view(m.N, m.G, c, m.H, m.W).sum(1)
+                dsrcs.append(g)
+            else:
+                dsrcs.append(None)
+            coff += c
+        dw = db = None
+        if ctx.needs_input_grad[0]:
+            dw = torch.empty_like(weight)
+            d = _make_desc(m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW, m.KH, m.KW, m.stride, m.pad, m.pad, 1,
+                           m.specs, m.cin_tot, 0, m.G * m.Cout, 0, ACT_NONE, 0.0)
+            ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+            check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 0), "jaf_conv2d_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            db = torch.empty(m.G * m.Cout, device=dy.device, dtype=torch.float32)
+            check(L.jaf_channel_sum(_s(), _p(dz), m.N, m.G * m.Cout, 0, m.G * m.Cout, m.OH * m.OW, _p(db), 0),
+                  "jaf_channel_sum")
+        return (dw, db, None) + tuple(dsrcs)
+
+
+def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0,
+           act: int = ACT_NONE, slope: float = 0.0, groups: int = 1, shared: Optional[Sequence[bool]] = None):
+    """Grouped convolution over the channel concatenation of `srcs` with fused bias + activation.
+
+    srcs[i]: [N, groups*c_i, H, W] (or [N, c_i, H, W] when shared[i]: every group reads the same
+    channels).  weight: [groups*Cout, sum(c_i), KH, KW] or [groups, Cout, sum(c_i), KH, KW].
+    """
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    srcs = [_chk(t, "conv2d source") for t in srcs]
+    _chk(weight, "conv2d weight")
+    if bias is not None:
+        _chk(bias, "conv2d bias")
+    G = groups
+    if shared is None:
+        shared = [False] * len(srcs)
+    m = _ConvMeta()
+    KH, KW = int(weight.shape[-2]), int(weight.shape[-1])
+    cin_tot = int(weight.shape[-3])
+    Cout = int(weight.numel() // (cin_tot * KH * KW)) // G
+    N, _, H, W = srcs[0].shape
+    specs = []
+    for t, sh in zip(srcs, shared):
+        if t.shape[0] != N or t.shape[2] != H or t.shape[3] != W:
+            raise RuntimeError("conv2d sources disagree in shape")
+        ct = int(t.shape[1])
+        if sh:
+            specs.append((ct, ct, 0, 0))
+        else:
+            if ct % G:
+                raise RuntimeError("source channels not divisible by groups")
+            specs.append((ct // G, ct, 0, ct // G))
+    Cin = sum(s[0] for s in specs)
+    if Cin != cin_tot:
+        raise RuntimeError("conv2d: weight expects %d input channels, sources provide %d" % (cin_tot, Cin))
+    m.G, m.stride, m.pad, m.act, m.slope = G, stride, pad, act, float(slope)
+    m.specs, m.N, m.Cin, m.Cout, m.H, m.W = specs, int(N), Cin, Cout, int(H), int(W)
+    m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
+    return _ConvFn.apply(weight, bias, m, *srcs)
+
+
+def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=0.0, groups=1):
+    """One-thread-per-output cross-check kernel (tests only)."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    G = groups
+    KH, KW = int(weight.shape[-2]), int(weight.shape[-1])
+    cin_tot = int(weight.shape[-3])
+    Cout = int(weight.numel() // (cin_tot * KH * KW)) // G
+    N, _, H, W = srcs[0].shape
+    specs = [(int(t.shape[1]) // G, int(t.shape[1]), 0, int(t.shape[1]) // G) for t in srcs]
+    OH, OW = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad)
+    d = _make_desc(int(N), G, cin_tot, Cout, int(H), int(W), OH, OW, KH, KW, stride, pad, pad, 1, specs, cin_tot, 0,
+                   G * Cout, 0, act, slope)
+    out = torch.empty((N, G * Cout, OH, OW), device=srcs[0].device, dtype=torch.float32)
+    ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+    check(lib().jaf_conv2d_fwd_direct(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(weight), _p(bias), _p(out)),
+          "jaf_conv2d_fwd_direct")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# ConvLSTM (whole sequence, one autograd node; BPTT in backward)
+# --------------------------------------------------------------------------------------------
+class _ConvLSTMFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, G: int, need_all: bool):
+        # x: [T, N, G*C, H, W]; weight: [G*4C, 2C, 3, 3]; bias [G*4C]
+        T, N, GC, H, W = x.shape
+        C = GC // G
+        L = lib()
+        keep = any(ctx.needs_input_grad[:3])
+        hs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
+        cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
+        gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.float32) if keep else None
+        for t in range(T):
+            first = t == 0
+            specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
+            Cin = C if first else 2 * C
+            key = ("lstm", N, G, Cin, C, H, W)
+            d = _make_desc(N, G, Cin, 4 * C, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, 2 * C, 0, 4 * GC, 0, ACT_NONE, 0.0)
+            pl = _plan(key, d, 1)
+            wpk = _packed(weight, 4 * C, d, pl, PACK_LSTM, key)
+            check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
+                                          None if first else _p(hs[t - 1]), _p(wpk), _p(bias),
+                                          None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
+                                          _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd")
+        ctx.G = G
+        ctx.need_all = need_all
+        if keep:
+            ctx.save_for_backward(x, weight, hs, cs, gates)
+        c_last = cs[T - 1].clone()
+        ctx.mark_non_differentiable(c_last)
+        if need_all:
+            return hs, c_last
+        return hs[T - 1], c_last
+
+    @staticmethod
+    def backward(ctx, dh_out, _dc_unused=None):
+        x, weight, hs, cs, gates = ctx.saved_tensors
+        G = ctx.G
+        T, N, GC, H, W = x.shape
+        C = GC // G
+        L = lib()
+        dh_out = _c(dh_out)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(weight)
+        db = torch.empty(4 * GC, device=x.device, dtype=torch.float32)
+        dc = None
+        dh = None
+        for t in range(T - 1, -1, -1):
+            first = t == 0
+            if ctx.need_all:
+                dht = dh_out[t] if dh is None else dh_out[t] + dh
+            else:
+                dht = dh_out if t == T - 1 else dh
+            dht = _c(dht)
+            dc_prev = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
+            gt = gates[t]      # overwritten with the pre-activation gate gradients
+            check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
+                                           None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev)),
+                  "jaf_convlstm_gates_bwd")
+            # weight / bias gradients (accumulated over t)
+            specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
+            Cin = C if first else 2 * C
+            d = _make_desc(N, G, Cin, 4 * C, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, 2 * C, 0, 4 * GC, 0, ACT_NONE, 0.0)
+            acc = 0 if t == T - 1 else 1
+            check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None, _p(gt),
+                                     _p(dw), acc), "jaf_conv2d_wgrad")
+            check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), acc), "jaf_channel_sum")
+            gspec = [(4 * C, 4 * GC, 0, 4 * C)]
+            if dx is not None:
+                _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1, 1,
+                          2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0)
+            if not first:
+                dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
+                               1, 2 * C, C, ACT_NONE, 0.0)
+            dc = dc_prev
+        return dx, dw, db, None, None
+
+
+def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int = 1, return_all: bool = False):
+    """x: [T, N, G*C, H, W] -> (h_T [N, G*C, H, W] or all h_t, c_T).  Zero initial state
+    (src/convLSTM.py:58-63,119-120); gate order i,f,o,g (:46).  c_T carries no gradient."""
+    _chk(x, "convlstm x"); _chk(weight, "convlstm weight"); _chk(bias, "convlstm bias")
+    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all)
+
+
+# --------------------------------------------------------------------------------------------
+# normalisation
+# --------------------------------------------------------------------------------------------
+class _LayerNormLReLUFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float, slope: float):
+        N, C, H, W = x.shape
+        L = lib()
+        ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
+        stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
+        check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")
+        y = torch.empty_like(x)
+        check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
+              "jaf_layernorm_lrelu_fwd")
+        ctx.eps, ctx.slope = eps, slope
+        ctx.save_for_backward(x, gamma, beta, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        N, C, H, W = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(beta)
+        ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
+        check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
+                                            _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
+              "jaf_layernorm_lrelu_bwd")
+        return dx, dgamma, dbeta, None, None
+
+
+def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01):
+    _chk(x, "layernorm x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope)
+
+
+class _BatchNormActFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training: bool, act: int, slope: float, residual,
+                eps: float, momentum: float):
+        N, C, H, W = x.shape
+        L = lib()
+        stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        check(L.jaf_batchnorm_stats(_s(), _p(x), N, C, H * W, eps, momentum, _p(running_mean), _p(running_var),
+                                    _p(stats), 1 if training else 0), "jaf_batchnorm_stats")
+        y = torch.empty_like(x)
+        check(L.jaf_batchnorm_act_fwd(_s(), _p(x), _p(stats), _p(weight), _p(bias), _p(residual), _p(y), N, C, H * W,
+                                      act, slope), "jaf_batchnorm_act_fwd")
+        ctx.cfg = (training, act, slope, residual is not None)
+        ctx.save_for_backward(x, y, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, stats = ctx.saved_tensors
+        training, act, slope, has_res = ctx.cfg
+        N, C, H, W = x.shape
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(weight)
+        db = torch.empty_like(weight)
+        check(lib().jaf_batchnorm_act_bwd(_s(), _p(dy), _p(x), _p(y), _p(stats), _p(weight), _p(dx), _p(dw), _p(db), N,
+                                          C, H * W, act, slope, 1 if training else 0), "jaf_batchnorm_act_bwd")
+        return dx, dw, db, None, None, None, None, None, (dy if has_res else None), None, None
+
+
+def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, act=ACT_NONE, slope=0.0, residual=None,
+                  eps=1e-5, momentum=0.1):
+    _chk(x, "batchnorm x")
+    if residual is not None:
+        _chk(residual, "residual")
+    return _BatchNormActFn.apply(x, weight, bias, running_mean, running_var, training, act, slope, residual, eps,
+                                 momentum)
+
+
+# --------------------------------------------------------------------------------------------
+# resampling
+# --------------------------------------------------------------------------------------------
+class _AvgPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, k, stride, pad):
+        N, C, H, W = x.shape
+        OH, OW = _out_size(H, k, stride, pad), _out_size(W, k, stride, pad)
+        y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32)
+        check(lib().jaf_avgpool_fwd(_s(), _p(x), _p(y), N * C, H, W, OH, OW, k, stride, pad), "jaf_avgpool_fwd")
+        ctx.cfg = (N, C, H, W, OH, OW, k, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, OH, OW, k, stride, pad = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        check(lib().jaf_avgpool_bwd(_s(), _p(dy), _p(dx), N * C, H, W, OH, OW, k, stride, pad), "jaf_avgpool_bwd")
+        return dx, None, None, None
+
+
+def avg_pool(x, k: int, stride: int, pad: int):
+    return _AvgPoolFn.apply(_chk(x, "avg_pool x"), k, stride, pad)
+
+
+class _ResizeFn(Function):
+    @staticmethod
+    def forward(ctx, x, OH, OW, align, nearest, crop):
+        N, C, H, W = x.shape
+        y0, x0, ch, cw = crop if crop is not None else (0, 0, H, W)
+        y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32)
+        check(lib().jaf_resize_fwd(_s(), _p(x), _p(y), N, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0,
+                                   1 if nearest else 0), "jaf_resize_fwd")
+        ctx.cfg = (N, C, H, W, y0, x0, ch, cw, OH, OW, align, nearest)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, y0, x0, ch, cw, OH, OW, align, nearest = ctx.cfg
+        if nearest:
+            raise RuntimeError("nearest resize has no backward on this path")
+        dy = _c(dy)
+        dx = torch.zeros((N, C, H, W), device=dy.device, dtype=torch.float32)
+        check(lib().jaf_resize_bwd(_s(), _p(dy), _p(dx), N, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0),
+              "jaf_resize_bwd")
+        return dx, None, None, None, None, None
+
+
+def resize(x, size: Tuple[int, int], align_corners: bool, nearest: bool = False, crop=None):
+    """Bilinear (or nearest) resize of x (optionally of the crop window (y0, x0, h, w))."""
+    return _ResizeFn.apply(_chk(x, "resize x"), int(size[0]), int(size[1]), bool(align_corners), bool(nearest), crop)
+
+
+class _ReflectPadFn(Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, H + 2 * p, W + 2 * p), device=x.device, dtype=torch.float32)
+        check(lib().jaf_reflect_pad_fwd(_s(), _p(x), _p(y), N * C, H, W, p), "jaf_reflect_pad_fwd")
+        ctx.cfg = (N, C, H, W, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, p = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        check(lib().jaf_reflect_pad_bwd(_s(), _p(dy), _p(dx), N * C, H, W, p), "jaf_reflect_pad_bwd")
+        return dx, None
+
+
+def reflect_pad(x, p: int):
+    return _ReflectPadFn.apply(_chk(x, "reflect_pad x"), p)
+
+
+# --------------------------------------------------------------------------------------------
+# gathers and blends
+# --------------------------------------------------------------------------------------------
+class _TextureWarpFn(Function):
+    @staticmethod
+    def forward(ctx, tex, iuv, align):
+        B, C, TH, TW = tex.shape
+        S = iuv.shape[1]
+        out = torch.empty((B, 3, S, S), device=tex.device, dtype=torch.float32)
+        check(lib().jaf_texture_warp_fwd(_s(), _p(tex), _p(iuv), _p(out), B, S, TH, TW, 1 if align else 0),
+              "jaf_texture_warp_fwd")
+        ctx.cfg = (B, S, TH, TW, align)
+        ctx.save_for_backward(iuv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (iuv,) = ctx.saved_tensors
+        B, S, TH, TW, align = ctx.cfg
+        dout = _c(dout)
+        dtex = torch.zeros((B, 72, TH, TW), device=dout.device, dtype=torch.float32)
+        check(lib().jaf_texture_warp_bwd(_s(), _p(dout), _p(iuv), _p(dtex), B, S, TH, TW, 1 if align else 0),
+              "jaf_texture_warp_bwd")
+        return dtex, None, None
+
+
+def texture_warp(tex: torch.Tensor, iuv255: torch.Tensor, align_corners: bool = False):
+    """tex [B, 72, 200, 200] (24 parts x 3), iuv255 uint8 [B, S, S, 3] -> [B, 3, S, S]."""
+    _chk(tex, "texture_warp tex")
+    _chk(iuv255, "texture_warp iuv", torch.uint8)
+    if tex.shape[1] != 72 or iuv255.dim() != 4 or iuv255.shape[3] != 3 or iuv255.shape[1] != iuv255.shape[2]:
+        raise RuntimeError("texture_warp: bad shapes %s %s" % (tuple(tex.shape), tuple(iuv255.shape)))
+    return _TextureWarpFn.apply(tex, iuv255, align_corners)
+
+
+def grid_sample(src, grid, padding_border: bool, align_corners: bool = False):
+    """Forward-only bilinear grid_sample (the flow warp carries no gradient on this path)."""
+    _chk(src, "grid_sample src"); _chk(grid, "grid_sample grid")
+    B, C, H, W = src.shape
+    OH, OW = grid.shape[1], grid.shape[2]
+    out = torch.empty((B, C, OH, OW), device=src.device, dtype=torch.float32)
+    check(lib().jaf_grid_sample_fwd(_s(), _p(src), _p(grid), _p(out), B, C, H, W, OH, OW, 1 if padding_border else 0,
+                                    1 if align_corners else 0), "jaf_grid_sample_fwd")
+    return out
+
+
+class _BlendFn(Function):
+    @staticmethod
+    def forward(ctx, a, b, m):
+        N, C, H, W = a.shape
+        out = torch.empty_like(a)
+        check(lib().jaf_blend_fwd(_s(), _p(a), _p(b), _p(m), _p(out), N, C, H * W), "jaf_blend_fwd")
+        ctx.save_for_backward(a, b, m)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b, m = ctx.saved_tensors
+        N, C, H, W = a.shape
+        dout = _c(dout)
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        dm = torch.empty_like(m) if ctx.needs_input_grad[2] else None
+        check(lib().jaf_blend_bwd(_s(), _p(dout), _p(a), _p(b), _p(m), _p(da), _p(db), _p(dm), N, C, H * W),
+              "jaf_blend_bwd")
+        return da, db, dm
+
+
+def blend(a, b, m):
+    """a*m + b*(1-m); m is [N,1,H,W]."""
+    return _BlendFn.apply(_chk(a, "blend a"), _chk(b, "blend b"), _chk(m, "blend m"))
+
+
+class _MulBcastFn(Function):
+    @staticmethod
+    def forward(ctx, x, m):
+        N, C, H, W = x.shape
+        out = torch.empty_like(x)
+        check(lib().jaf_mul_bcast(_s(), _p(x), _p(m), _p(out), N, C, m.shape[1], H * W), "jaf_mul_bcast")
+        ctx.save_for_backward(m)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (m,) = ctx.saved_tensors
+        dout = _c(dout)
+        N, C, H, W = dout.shape
+        dx = torch.empty_like(dout)
+        check(lib().jaf_mul_bcast(_s(), _p(dout), _p(m), _p(dx), N, C, m.shape[1], H * W), "jaf_mul_bcast")
+        return dx, None
+
+
+def mul_bcast(x, m):
+    """x * m with m [N,1,H,W] or [N,C,H,W] (m carries no gradient: masks are data)."""
+    return _MulBcastFn.apply(_chk(x, "mul x"), _chk(m, "mul m"))
+
+
+class _PartMaskMulFn(Function):
+    @staticmethod
+    def forward(ctx, tex, masks, used):
+        B, PC, PS, _ = tex.shape
+        T, AH, AW = masks.shape[1], masks.shape[2], masks.shape[3]
+        out = torch.empty_like(tex)
+        check(lib().jaf_part_mask_mul(_s(), _p(tex), _p(masks), _p(used), _p(out), B, T, AH, AW, PC // 3, PS),
+              "jaf_part_mask_mul")
+        ctx.save_for_backward(masks, used)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        masks, used = ctx.saved_tensors
+        dout = _c(dout)
+        B, PC, PS, _ = dout.shape
+        T, AH, AW = masks.shape[1], masks.shape[2], masks.shape[3]
+        dx = torch.empty_like(dout)
+        check(lib().jaf_part_mask_mul(_s(), _p(dout), _p(masks), _p(used), _p(dx), B, T, AH, AW, PC // 3, PS),
+              "jaf_part_mask_mul")
+        return dx, None, None
+
+
+def part_mask_mul(tex, masks, used):
+    """tex [B,72,200,200] * OR_t(masks[b,t] & used[t]) cut per part (train/4...py:283-298)."""
+    _chk(tex, "tex"); _chk(masks, "masks"); _chk(used, "used", torch.int32)
+    return _PartMaskMulFn.apply(tex, masks, used)
+
+
+def atlas_to_parts(atlas: torch.Tensor, psz: int = 200) -> torch.Tensor:
+    """atlas [B,T,3,AH,AW] -> [T*B, 24*3, psz, psz] (image t*B+b), train/4...py:269-276."""
+    _chk(atlas, "atlas")
+    B, T, _, AH, AW = atlas.shape
+    P = (AH // psz) * (AW // psz)
+    out = torch.empty((T * B, P * 3, psz, psz), device=atlas.device, dtype=torch.float32)
+    check(lib().jaf_atlas_to_parts(_s(), _p(atlas), _p(out), B, T, AH, AW, psz), "jaf_atlas_to_parts")
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# losses / classifier / optimiser
+# --------------------------------------------------------------------------------------------
+class _VggPreFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        y = torch.empty_like(x)
+        check(lib().jaf_vgg_preprocess(_s(), _p(x), _p(y), N, H * W), "jaf_vgg_preprocess")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        check(lib().jaf_axpby(_s(), 127.5, _p(dy), 0.0, _p(dx), dy.numel()), "jaf_axpby")
+        return dx
+
+
+def vgg_preprocess(x):
+    x = _chk(x, "vgg_preprocess x")
+    if x.shape[1] != 3:
+        raise RuntimeError("vgg_preprocess expects 3 channels")
+    return _VggPreFn.apply(x)
+
+
+class _L1Fn(Function):
+    @staticmethod
+    def forward(ctx, a, b, w):
+        loss = torch.zeros(1, device=a.device, dtype=torch.float32)
+        check(lib().jaf_l1_loss_fwd(_s(), _p(a), _p(b), a.numel(), w, _p(loss)), "jaf_l1_loss_fwd")
+        ctx.w = w
+        ctx.save_for_backward(a, b)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        a, b = ctx.saved_tensors
+        dloss = _c(dloss)
+        da = torch.empty_like(a)
+        check(lib().jaf_l1_loss_bwd(_s(), _p(a), _p(b), a.numel(), ctx.w, _p(dloss), _p(da), 0), "jaf_l1_loss_bwd")
+        return da, None, None
+
+
+def l1_loss(a, b, weight: float = 1.0):
+    """weight * mean|a-b| as a 1-element tensor; gradient flows to `a` only (b is the detached
+    target branch, src/networks.py:106)."""
+    _chk(a, "l1 a"); _chk(b, "l1 b")
+    if a.shape != b.shape:
+        raise RuntimeError("l1_loss shape mismatch")
+    return _L1Fn.apply(a, b, float(weight))
+
+
+class _BCEFn(Function):
+    @staticmethod
+    def forward(ctx, p, target):
+        loss = torch.empty(1, device=p.device, dtype=torch.float32)
+        check(lib().jaf_bce_fwd(_s(), _p(p), p.numel(), target, _p(loss)), "jaf_bce_fwd")
+        ctx.target = target
+        ctx.save_for_backward(p)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (p,) = ctx.saved_tensors
+        dloss = _c(dloss)
+        dp = torch.empty_like(p)
+        check(lib().jaf_bce_bwd(_s(), _p(p), p.numel(), ctx.target, _p(dloss), _p(dp)), "jaf_bce_bwd")
+        return dp, None
+
+
+def bce_loss(p, target: float):
+    """nn.BCELoss()(p, full_like(p, target)) -> 1-element tensor."""
+    return _BCEFn.apply(_chk(p, "bce p"), float(target))
+
+
+class _LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act, slope):
+        N, I = x.shape
+        O = w.shape[0]
+        y = torch.empty((N, O), device=x.device, dtype=torch.float32)
+        check(lib().jaf_linear_fwd(_s(), _p(x), _p(w), _p(b), _p(y), N, I, O, act, slope), "jaf_linear_fwd")
+        ctx.cfg = (act, slope)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, slope = ctx.cfg
+        N, I = x.shape
+        O = w.shape[0]
+        dy = _c(dy)
+        L = lib()
+        if act != ACT_NONE:
+            dz = torch.empty_like(dy)
+            check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), act, slope), "jaf_act_bwd")
+        else:
+            dz = dy
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(O, device=x.device, dtype=torch.float32)
+        check(L.jaf_linear_bwd(_s(), _p(dz), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, I, O), "jaf_linear_bwd")
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b, act=ACT_NONE, slope=0.0):
+    return _LinearFn.apply(_chk(x, "linear x"), _chk(w, "linear w"), _chk(b, "linear b"), act, float(slope))
+
+
+def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8):
+    """In-place torch.optim.Adam update of a flat parameter buffer."""
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, "adam " + n)
+    check(lib().jaf_adam_step(_s(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step),
+          "jaf_adam_step")
+    invalidate_packed_weights()
+
+
+def invalidate_packed_weights():
+    """Weights written behind torch's back (the Adam kernel, RCCL broadcasts) do not bump
+    tensor._version, so the packed-weight cache is dropped explicitly."""
+    _PACK_CACHE.clear()
+
+
+def axpby(a: float, x, b: float, y):
+    """y = a*x + b*y in place."""
+    check(lib().jaf_axpby(_s(), a, _p(_chk(x, "x")), b, _p(_chk(y, "y")), x.numel()), "jaf_axpby")
+    return y
+
+
+# --------------------------------------------------------------------------------------------
+# renderer path (forward only: vertices carry no gradient in stage 4)
+# --------------------------------------------------------------------------------------------
+def project_faces(verts, cam, faces_idx, eye_z: float):
+    _chk(verts, "verts"); _chk(cam, "cam"); _chk(faces_idx, "faces", torch.int32)
+    B, NV, _ = verts.shape
+    NF = faces_idx.shape[0]
+    out = torch.empty((B, NF, 3, 3), device=verts.device, dtype=torch.float32)
+    check(lib().jaf_project_faces(_s(), _p(verts), _p(cam), _p(faces_idx), _p(out), B, NV, NF, eye_z),
+          "jaf_project_faces")
+    return out
+
+
+def rasterize_fim_wim(faces, image_size: int, near: float = 0.1, far: float = 100.0):
+    _chk(faces, "faces")
+    B, NF = faces.shape[0], faces.shape[1]
+    L = lib()
+    ws = torch.empty(int(L.jaf_rasterize_workspace(B, NF, image_size)), device=faces.device, dtype=torch.uint8)
+    fim = torch.empty((B, image_size, image_size), device=faces.device, dtype=torch.int32)
+    wim = torch.empty((B, image_size, image_size, 3), device=faces.device, dtype=torch.float32)
+    check(L.jaf_rasterize_fim_wim(_s(), _p(faces), _p(fim), _p(wim), _p(ws), B, NF, image_size, near, far),
+          "jaf_rasterize_fim_wim")
+    return fim, wim
+
+
+def bc_transform(src_faces, fim, wim):
+    _chk(src_faces, "src_faces"); _chk(fim, "fim", torch.int32); _chk(wim, "wim")
+    B, NF = src_faces.shape[0], src_faces.shape[1]
+    S = fim.shape[1]
+    T = torch.empty((B, S, S, 2), device=fim.device, dtype=torch.float32)
+    check(lib().jaf_bc_transform(_s(), _p(src_faces), _p(fim), _p(wim), _p(T), B, NF, S), "jaf_bc_transform")
+    return T
