@@ -1,0 +1,229 @@
+"""Stage-4 harnesses on the HIP modules: the train step (counterpart of
+train/4.convLSTM_flowpro_interval.py:206-413) and the forward-only clip loop (counterpart of
+test/conv_pro_test.py:219-279).
+
+The reference scripts cannot run on torch >= 1.7 and do their work on nested Python
+lists with a device round trip per sample; this harness keeps the same op sequence and the same
+quirks -- three discriminator updates on ACCUMULATING gradients (F10), the face GAN term on a
+detached crop (:399), BatchNorm in train mode in the propagater (F9), fresh noise in the
+background input (:231, passed in as data) -- on grouped device tensors.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .cal_flow import float_estimate
+from .crn_model import CRN_smaller
+from .flow_net import Propagation3DFlowNet
+from .networks import (Accumulate_LSTM_no_loss, FaceDiscriminator, ImageDiscriminator, UNet_inpainter,
+                       VGG_l1_loss)
+
+LRS = {"accu": 1e-5, "inpaint": 1e-5, "refine": 1e-5, "flow": 5e-5, "D": 3e-6, "face": 1e-6}   # :169-175
+
+
+class FlatParams:
+    """All parameters of a module in ONE contiguous buffer (and one gradient buffer): Adam is a
+    single launch over it and the RCCL all-reduce a single message per module."""
+
+    def __init__(self, module: nn.Module):
+        ps = [p for p in module.parameters() if p.requires_grad]
+        sizes = [(p.numel() + 3) // 4 * 4 for p in ps]          # keep every view 16-byte aligned
+        total = sum(sizes)
+        dev = ps[0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.m = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.v = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        for p, sz in zip(ps, sizes):
+            n = p.numel()
+            self.flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + n].view(p.shape)
+            p.grad = self.grad[off:off + n].view(p.shape)
+            off += sz
+        self.params = ps
+        self.step_count = 0
+        ops.invalidate_packed_weights()
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def adam(self, lr: float):
+        self.step_count += 1
+        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count)
+
+
+class Stage4Models(nn.Module):
+    def __init__(self, faces: np.ndarray, image_size: int = 256):
+        super().__init__()
+        self.Accu_model = Accumulate_LSTM_no_loss()
+        self.inpaint_model = UNet_inpainter()
+        self.bg_model = CRN_smaller(3)
+        self.refine_model = CRN_smaller(3, fg=True)
+        self.flow_calculator = float_estimate(faces=faces, image_size=image_size)
+        self.propagater = Propagation3DFlowNet(9, 32, 2, 3, use_deconv=False)
+        self.discriminator = ImageDiscriminator(ndf=32, input_channel=6)
+        self.F_Discriminator = FaceDiscriminator(ndf=32, input_channel=6)
+        self.loss_criterion = VGG_l1_loss()
+        self.image_size = image_size
+
+    def set_train_modes(self):
+        """train/4...py:185-191: everything .train() except the frozen background CRN."""
+        self.train()
+        self.bg_model.eval()
+        for p in self.bg_model.parameters():
+            p.requires_grad = False
+
+
+def _to_dev(batch: Dict[str, np.ndarray], device) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in batch.items():
+        out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device) if isinstance(v, np.ndarray) else v
+    return out
+
+
+def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequence[int], prosrc: int,
+                      align_corners: bool = False) -> Dict[str, torch.Tensor]:
+    """train/4...py:269-331 (== test/conv_pro_test.py:219-279 for one target frame)."""
+    B, T_all = b["src_img"].shape[0], b["src_img"].shape[1]
+    S = M.image_size
+    used = list(used)
+    tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
+    x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
+    accu = M.Accu_model.forward_grouped(x, len(used))                           # :278
+    flags = torch.zeros(T_all, dtype=torch.int32)
+    flags[used] = 1
+    masked = ops.part_mask_mul(accu, b["src_mask_im"].contiguous(), flags.to(accu.device))   # :283-298
+    inpaint = M.inpaint_model.forward_grouped(masked)                           # :300
+    inpaint_warp = ops.texture_warp(inpaint, b["tgt_IUV255"], align_corners)    # :309-312
+    refine_output, fg_mask = M.refine_model(inpaint_warp, S)                    # :318
+    src0 = b["src_img"][:, 0].contiguous()
+    bg_mask = 1.0 - b["src_mask_in_image0"]                                     # :230-231 (input prep)
+    bg_incomplete = (bg_mask * src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
+    with torch.no_grad():
+        bg_output = M.bg_model(bg_incomplete, S)                                # :319-320
+    fusion = ops.blend(refine_output, bg_output, fg_mask)                       # :321
+    prev_img = b["src_img"][:, prosrc].contiguous()
+    tsf = M.flow_calculator(prev_img, [b["src_cam"], None, b["src_verts"], None],
+                            [b["tgt_cam"], None, b["tgt_verts"], None])          # :325
+    pro = M.propagater({"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
+                        "tgt_smpl_mask": b["smpl_real_mask"], "tgt_IUV": b["tgt_IUV"], "use_IUV": True})
+    return {"final_output": pro["pred_target"], "final_mask": pro["weight"], "fusion_output": fusion,
+            "refine_output": refine_output, "fg_mask": fg_mask, "bg_output": bg_output, "tsf_image": tsf,
+            "inpaint_warp": inpaint_warp, "inpaint": inpaint, "accu": accu}
+
+
+def face_crops(final, tgt_img, tgt_IUV, bbox: np.ndarray):
+    """train/4...py:338-353.  bbox rows are (x0, x1, y0, y1) host integers (they originate on the
+    host, src/data.py:702-716, so no device sync is needed); x0 == x1 marks an invalid face."""
+    fp, fr, fi = [], [], []
+    for i in range(final.shape[0]):
+        x0, x1, y0, y1 = (int(v) for v in bbox[i])
+        if x0 == x1:
+            continue
+        crop = (y0, x0, y1 - y0, x1 - x0)
+        fp.append(ops.resize(final[i:i + 1], (64, 64), False, crop=crop))
+        fr.append(ops.resize(tgt_img[i:i + 1].contiguous(), (64, 64), False, crop=crop))
+        fi.append(ops.resize(tgt_IUV[i:i + 1].contiguous(), (64, 64), False, nearest=True, crop=crop))
+    if not fp:
+        raise RuntimeError("no valid face box in the batch (the reference crashes here too, :351)")
+    return torch.cat(fp, 0), torch.cat(fr, 0), torch.cat(fi, 0)
+
+
+class Stage4Trainer:
+    def __init__(self, models: Stage4Models, reducer=None, lrs: Optional[Dict[str, float]] = None):
+        self.M = models
+        self.M.set_train_modes()
+        self.lrs = dict(LRS if lrs is None else lrs)
+        self.flat = {
+            "accu": FlatParams(models.Accu_model), "inpaint": FlatParams(models.inpaint_model),
+            "refine": FlatParams(models.refine_model), "flow": FlatParams(models.propagater),
+            "D": FlatParams(models.discriminator), "face": FlatParams(models.F_Discriminator),
+        }
+        self.reducer = reducer          # jafpro_amd.dist.GradReducer or None (single GPU)
+
+    def _reduce(self, names: Sequence[str]):
+        if self.reducer is not None:
+            self.reducer.all_reduce_mean([self.flat[n].grad for n in names])
+
+    def train_step(self, batch: Dict[str, torch.Tensor], used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0,
+                   align_corners: bool = False) -> Dict[str, torch.Tensor]:
+        M, b = self.M, batch
+        for f in self.flat.values():                                             # :206-212
+            f.zero_grad()
+        g = generator_forward(M, b, used, prosrc, align_corners)
+        final = g["final_output"]
+        target = b["tgt_img"].contiguous()
+        loss = M.loss_criterion(final, target)                                   # :332
+        face_pred, face_real, face_IUV = face_crops(final, target, b["tgt_IUV"], b["face_bbox"])
+        src0 = b["src_img"][:, 0].contiguous()
+        face_pred_d = face_pred.detach()
+        # ---- face discriminator, one update (:362-374)
+        F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
+        F_errD_real.backward()
+        F_errD_fake = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 0.0)
+        F_errD_fake.backward()
+        self._reduce(["face"])
+        self.flat["face"].adam(self.lrs["face"])
+        # ---- image discriminator, three updates on accumulating grads (:380-394, F10)
+        final_d = final.detach()
+        for _ in range(3):
+            errD_real = ops.bce_loss(M.discriminator([target, src0]), 1.0)
+            errD_real.backward()
+            errD_fake = ops.bce_loss(M.discriminator([final_d, src0]), 0.0)
+            errD_fake.backward()
+            self._reduce(["D"])
+            self.flat["D"].adam(self.lrs["D"])
+        # ---- generator (:398-413)
+        errG = ops.bce_loss(M.discriminator([final, src0]), 1.0)
+        F_errG = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0)
+        total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
+        total.backward()
+        self._reduce(["flow", "refine", "inpaint", "accu"])                      # reverse graph order
+        for n in ("accu", "inpaint", "refine", "flow"):
+            self.flat[n].adam(self.lrs[n])
+        return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),
+                "errG": errG.detach(), "F_errD": (F_errD_real + F_errD_fake).detach(), "F_errG": F_errG.detach(),
+                "final_output": final_d}
+
+
+@torch.no_grad()
+def forward_clip(M: Stage4Models, clip: Dict[str, torch.Tensor], used: Sequence[int] = (0, 1, 2, 3),
+                 align_corners: bool = False) -> torch.Tensor:
+    """Forward-only clip loop, test/conv_pro_test.py:219-279: accumulate + inpaint + background
+    once per clip, then per target frame warp -> refine -> blend -> flow -> propagate.
+    clip tensors: src_* as in a stage-4 batch with B clips; per-frame tensors carry an extra
+    frame axis: tgt_IUV255 [B,F,S,S,3], tgt_IUV [B,F,3,S,S], smpl_real_mask [B,F,3,S,S],
+    tgt_verts [B,F,NV,3], tgt_cam [B,F,3].  The propagater stays in train mode.
+    Returns pred_target [B,F,3,S,S]."""
+    S = M.image_size
+    B, T_all = clip["src_img"].shape[0], clip["src_img"].shape[1]
+    used = list(used)
+    tex = clip["src_texture_im"] if len(used) == T_all else clip["src_texture_im"][:, used].contiguous()
+    accu = M.Accu_model.forward_grouped(ops.atlas_to_parts(tex.contiguous()), len(used))
+    flags = torch.zeros(T_all, dtype=torch.int32)
+    flags[used] = 1
+    masked = ops.part_mask_mul(accu, clip["src_mask_im"].contiguous(), flags.to(accu.device))
+    inpaint = M.inpaint_model.forward_grouped(masked)
+    src0 = clip["src_img"][:, 0].contiguous()
+    bg_mask = 1.0 - clip["src_mask_in_image0"]
+    bg_output = M.bg_model((bg_mask * src0 + (1.0 - bg_mask) * clip["bg_noise"]).contiguous(), S)
+    Fn = clip["tgt_IUV255"].shape[1]
+    outs = []
+    for f in range(Fn):
+        warp = ops.texture_warp(inpaint, clip["tgt_IUV255"][:, f].contiguous(), align_corners)
+        refine_output, fg_mask = M.refine_model(warp, S)
+        fusion = ops.blend(refine_output, bg_output, fg_mask)
+        # nearest chosen reference by frame distance is host logic (:256-258); source = ref 0 here
+        tsf = M.flow_calculator(src0, [clip["src_cam"], None, clip["src_verts"], None],
+                                [clip["tgt_cam"][:, f].contiguous(), None, clip["tgt_verts"][:, f].contiguous(), None])
+        pro = M.propagater({"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
+                            "tgt_smpl_mask": clip["smpl_real_mask"][:, f].contiguous(),
+                            "tgt_IUV": clip["tgt_IUV"][:, f].contiguous(), "use_IUV": True})
+        outs.append(pro["pred_target"])
+    return torch.stack(outs, 1)

@@ -1,0 +1,398 @@
+"""GPU parity of every C-ABI kernel against the oracle's torch-CPU fp32 ops (oracle/torch_oracle.py
+uses exactly these torch.nn.functional calls).  Tolerances: fp32 MFMA accumulates in a different
+order than the CPU GEMM, so conv-like ops are held to 2e-4 * scale; pure elementwise ops to 1e-6."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from jafpro_amd import ops
+    return ops
+
+
+def R(seed, *shape, lo=-1.0, hi=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy(g.uniform(lo, hi, shape).astype(np.float32))
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def maxerr(a, b):
+    return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+CONV_CASES = [
+    # N, G, cins, Cout, H, W, k, stride, pad, act
+    (2, 1, [5], 7, 19, 23, 3, 1, 1, 1),
+    (1, 1, [3], 64, 64, 64, 3, 1, 1, 0),
+    (2, 1, [3, 16, 13], 32, 32, 32, 3, 1, 1, 0),       # 3-source concat, odd Cin
+    (2, 3, [4], 12, 50, 50, 5, 1, 2, 1),               # grouped 5x5
+    (2, 3, [6], 8, 50, 50, 3, 2, 1, 1),                # stride 2, even size
+    (1, 2, [8], 16, 25, 25, 3, 2, 1, 1),               # stride 2, odd size 25 -> 13
+    (1, 1, [9], 32, 38, 38, 7, 1, 0, 0),               # 7x7 valid
+    (2, 1, [256], 3, 16, 16, 1, 1, 0, 3),              # 1x1 + sigmoid
+    (1, 24, [12, 12], 48, 26, 26, 3, 1, 1, 0),         # LSTM-like shape as a plain conv
+    (1, 2, [96, 48], 48, 13, 13, 3, 1, 1, 1),
+    (1, 1, [6], 32, 256, 256, 3, 2, 1, 1),
+    (1, 1, [64], 64, 100, 100, 3, 1, 1, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward_backward(case):
+    ops = _ops()
+    N, G, cins, Cout, H, W, k, s, p, act = case
+    srcs = [R(10 + i, N, G * c, H, W) for i, c in enumerate(cins)]
+    Cin = sum(cins)
+    w = R(3, G * Cout, Cin, k, k, lo=-0.3, hi=0.3)
+    b = R(4, G * Cout)
+    # CPU reference: grouped conv over the per-group channel concat
+    xs = [t.view(N, G, c, H, W) for t, c in zip(srcs, cins)]
+    xcat = torch.cat(xs, 2).reshape(N, G * Cin, H, W).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = F.conv2d(xcat, wr, br, stride=s, padding=p, groups=G)
+    actf = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu, 3: torch.sigmoid}[act]
+    y_ref = actf(y_ref)
+    proj = R(5, *y_ref.shape)
+    (y_ref * proj).sum().backward()
+
+    ds = [dev(t).requires_grad_(True) for t in srcs]
+    wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    y = ops.conv2d(ds, wd, bd, stride=s, pad=p, act=act, slope=0.2, groups=G)
+    scale = max(1.0, y_ref.abs().max().item())
+    assert y.shape == y_ref.shape
+    assert maxerr(y, y_ref) <= 2e-4 * scale
+    # the one-thread-per-output kernel must agree as well
+    yd = ops.conv2d_direct([t.detach() for t in ds], wd.detach(), bd.detach(), stride=s, pad=p, act=act, slope=0.2, groups=G)
+    assert maxerr(yd, y_ref) <= 2e-4 * scale
+    (y * dev(proj)).sum().backward()
+    gx = xcat.grad.view(N, G, Cin, H, W)
+    off = 0
+    for t, c in zip(ds, cins):
+        ref = gx[:, :, off:off + c].reshape(N, G * c, H, W)
+        assert maxerr(t.grad, ref) <= 3e-4 * max(1.0, ref.abs().max().item()), "dgrad source at %d" % off
+        off += c
+    assert maxerr(wd.grad, wr.grad) <= 3e-4 * max(1.0, wr.grad.abs().max().item()), "wgrad"
+    assert maxerr(bd.grad, br.grad) <= 3e-4 * max(1.0, br.grad.abs().max().item()), "bias grad"
+
+
+def test_conv2d_shared_source():
+    """inpainter dec1: the 72-channel global embed is read by all 24 groups (src/networks.py:1164)."""
+    ops = _ops()
+    N, G, H = 2, 4, 13
+    a, e, c = R(1, N, G * 6, H, H), R(2, N, 5, H, H), R(3, N, G * 3, H, H)
+    w, b = R(4, G * 8, 14, 3, 3, lo=-0.3, hi=0.3), R(5, G * 8)
+    ar, er, cr = a.clone().requires_grad_(True), e.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    outs = []
+    for g in range(G):
+        xin = torch.cat([ar[:, g * 6:(g + 1) * 6], er, cr[:, g * 3:(g + 1) * 3]], 1)
+        outs.append(F.leaky_relu(F.conv2d(xin, w[g * 8:(g + 1) * 8], b[g * 8:(g + 1) * 8], padding=1), 0.2))
+    y_ref = torch.cat(outs, 1)
+    proj = R(6, *y_ref.shape)
+    (y_ref * proj).sum().backward()
+    ad, ed, cd = (dev(t).requires_grad_(True) for t in (a, e, c))
+    y = ops.conv2d([ad, ed, cd], dev(w), dev(b), stride=1, pad=1, act=1, slope=0.2, groups=G, shared=[False, True, False])
+    assert maxerr(y, y_ref) <= 2e-4 * max(1.0, y_ref.abs().max().item())
+    (y * dev(proj)).sum().backward()
+    for t, r in ((ad, ar), (ed, er), (cd, cr)):
+        assert maxerr(t.grad, r.grad) <= 3e-4 * max(1.0, r.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 1, 4, 7, 5), (4, 1, 3, 12, 20, 20), (2, 2, 2, 24, 13, 13)])
+def test_convlstm_sequence(shape):
+    from oracle import torch_oracle as O
+    ops = _ops()
+    T, B, G, C, H, W = shape
+    x = R(1, T, B, G * C, H, W)
+    w = R(2, G * 4 * C, 2 * C, 3, 3, lo=-0.3, hi=0.3)
+    b = R(3, G * 4 * C, lo=-0.2, hi=0.2)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    hT = []
+    for g in range(G):
+        seq = [xr[t][:, g * C:(g + 1) * C] for t in range(T)]
+        _, (h, c) = O.convlstm(wr[g * 4 * C:(g + 1) * 4 * C], br[g * 4 * C:(g + 1) * 4 * C], seq)
+        hT.append(h)
+    h_ref = torch.cat(hT, 1)
+    proj = R(4, *h_ref.shape)
+    (h_ref * proj).sum().backward()
+    xd, wd, bd = dev(x).requires_grad_(True), dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+    h, c_last = ops.convlstm(xd, wd, bd, groups=G, return_all=False)
+    assert maxerr(h, h_ref) <= 1e-4
+    (h * dev(proj)).sum().backward()
+    assert maxerr(xd.grad, xr.grad) <= 2e-4 * max(1.0, xr.grad.abs().max().item())
+    assert maxerr(wd.grad, wr.grad) <= 3e-4 * max(1.0, wr.grad.abs().max().item())
+    assert maxerr(bd.grad, br.grad) <= 3e-4 * max(1.0, br.grad.abs().max().item())
+
+
+def test_layernorm_lrelu():
+    from oracle import torch_oracle as O
+    ops = _ops()
+    x, g, b = R(1, 3, 10, 17, 9, lo=-2, hi=3), R(2, 10, lo=0.2, hi=1.0), R(3, 10, lo=-0.2, hi=0.2)
+    xr, gr, br = (t.clone().requires_grad_(True) for t in (x, g, b))
+    y_ref = F.leaky_relu(O.crn_layernorm(xr, gr, br), 0.01)
+    proj = R(4, *x.shape)
+    (y_ref * proj).sum().backward()
+    xd, gd, bd = (dev(t).requires_grad_(True) for t in (x, g, b))
+    y = ops.layernorm_lrelu(xd, gd, bd, 1e-5, 0.01)
+    assert maxerr(y, y_ref) <= 2e-6 * max(1.0, y_ref.abs().max().item())
+    (y * dev(proj)).sum().backward()
+    assert maxerr(xd.grad, xr.grad) <= 1e-5
+    assert maxerr(gd.grad, gr.grad) <= 1e-4
+    assert maxerr(bd.grad, br.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("act,res,training", [(2, False, True), (0, True, True), (1, False, True), (2, False, False)])
+def test_batchnorm_act(act, res, training):
+    ops = _ops()
+    N, C, H, W = 3, 6, 11, 7
+    x, w, b = R(1, N, C, H, W, lo=-2, hi=2), R(2, C, lo=0.5, hi=1.5), R(3, C, lo=-0.3, hi=0.3)
+    rm, rv = R(4, C, lo=-0.1, hi=0.1), R(5, C, lo=0.8, hi=1.2)
+    rsd = R(6, N, C, H, W)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    rr = rsd.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y_ref = F.batch_norm(xr, rm_r, rv_r, wr, br, training, 0.1, 1e-5)
+    y_ref = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu}[act](y_ref)
+    if res:
+        y_ref = y_ref + rr
+    proj = R(7, N, C, H, W)
+    (y_ref * proj).sum().backward()
+    xd, wd, bd = (dev(t).requires_grad_(True) for t in (x, w, b))
+    rd = dev(rsd).requires_grad_(True)
+    rm_d, rv_d = dev(rm), dev(rv)
+    y = ops.batchnorm_act(xd, wd, bd, rm_d, rv_d, training, act, 0.2, rd if res else None)
+    assert maxerr(y, y_ref) <= 5e-6 * max(1.0, y_ref.abs().max().item())
+    assert maxerr(rm_d, rm_r) <= 1e-6 and maxerr(rv_d, rv_r) <= 1e-6
+    (y * dev(proj)).sum().backward()
+    assert maxerr(xd.grad, xr.grad) <= 2e-5
+    assert maxerr(wd.grad, wr.grad) <= 1e-4 and maxerr(bd.grad, br.grad) <= 1e-4
+    if res:
+        assert maxerr(rd.grad, rr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 16, 16), (3, 2, 1, 9, 7), (2, 2, 0, 8, 12)])
+def test_avgpool(k, s, p, H, W):
+    ops = _ops()
+    x = R(1, 2, 5, H, W)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.avg_pool2d(xr, k, s, p)
+    proj = R(2, *y_ref.shape)
+    (y_ref * proj).sum().backward()
+    xd = dev(x).requires_grad_(True)
+    y = ops.avg_pool(xd, k, s, p)
+    assert maxerr(y, y_ref) <= 1e-6
+    (y * dev(proj)).sum().backward()
+    assert maxerr(xd.grad, xr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("H,W,OH,OW,ac", [(13, 13, 25, 25, True), (25, 25, 50, 50, True), (256, 256, 4, 4, True),
+                                           (8, 8, 16, 16, True), (16, 16, 32, 32, False), (64, 64, 13, 9, False)])
+def test_resize_bilinear(H, W, OH, OW, ac):
+    ops = _ops()
+    x = R(1, 2, 3, H, W)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=ac)
+    proj = R(2, *y_ref.shape)
+    (y_ref * proj).sum().backward()
+    xd = dev(x).requires_grad_(True)
+    y = ops.resize(xd, (OH, OW), ac)
+    assert maxerr(y, y_ref) <= 2e-6
+    (y * dev(proj)).sum().backward()
+    assert maxerr(xd.grad, xr.grad) <= 1e-5
+
+
+def test_resize_crop_and_nearest():
+    """face crops, train/4...py:342-350: bilinear (AC=False) and nearest to 64x64 of a box."""
+    ops = _ops()
+    x = R(1, 2, 3, 256, 256)
+    y0, y1, x0, x1 = 32, 96, 96, 160
+    crop = x[:, :, y0:y1, x0:x1]
+    ref_b = F.interpolate(crop, size=(64, 64), mode="bilinear", align_corners=False)
+    ref_n = F.interpolate(x[:, :, 30:77, 90:141], size=(64, 64), mode="nearest")
+    xd = dev(x)
+    assert maxerr(ops.resize(xd, (64, 64), False, crop=(y0, x0, y1 - y0, x1 - x0)), ref_b) <= 2e-6
+    assert maxerr(ops.resize(xd, (64, 64), False, nearest=True, crop=(30, 90, 47, 51)), ref_n) == 0.0
+
+
+@pytest.mark.parametrize("p", [1, 3])
+def test_reflect_pad(p):
+    ops = _ops()
+    x = R(1, 2, 3, 9, 12)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.pad(xr, (p, p, p, p), mode="reflect")
+    proj = R(2, *y_ref.shape)
+    (y_ref * proj).sum().backward()
+    xd = dev(x).requires_grad_(True)
+    y = ops.reflect_pad(xd, p)
+    assert maxerr(y, y_ref) == 0.0
+    (y * dev(proj)).sum().backward()
+    assert maxerr(xd.grad, xr.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("ac", [False, True])
+def test_texture_warp(ac):
+    from oracle import torch_oracle as O
+    from jafpro_amd import synth
+    ops = _ops()
+    B = 2
+    iuv = synth.iuv255(5, "iuv", B, 256)
+    iuv[0, 0, 0] = (3, 0, 255)          # corner taps: exercises the zero padding
+    iuv[0, 0, 1] = (3, 255, 0)
+    tex = R(1, B, 72, 200, 200)
+    tr = tex.clone().requires_grad_(True)
+    ref = torch.stack([O.texture_warp([tr[b, 3 * p:3 * p + 3] for p in range(24)], iuv[b], ac) for b in range(B)])
+    proj = R(2, *ref.shape)
+    (ref * proj).sum().backward()
+    td = dev(tex).requires_grad_(True)
+    out = ops.texture_warp(td, torch.from_numpy(iuv).cuda(), ac)
+    assert maxerr(out, ref) <= 2e-6
+    (out * dev(proj)).sum().backward()
+    assert maxerr(td.grad, tr.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("border,ac", [(True, False), (False, False), (True, True)])
+def test_grid_sample(border, ac):
+    ops = _ops()
+    src = R(1, 2, 3, 40, 37)
+    grid = R(2, 2, 21, 19, 2, lo=-1.3, hi=1.3)
+    grid[0, 0, 0] = -2.0
+    ref = F.grid_sample(src, grid, mode="bilinear", padding_mode="border" if border else "zeros", align_corners=ac)
+    out = ops.grid_sample(dev(src), dev(grid), border, ac)
+    assert maxerr(out, ref) <= 2e-6
+
+
+def test_blend_and_mul():
+    ops = _ops()
+    a, b, m = R(1, 2, 3, 16, 16), R(2, 2, 3, 16, 16), R(3, 2, 1, 16, 16, lo=0, hi=1)
+    ar, br, mr = (t.clone().requires_grad_(True) for t in (a, b, m))
+    ref = ar * mr.repeat(1, 3, 1, 1) + br * (1 - mr.repeat(1, 3, 1, 1))
+    proj = R(4, *ref.shape)
+    (ref * proj).sum().backward()
+    ad, bd, md = (dev(t).requires_grad_(True) for t in (a, b, m))
+    out = ops.blend(ad, bd, md)
+    assert maxerr(out, ref) <= 1e-6
+    (out * dev(proj)).sum().backward()
+    for t, r in ((ad, ar), (bd, br), (md, mr)):
+        assert maxerr(t.grad, r.grad) <= 1e-6
+    m3 = R(5, 2, 3, 16, 16, lo=0, hi=1)
+    assert maxerr(ops.mul_bcast(dev(a), dev(m3)), a * m3) <= 1e-7
+    assert maxerr(ops.mul_bcast(dev(a), dev(m)), a * m) <= 1e-7
+
+
+def test_part_mask_and_atlas():
+    from oracle import torch_oracle as O
+    from jafpro_amd import synth
+    ops = _ops()
+    B, T = 2, 4
+    atlas = R(1, B, T, 3, 800, 1200)
+    parts = ops.atlas_to_parts(dev(atlas))
+    ref = torch.cat([torch.cat([atlas[:, t, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200]
+                                for i in range(4) for j in range(6)], 1) for t in range(T)], 0)
+    assert maxerr(parts, ref) == 0.0
+    masks = torch.from_numpy(synth.rect_masks(3, "m", (B, T, 800, 1200)))
+    tex = R(2, B, 72, 200, 200)
+    used = [0, 2]
+    area = O.common_area_mask(masks, used)
+    ref = torch.cat(O.mask_parts([tex[:, 3 * p:3 * p + 3] for p in range(24)], area), 1)
+    u = torch.zeros(T, dtype=torch.int32); u[used] = 1
+    out = ops.part_mask_mul(dev(tex), dev(masks), u.cuda())
+    assert maxerr(out, ref) == 0.0
+
+
+def test_losses_linear_adam():
+    ops = _ops()
+    a, b = R(1, 2, 3, 33, 17), R(2, 2, 3, 33, 17)
+    ar = a.clone().requires_grad_(True)
+    ref = 0.7 * F.l1_loss(ar, b)
+    ref.backward()
+    ad = dev(a).requires_grad_(True)
+    out = ops.l1_loss(ad, dev(b), 0.7)
+    assert abs(out.item() - ref.item()) <= 1e-6
+    out.sum().backward()
+    assert maxerr(ad.grad, ar.grad) <= 1e-9
+    # vgg preprocess
+    from oracle import torch_oracle as O
+    assert maxerr(ops.vgg_preprocess(dev(a)), O.vgg_preprocess(a)) <= 2e-5
+    # BCE
+    p = R(3, 5, 1, lo=0.01, hi=0.99)
+    for tgt in (0.0, 1.0):
+        pr = p.clone().requires_grad_(True)
+        ref = F.binary_cross_entropy(pr, torch.full_like(pr, tgt))
+        ref.backward()
+        pd = dev(p).requires_grad_(True)
+        out = ops.bce_loss(pd, tgt)
+        assert abs(out.item() - ref.item()) <= 1e-6
+        out.sum().backward()
+        assert maxerr(pd.grad, pr.grad) <= 1e-6
+    # linear
+    x, w, bb = R(4, 3, 70), R(5, 11, 70, lo=-0.2, hi=0.2), R(6, 11)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, bb))
+    ref = F.leaky_relu(F.linear(xr, wr, br), 0.2)
+    proj = R(7, 3, 11)
+    (ref * proj).sum().backward()
+    xd, wd, bd = (dev(t).requires_grad_(True) for t in (x, w, bb))
+    out = ops.linear(xd, wd, bd, 1, 0.2)
+    assert maxerr(out, ref) <= 1e-5
+    (out * dev(proj)).sum().backward()
+    for t, r in ((xd, xr), (wd, wr), (bd, br)):
+        assert maxerr(t.grad, r.grad) <= 1e-5
+    # Adam vs torch.optim.Adam, 3 steps
+    pp = R(8, 1003)
+    pr = pp.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pd, m, v = dev(pp), torch.zeros(1003).cuda(), torch.zeros(1003).cuda()
+    for step in range(1, 4):
+        g = R(20 + step, 1003)
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam_step(pd, dev(g), m, v, 1e-3, step)
+    assert maxerr(pd, pr) <= 1e-6
+
+
+def test_rasterizer_and_flow():
+    """fim must be bit-exact vs the C restatement; weights/flow within 1e-6."""
+    from oracle import raster_oracle, torch_oracle as O
+    from jafpro_amd import synth
+    ops = _ops()
+    B = 2
+    vs, vt = synth.posed_vertices(81, "src", B), synth.posed_vertices(81, "tgt", B)
+    cam = np.zeros((B, 3), np.float32); cam[:, 0] = 0.9
+    _, fidx = synth.body_mesh()
+    f_ref = O.project_faces(torch.from_numpy(vt), torch.from_numpy(cam), fidx)
+    f_gpu = ops.project_faces(torch.from_numpy(vt).cuda(), torch.from_numpy(cam).cuda(), torch.from_numpy(fidx).cuda(), float(np.float32(O.EYE_Z)))
+    assert maxerr(f_gpu, f_ref) == 0.0
+    fim_ref, wim_ref = raster_oracle.rasterize_fim_wim(f_ref.numpy(), 256)
+    fim, wim = ops.rasterize_fim_wim(f_gpu, 256)
+    assert (fim.cpu().numpy() == fim_ref).all(), "face index map differs at %d pixels" % (fim.cpu().numpy() != fim_ref).sum()
+    assert np.abs(wim.cpu().numpy() - wim_ref).max() == 0.0
+    fs_ref = O.project_faces(torch.from_numpy(vs), torch.from_numpy(cam), fidx)
+    img = R(1, B, 3, 256, 256)
+    warped_ref, T_ref = O.flow_warp(img, fs_ref, torch.from_numpy(fim_ref), torch.from_numpy(wim_ref))
+    T_gpu = ops.bc_transform(fs_ref.cuda().contiguous(), fim, wim)
+    assert maxerr(T_gpu, T_ref) <= 1e-6
+    assert maxerr(ops.grid_sample(dev(img), T_gpu, True, False), warped_ref) <= 1e-5
+
+
+def test_rasterizer_small_cases():
+    """single triangle, degenerate and back-facing faces, batch index (tests/utils.py:11-27 idea)."""
+    from oracle import raster_oracle
+    ops = _ops()
+    faces = np.zeros((3, 4, 3, 3), np.float32)
+    faces[1, 0] = [[-0.5, -0.5, 2.0], [0.5, -0.5, 2.0], [0.0, 0.6, 2.5]]          # front (ccw)
+    faces[1, 1] = [[-0.5, -0.5, 1.5], [0.0, 0.6, 1.5], [0.5, -0.5, 1.5]]          # back-facing, nearer: culled
+    faces[1, 2] = [[-0.2, -0.2, 1.0], [0.3, -0.2, 1.0], [0.0, 0.3, 1.0]]          # front, nearest
+    faces[1, 3] = [[-0.2, -0.2, 1.0], [0.3, -0.2, 1.0], [0.0, 0.3, 1.0]]          # duplicate: lower index must win
+    faces[2, 0] = [[-0.9, -0.9, 150.0], [0.9, -0.9, 150.0], [0.0, 0.9, 150.0]]    # beyond far
+    for S in (64, 256):
+        fr, wr = raster_oracle.rasterize_fim_wim(faces, S)
+        fg, wg = ops.rasterize_fim_wim(torch.from_numpy(faces).cuda(), S)
+        assert (fg.cpu().numpy() == fr).all()
+        assert np.abs(wg.cpu().numpy() - wr).max() == 0.0
+        assert (fr[0] == -1).all() and (fr[2] == -1).all() and (fr[1] == 2).any() and not (fr[1] == 3).any()
