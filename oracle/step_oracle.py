@@ -1,0 +1,118 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py cpu_baseline).
+
+CPU restatement of the stage-4 train step, train/4.convLSTM_flowpro_interval.py:206-413, composed
+from oracle/torch_oracle.py (each piece pinned bit-exact against the reference modules by
+oracle/make_golden.py) with torch autograd and torch.optim.Adam on CPU.  The script itself cannot
+run under torch >= 1.7 (int64 torch.full, BCE target shapes), so the sequence is
+restated with exactly the F6 patches of SURVEY Appendix C and nothing else:
+  * three discriminator updates on gradients that are NOT zeroed in between (:380-394, F10),
+  * face GAN generator term on face_pred.detach() (:399),
+  * propagater BatchNorm in train mode; background CRN frozen, under no_grad (:319-320),
+  * total = loss.sum() + 2*errG + 2*F_errG (:407), Adam lrs of :169-175.
+The random reference subset (:249-261) and the fresh background noise (:231) are inputs.
+"""
+from __future__ import annotations
+
+from typing import Dict, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import raster_oracle
+from . import torch_oracle as O
+
+LRS = {"accu": 1e-5, "inpaint": 1e-5, "refine": 1e-5, "flow": 5e-5, "D": 3e-6, "face": 1e-6}
+
+
+def _as_params(sd, trainable=True):
+    out = {}
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if trainable and t.is_floating_point() and not ("running_" in k):
+            t.requires_grad_(True)
+        out[k] = t
+    return out
+
+
+class OracleStage4:
+    def __init__(self, sds: Dict[str, Dict[str, torch.Tensor]], faces_idx: np.ndarray, lrs=None):
+        """sds keys: accu, inpaint, bg, refine, flow, D, face, vgg (state_dicts with reference keys)."""
+        self.sd = {k: _as_params(v, trainable=k not in ("bg", "vgg")) for k, v in sds.items()}
+        self.faces_idx = faces_idx
+        lrs = dict(LRS if lrs is None else lrs)
+        self.opt = {k: torch.optim.Adam([p for p in self.sd[k].values() if p.requires_grad], lr=lrs[k])
+                    for k in ("accu", "inpaint", "refine", "flow", "D", "face")}
+
+    # train/4...py:269-331
+    def generator_forward(self, b: Dict[str, torch.Tensor], used: Sequence[int], prosrc: int, align_corners=False):
+        B = b["src_img"].shape[0]
+        used = list(used)
+        x_in = []
+        for i in range(4):
+            for j in range(6):
+                x_in.append([b["src_texture_im"][:, t, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200] for t in used])
+        accu = O.accumulate_forward(self.sd["accu"], x_in)
+        area = O.common_area_mask(b["src_mask_im"], used)
+        masked = O.mask_parts(accu, area)
+        inpaint = O.inpaint_forward(self.sd["inpaint"], masked)
+        iuv = b["tgt_IUV255"].numpy()
+        warp = torch.stack([O.texture_warp([t[i] for t in inpaint], iuv[i], align_corners) for i in range(B)])
+        refine_output, fg_mask = O.crn_smaller_forward(self.sd["refine"], warp, 256, True)
+        src0 = b["src_img"][:, 0]
+        bg_mask = 1 - b["src_mask_in_image0"]
+        bg_incomplete = bg_mask * src0 + (1 - bg_mask) * b["bg_noise"]
+        with torch.no_grad():
+            bg_output = O.crn_smaller_forward(self.sd["bg"], bg_incomplete, 256, False)
+        fusion = refine_output * fg_mask.repeat(1, 3, 1, 1) + bg_output * (1 - fg_mask.repeat(1, 3, 1, 1))
+        with torch.no_grad():
+            fs = O.project_faces(b["src_verts"], b["src_cam"], self.faces_idx)
+            ft = O.project_faces(b["tgt_verts"], b["tgt_cam"], self.faces_idx)
+            fim, wim = raster_oracle.rasterize_fim_wim(ft.numpy(), 256)
+            tsf, _ = O.flow_warp(b["src_img"][:, prosrc], fs, torch.from_numpy(fim), torch.from_numpy(wim), align_corners)
+        pro = O.propagation_forward(self.sd["flow"], {"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
+                                                      "tgt_smpl_mask": b["smpl_real_mask"], "tgt_IUV": b["tgt_IUV"],
+                                                      "use_IUV": True}, True)
+        return {"final_output": pro["pred_target"], "final_mask": pro["weight"], "fusion_output": fusion,
+                "refine_output": refine_output, "fg_mask": fg_mask, "bg_output": bg_output, "tsf_image": tsf,
+                "inpaint_warp": warp, "inpaint": torch.cat(inpaint, 1), "accu": torch.cat(accu, 1)}
+
+    def train_step(self, b: Dict[str, torch.Tensor], used=(0, 1, 2, 3), prosrc=0, align_corners=False):
+        for o in self.opt.values():
+            o.zero_grad(set_to_none=False)
+        g = self.generator_forward(b, used, prosrc, align_corners)
+        final, target = g["final_output"], b["tgt_img"]
+        loss = O.vgg_l1_loss(self.sd["vgg"], final, target)
+        fp, fr, fi = [], [], []
+        for i in range(final.shape[0]):                                         # :338-353
+            x0, x1, y0, y1 = (int(v) for v in b["face_bbox"][i])
+            if x0 == x1:
+                continue
+            fp.append(F.interpolate(final[i:i + 1, :, y0:y1, x0:x1], size=(64, 64), mode="bilinear", align_corners=False))
+            fr.append(F.interpolate(target[i:i + 1, :, y0:y1, x0:x1], size=(64, 64), mode="bilinear", align_corners=False))
+            fi.append(F.interpolate(b["tgt_IUV"][i:i + 1, :, y0:y1, x0:x1], size=(64, 64), mode="nearest"))
+        face_pred, face_real, face_IUV = torch.cat(fp), torch.cat(fr), torch.cat(fi)
+        bce = lambda p, t: F.binary_cross_entropy(p, torch.full_like(p, t))
+        FD = lambda x: O.discriminator_forward(self.sd["face"], x, True, O.FACE_D_CONVS)
+        D = lambda x: O.discriminator_forward(self.sd["D"], x, True, O.IMAGE_D_CONVS)
+        src0 = b["src_img"][:, 0]
+        F_errD_real = bce(FD(torch.cat([face_real, face_IUV], 1)), 1.0)
+        F_errD_real.backward()
+        F_errD_fake = bce(FD(torch.cat([face_pred.detach(), face_IUV], 1)), 0.0)
+        F_errD_fake.backward()
+        self.opt["face"].step()
+        for _ in range(3):                                                       # no zero_grad inside (F10)
+            errD_real = bce(D(torch.cat([target, src0], 1)), 1.0)
+            errD_real.backward()
+            errD_fake = bce(D(torch.cat([final.detach(), src0], 1)), 0.0)
+            errD_fake.backward()
+            self.opt["D"].step()
+        errG = bce(D(torch.cat([final, src0], 1)), 1.0)
+        F_errG = bce(FD(torch.cat([face_pred.detach(), face_IUV], 1)), 1.0)
+        total = loss.sum() + 2 * errG + 2 * F_errG
+        total.backward()
+        for k in ("accu", "inpaint", "refine", "flow"):
+            self.opt[k].step()
+        return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),
+                "errG": errG.detach(), "F_errD": (F_errD_real + F_errD_fake).detach(), "F_errG": F_errG.detach(),
+                "final_output": final.detach()}

@@ -1,0 +1,256 @@
+"""GPU parity of the nn.Module mirrors against the committed golden vectors, which were produced
+by the REFERENCE modules (oracle/make_golden.py) on the same portable synthetic weights/inputs.
+Forward bar: <= 1e-3 L-inf in fp32 (BASELINE.json north_star); gradients: 1e-3 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+FWD_TOL = 1e-3
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def check(st, name, t, tol, rel=False):
+    t = t.detach().float().cpu()
+    if name in st:
+        ref = torch.from_numpy(st[name])
+        assert tuple(ref.shape) == tuple(t.shape), (name, ref.shape, t.shape)
+        err = (t - ref).abs().max().item()
+        scale = max(1.0, ref.abs().max().item()) if rel else 1.0
+        assert err <= tol * scale, "%s: max|diff| %.3e > %.1e*%.2f" % (name, err, tol, scale)
+        return err
+    assert tuple(st[name + ".shape"]) == tuple(t.shape), name
+    flat = t.reshape(-1)
+    ref = torch.from_numpy(st[name + ".samples"])
+    err = (flat[torch.from_numpy(st[name + ".idx"])] - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item()) if rel else 1.0
+    assert err <= tol * scale, "%s: sample max|diff| %.3e" % (name, err)
+    s = flat.double().sum().item()
+    sa = flat.double().abs().sum().item()
+    assert abs(sa - st[name + ".sumabs"]) <= max(tol * flat.numel() * 0.05, 1e-3 * abs(st[name + ".sumabs"])), name
+    assert abs(s - st[name + ".sum"]) <= max(tol * flat.numel() * 0.05, 1e-3 * abs(st[name + ".sumabs"])), name
+    return err
+
+
+def grouped_grad(module, key):
+    """gradient of a reference-keyed per-part parameter from the grouped parameter's .grad"""
+    for pname, template in module._key_map.items():
+        for p in range(24):
+            if template.format(p=p) == key:
+                g = getattr(module, pname).grad
+                per = g.shape[0] // 24
+                return g[p * per:(p + 1) * per]
+    raise KeyError(key)
+
+
+def named_grad(module, key):
+    return dict(module.named_parameters())[key].grad
+
+
+def test_convlstm_toy(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.convLSTM import ConvLSTM
+    st = load(golden_dir, "convlstm_toy.npz")
+    m = synth.load_synth(ConvLSTM((7, 5), 4, [4], [(3, 3)], 1, batch_first=True, bias=True), 11).cuda()
+    x = T(synth.uniform(11, "x", (2, 3, 4, 7, 5))).requires_grad_(True)
+    out, last = m(x)
+    check(st, "out", out, 1e-5); check(st, "h_T", last[0][0], 1e-5); check(st, "c_T", last[0][1], 1e-5)
+    proj = T(synth.uniform(11, "proj", tuple(last[0][0].shape)))
+    ((last[0][0] * proj).sum() + 0.5 * (out * out).sum()).backward()
+    check(st, "dx", x.grad, 1e-4)
+    check(st, "dw", m.cell_list[0].conv.weight.grad, 1e-3, rel=True)
+    check(st, "db", m.cell_list[0].conv.bias.grad, 1e-3, rel=True)
+
+
+def test_accumulate_golden(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.networks import Accumulate_LSTM_no_loss
+    st = load(golden_dir, "accumulate_b1_t2.npz")
+    m = synth.load_synth(Accumulate_LSTM_no_loss(), 21).cuda()
+    atlas = synth.uniform(21, "src_texture_im", (1, 2, 3, 800, 1200))
+    x_in = [[T(atlas[:, t, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200]) for t in range(2)]
+            for i in range(4) for j in range(6)]
+    outs = m(x_in)
+    assert len(outs) == 24 and tuple(outs[0].shape) == (1, 3, 200, 200)
+    out = torch.cat(outs, 1)
+    check(st, "out", out, FWD_TOL)
+    proj = T(synth.uniform(21, "proj", tuple(out.shape)))
+    (out * proj).sum().backward()
+    for k in [k[5:] for k in st if k.startswith("grad.")]:
+        check(st, "grad." + k, grouped_grad(m, k), 2e-3, rel=True)
+
+
+def test_inpaint_golden(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.networks import UNet_inpainter
+    st = load(golden_dir, "inpaint_b1.npz")
+    m = synth.load_synth(UNet_inpainter(), 31).cuda()
+    tex = [T(synth.uniform(31, "tex%d" % p, (1, 3, 200, 200))).requires_grad_(True) for p in range(24)]
+    out = torch.cat(m(tex), 1)
+    check(st, "out", out, FWD_TOL)
+    proj = T(synth.uniform(31, "proj", tuple(out.shape)))
+    (out * proj).sum().backward()
+    check(st, "dtex3", tex[3].grad, 2e-3, rel=True)
+    for k in [k[5:] for k in st if k.startswith("grad.")]:
+        check(st, "grad." + k, grouped_grad(m, k), 2e-3, rel=True)
+
+
+@pytest.mark.parametrize("sp,B", [(64, 2), (256, 1)])
+def test_crn_golden(golden_dir, sp, B):
+    from jafpro_amd import synth
+    from jafpro_amd.crn_model import CRN_smaller
+    st = load(golden_dir, "crn_sp%d.npz" % sp)
+    m = synth.load_synth(CRN_smaller(3, fg=True), 41).cuda()
+    x = T(synth.uniform(41, "label%d" % sp, (B, 3, sp, sp))).requires_grad_(True)
+    rgb, mask = m(x, sp)
+    check(st, "rgb", rgb, FWD_TOL); check(st, "mask", mask, FWD_TOL)
+    if sp == 64:
+        proj = T(synth.uniform(41, "proj", tuple(rgb.shape)))
+        ((rgb * proj).sum() + mask.sum()).backward()
+        check(st, "dlabel", x.grad, 2e-3, rel=True)
+        for k in [k[5:] for k in st if k.startswith("grad.")]:
+            check(st, "grad." + k, named_grad(m, k), 2e-3, rel=True)
+
+
+def test_propagation_golden(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.flow_net import Propagation3DFlowNet
+    st = load(golden_dir, "propagation_64.npz")
+    m = synth.load_synth(Propagation3DFlowNet(9, 32, 2, 3, use_deconv=False), 51).cuda()
+    m.train()
+    B, S = 2, 64
+    x = {"fake_tgt": T(synth.uniform(51, "fake", (B, 3, S, S))).requires_grad_(True),
+         "tsf_image": T(synth.uniform(51, "tsf", (B, 3, S, S))),
+         "tgt_smpl_mask": T((synth.uniform(51, "mask", (B, 3, S, S)) > 0).astype(np.float32)),
+         "tgt_IUV": T(synth.uniform(51, "iuv", (B, 3, S, S))), "use_mask": True, "use_IUV": True}
+    out = m(x)
+    check(st, "pred", out["pred_target"], FWD_TOL); check(st, "weight", out["weight"], FWD_TOL)
+    sd = m.state_dict()
+    for k in [k[6:] for k in st if k.startswith("after.")]:
+        check(st, "after." + k, sd[k], 1e-5)                      # train-mode BN side effect (F9)
+    assert int(sd["composite_unet.model_down_img.2.num_batches_tracked"]) == 1
+    proj = T(synth.uniform(51, "proj", tuple(out["pred_target"].shape)))
+    (out["pred_target"] * proj).sum().backward()
+    check(st, "dfake", x["fake_tgt"].grad, 2e-3, rel=True)
+    for k in [k[5:] for k in st if k.startswith("grad.")]:
+        check(st, "grad." + k, named_grad(m, k), 2e-3, rel=True)
+
+
+def test_discriminators_golden(golden_dir):
+    from jafpro_amd import ops, synth
+    from jafpro_amd.networks import FaceDiscriminator, ImageDiscriminator
+    st = load(golden_dir, "discriminators.npz")
+    for name, cls, size in (("D", ImageDiscriminator, 256), ("FD", FaceDiscriminator, 64)):
+        m = synth.load_synth(cls(32, 6), 61).cuda()
+        m.train()
+        x = T(synth.uniform(61, name + "x", (2, 6, size, size))).requires_grad_(True)
+        p = m(x)
+        check(st, name + ".p", p, 1e-4)
+        loss = ops.bce_loss(p, 1.0)
+        check(st, name + ".loss", loss, 1e-4)
+        loss.sum().backward()
+        check(st, name + ".dx", x.grad, 2e-3, rel=True)
+        for k in ("main.0.weight", "classifier.2.weight", "main.3.weight"):
+            check(st, name + ".grad." + k, named_grad(m, k), 2e-3, rel=True)
+        check(st, name + ".after.main.3.running_var", m.state_dict()["main.3.running_var"], 1e-5)
+
+
+def test_texture_warp_golden(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.networks import texture_warp_pytorch
+    st = load(golden_dir, "texture_warp.npz")
+    iuv = synth.iuv255(71, "iuv", 1, 256)[0]
+    tex = [T(synth.uniform(71, "tex%d" % p, (3, 200, 200))) for p in range(24)]
+    check(st, "out_ac0", texture_warp_pytorch(tex, iuv, "cuda"), 1e-5)
+    check(st, "out_ac1", texture_warp_pytorch(tex, iuv, "cuda", align_corners=True), 1e-5)
+
+
+def test_flow_golden(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.cal_flow import float_estimate
+    st = load(golden_dir, "flow_b2.npz")
+    B = 2
+    _, fidx = synth.body_mesh()
+    fe = float_estimate(faces=fidx).cuda()
+    vs, vt = T(synth.posed_vertices(81, "src", B)), T(synth.posed_vertices(81, "tgt", B))
+    cam = torch.zeros(B, 3).cuda(); cam[:, 0] = 0.9
+    ft, fim, wim = fe.render.render_fim_wim(cam, vt)
+    check(st, "faces_tgt", ft, 1e-6)
+    f = fim.cpu().numpy()
+    assert int((f >= 0).sum()) == int(st["fim.cov"]) and int(f.astype(np.int64).sum()) == int(st["fim.sum"])
+    assert (f.reshape(-1)[st["fim.idx"]] == st["fim.samples"]).all()
+    check(st, "wim", wim, 1e-7)
+    src_img = T(synth.uniform(81, "img", (B, 3, 256, 256)))
+    flow = fe.cal_flow(cam, None, vs, None, cam, None, vt, None)
+    check(st, "T", flow, 1e-6)
+    check(st, "warped", fe(src_img, [cam, None, vs, None], [cam, None, vt, None]), 1e-5)
+
+
+def test_vgg_l1_golden(golden_dir):
+    from jafpro_amd import synth
+    from jafpro_amd.networks import VGG_l1_loss
+    st = load(golden_dir, "vgg_l1_64.npz")
+    m = VGG_l1_loss()
+    # the golden VGG was filled through the reference's state_dict, which also holds conv5_3/5_4
+    sd = m.state_dict()
+    vals = synth.synth_state_dict({k: tuple(v.shape) for k, v in sd.items()}, 91)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in vals.items()})
+    m = m.cuda()
+    x = T(synth.uniform(91, "x", (1, 3, 64, 64))).requires_grad_(True)
+    y = T(synth.uniform(91, "y", (1, 3, 64, 64)))
+    loss = m(x, y)
+    ref = float(st["loss"][0])
+    assert abs(loss.item() - ref) <= 1e-3 * max(1.0, abs(ref)), (loss.item(), ref)
+    loss.backward()
+    # d|a-b| = sign(a-b) is discontinuous: a feature difference of 1e-6 flips a sign and moves single
+    # pixels of dx by O(1e-2); gradients of the L1 terms are therefore compared in relative L2.
+    ref_dx = torch.from_numpy(st["dx"])
+    rel = ((x.grad.cpu() - ref_dx).norm() / ref_dx.norm()).item()
+    print("vgg dx rel-L2 %.3e" % rel)
+    assert rel <= 2e-2, rel
+
+
+def test_stage1_golden(golden_dir):
+    """BASELINE config 1: Accumulate_LSTM with atlas paste + masked L1 (src/networks.py:1607-1639)."""
+    from jafpro_amd import synth
+    from jafpro_amd.networks import Accumulate_LSTM
+    st = load(golden_dir, "stage1_b1_t2.npz")
+    m = synth.load_synth(Accumulate_LSTM(), 101).cuda()
+    atlas = synth.uniform(101, "src_texture_im", (1, 2, 3, 800, 1200))
+    x_in = [[T(atlas[:, t, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200]) for t in range(2)]
+            for i in range(4) for j in range(6)]
+    src_mask = T(synth.rect_masks(101, "sm", (1, 2, 3, 800, 1200)).astype(np.uint8))
+    tgt_mask = T(synth.rect_masks(101, "tm", (1, 3, 3, 800, 1200)).astype(np.uint8))
+    tgt_tex = T(synth.uniform(101, "tt", (1, 3, 3, 800, 1200)))
+    atlas_out, loss = m(x_in, src_mask, tgt_mask, tgt_tex)
+    check(st, "atlas", atlas_out, FWD_TOL)
+    assert abs(loss.item() - float(st["loss"][0])) <= 1e-4
+    loss.backward()
+    check(st, "grad.Upsampler_list.3.conv.weight", grouped_grad(m, "Upsampler_list.3.conv.weight"), 2e-3, rel=True)
+
+
+def test_state_dict_roundtrip_on_gpu():
+    from jafpro_amd import synth
+    from jafpro_amd.networks import UNet_inpainter
+    a = synth.load_synth(UNet_inpainter(), 5).cuda()
+    b = UNet_inpainter().cuda()
+    b.load_state_dict(a.state_dict())
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+
+
+def test_ops_reject_cpu_tensors():
+    from jafpro_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, pad=1)
+    with pytest.raises(RuntimeError):
+        ops.avg_pool(torch.zeros(1, 1, 4, 4), 2, 2, 0)

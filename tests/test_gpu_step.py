@@ -1,0 +1,77 @@
+"""Full stage-4 train step on the GPU vs the CPU restatement (oracle/step_oracle.py) on the same
+synthetic weights and batch: generated frame <= 1e-3 L-inf, losses, and per-module gradients."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = {"accu": 201, "inpaint": 202, "bg": 203, "refine": 204, "flow": 205, "D": 206, "face": 207, "vgg": 208}
+
+
+def build(B):
+    from jafpro_amd import synth
+    from jafpro_amd.step import Stage4Models, Stage4Trainer, _to_dev
+    from oracle.step_oracle import OracleStage4
+    _, fidx = synth.body_mesh()
+    M = Stage4Models(fidx)
+    mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
+            "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
+    for k, m in mods.items():
+        synth.load_synth(m, SEEDS[k])
+    sds = {k: {kk: vv.detach().clone() for kk, vv in m.state_dict().items()} for k, m in mods.items()}
+    M = M.cuda()
+    batch = synth.stage4_batch(300, B)
+    return M, Stage4Trainer(M), OracleStage4(sds, fidx), batch, _to_dev(batch, "cuda"), mods
+
+
+def rel_l2(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def test_generator_forward_parity():
+    """BASELINE config 2 chain for one target frame (forward only)."""
+    from jafpro_amd.step import generator_forward
+    M, tr, orc, batch, dbatch, _ = build(1)
+    with torch.no_grad():
+        g = generator_forward(M, dbatch, (0, 1, 2, 3), 0)
+        cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+        r = orc.generator_forward(cb, (0, 1, 2, 3), 0)
+    for k in ("accu", "inpaint", "inpaint_warp", "refine_output", "fg_mask", "bg_output", "fusion_output", "tsf_image",
+              "final_mask", "final_output"):
+        err = (g[k].cpu() - r[k]).abs().max().item()
+        print("%-16s max|diff| = %.3e" % (k, err))
+        assert err <= 1e-3, (k, err)
+
+
+def test_train_step_parity():
+    M, tr, orc, batch, dbatch, mods = build(1)
+    out = tr.train_step(dbatch)
+    cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+    ref = orc.train_step(cb)
+    assert (out["final_output"].cpu() - ref["final_output"]).abs().max().item() <= 1e-3
+    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
+        a, b = float(out[k].reshape(-1)[0]), float(ref[k].reshape(-1)[0])
+        print("%-10s gpu %.6f cpu %.6f" % (k, a, b))
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
+    # gradients left in the buffers after the step (incl. the F10 accumulation in D / face-D)
+    for name, key in (("accu", "accu"), ("inpaint", "inpaint"), ("refine", "refine"), ("flow", "flow"), ("D", "D"), ("face", "face")):
+        gsd = {k: v for k, v in mods[name].state_dict(keep_vars=True).items()}
+        num = den = 0.0
+        for k, p in orc.sd[key].items():
+            if not p.requires_grad:
+                continue
+            q = gsd[k]
+            gq = q.grad if q.grad is not None else None
+            if gq is None:      # grouped parameter: slice of the grouped gradient
+                from tests.test_gpu_modules import grouped_grad
+                gq = grouped_grad(mods[name], k)
+            d = (gq.detach().cpu().double() - p.grad.double())
+            num += float((d * d).sum()); den += float((p.grad.double() ** 2).sum())
+        rel = (num / max(den, 1e-300)) ** 0.5
+        print("grad rel-L2 %-8s %.3e" % (name, rel))
+        assert rel <= 5e-3, (name, rel)
+    # parameters moved by Adam: every trainable buffer changed, frozen ones did not
+    for name in ("accu", "inpaint", "refine", "flow", "D", "face"):
+        assert tr.flat[name].step_count == (3 if name == "D" else 1)
