@@ -1,0 +1,154 @@
+"""Stage-4 train-step benchmark (BASELINE.json metric: train-step frames/sec, 256x256, stage 4).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one full stage-4 train step (generator forward, VGG+L1 loss, face-D update, 3 D updates,
+generator backward, 6 Adam updates, gradient all-reduce when N > 1) over a synthetic batch of
+B=8 samples per GPU that is already resident in HBM.  One target frame is generated per sample
+(SURVEY F4), so frames/s = global batch / step time.  fp32 end to end (fp32 MFMA).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+SEEDS = {"accu": 1301, "inpaint": 1302, "bg": 1303, "refine": 1304, "flow": 1305, "D": 1306, "face": 1307, "vgg": 1308}
+
+
+def build_models(fidx):
+    from jafpro_amd import synth
+    from jafpro_amd.step import Stage4Models
+    M = Stage4Models(fidx)
+    mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
+            "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
+    for k, m in mods.items():
+        synth.load_synth(m, SEEDS[k])
+    return M, mods
+
+
+def cpu_baseline(mods, fidx):
+    """The oracle (CPU restatement of the reference step) timed on this node's host cores on a
+    bounded sample: ONE full train step at B=1, T=4 (the GPU workload is B=8)."""
+    from jafpro_amd import synth
+    from oracle.step_oracle import OracleStage4
+    sds = {k: {kk: vv.detach().cpu().clone() for kk, vv in m.state_dict().items()} for k, m in mods.items()}
+    torch.set_num_threads(os.cpu_count() or 1)
+    orc = OracleStage4(sds, fidx)
+    b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.stage4_batch(1400, 1).items()}
+    t0 = time.perf_counter()
+    orc.train_step(b)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 full stage-4 train step at B=1, T=4, 256x256 fp32 (%.1f s); brute-force C rasteriser "
+                      "single-threaded, torch ops on all cores" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    reducer = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from jafpro_amd.dist import GradReducer
+        reducer = GradReducer()
+
+    from jafpro_amd import ops, synth
+    from jafpro_amd.step import Stage4Trainer, _to_dev
+    _, fidx = synth.body_mesh()
+    M, mods = build_models(fidx)
+    M = M.cuda()
+    trainer = Stage4Trainer(M, reducer=reducer)
+    B = args.batch
+    batch = _to_dev(synth.stage4_batch(1300 + rank, B), "cuda")       # weak scaling: B per GPU fixed
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.train_step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = world * B * args.steps / elapsed
+
+    result = {
+        "metric": "train-step frames/sec, 256x256 30-frame clips, stage-4",
+        "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "stage-4 full train step (G fwd+bwd, VGG+L1, 3x D, face-D, 6x Adam), "
+                               "B=%d/GPU, T=4 refs, 256x256, 1 target frame/sample (configs[2] at fp32)" % B,
+                   "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
+                   "clips_per_s": frames_per_s / 30.0,
+                   "algorithmic_tflop_per_step": 2.2788 * world * B,
+                   "loss": float(out["total_loss"].reshape(-1)[0])},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        prof = ops.KernelProfiler()
+        ops.set_profiler(prof)
+        trainer.train_step(batch)
+        ops.set_profiler(None)
+        summ = prof.summary()
+        dom = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        name, r = dom
+        achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+        tot_ms = sum(v["ms"] for v in summ.values())
+        tot_fl = sum(v["flops"] for v in summ.values())
+        result["roofline"] = {
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "kernel": name, "launches_per_step": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
+            "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
+            "all_mfma_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
+                                 "share_of_step": tot_ms / ms_per_step},
+            "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(summ.items())},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(mods, fidx)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

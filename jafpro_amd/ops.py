@@ -53,6 +53,40 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 _PLAN_CACHE = {}
 _PACK_CACHE = {}
+_PROF = None
+
+
+class KernelProfiler:
+    """Optional per-launch timing of the MFMA kernels with events on the launch stream
+    (bench.py's roofline leg).  Records (kernel name, algorithmic FLOPs, start, end)."""
+
+    def __init__(self):
+        self.records = []
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, name, flops, ev0):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream())
+        self.records.append((name, float(flops), ev0, ev1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1 in self.records:
+            r = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            r["launches"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["flops"] += flops
+        return out
+
+
+def set_profiler(p):
+    global _PROF
+    _PROF = p
 
 
 def _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, specs, w_cin_tot,
@@ -113,8 +147,12 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
     pl = _plan(key, d, 0)
     wpk = _packed(weight, w_rows_tot, d, pl, mode, key[:17])
     ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+    ev = _PROF.begin() if _PROF is not None else None
     check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
                                _p(out)), "jaf_conv2d_fwd")
+    if ev is not None:
+        _PROF.end("conv_mfma_kernel<%d, %d, %d, false>" % (3 if (KH == 3 and KW == 3) else 0, pl.MT, pl.NT),
+                  2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
     return out
 
 
@@ -168,7 +206,10 @@ class _ConvFn(Function):
             d = _make_desc(m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW, m.KH, m.KW, m.stride, m.pad, m.pad, 1,
                            m.specs, m.cin_tot, 0, m.G * m.Cout, 0, ACT_NONE, 0.0)
             ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+            ev = _PROF.begin() if _PROF is not None else None
             check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 0), "jaf_conv2d_wgrad")
+            if ev is not None:
+                _PROF.end("conv_wgrad_kernel", 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
         if ctx.has_bias and ctx.needs_input_grad[1]:
             db = torch.empty(m.G * m.Cout, device=dy.device, dtype=torch.float32)
             check(L.jaf_channel_sum(_s(), _p(dz), m.N, m.G * m.Cout, 0, m.G * m.Cout, m.OH * m.OW, _p(db), 0),
@@ -259,10 +300,13 @@ class _ConvLSTMFn(Function):
             d = _make_desc(N, G, Cin, 4 * C, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, 2 * C, 0, 4 * GC, 0, ACT_NONE, 0.0)
             pl = _plan(key, d, 1)
             wpk = _packed(weight, 4 * C, d, pl, PACK_LSTM, key)
+            ev = _PROF.begin() if _PROF is not None else None
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
                                           None if first else _p(hs[t - 1]), _p(wpk), _p(bias),
                                           None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
                                           _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd")
+            if ev is not None:
+                _PROF.end("conv_mfma_kernel<3, %d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
         ctx.G = G
         ctx.need_all = need_all
         if keep:
@@ -303,8 +347,11 @@ class _ConvLSTMFn(Function):
             Cin = C if first else 2 * C
             d = _make_desc(N, G, Cin, 4 * C, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, 2 * C, 0, 4 * GC, 0, ACT_NONE, 0.0)
             acc = 0 if t == T - 1 else 1
+            ev = _PROF.begin() if _PROF is not None else None
             check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None, _p(gt),
                                      _p(dw), acc), "jaf_conv2d_wgrad")
+            if ev is not None:
+                _PROF.end("conv_wgrad_kernel", 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
             check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), acc), "jaf_channel_sum")
             gspec = [(4 * C, 4 * GC, 0, 4 * C)]
             if dx is not None:
