@@ -332,6 +332,18 @@ def g_stage1():
     np.savez_compressed(os.path.join(GOLD, "stage1_b1_t2.npz"), **st)
 
 
+# ---- 11. state_dict schema of the boundary modules -------------------------------
+def g_schema():
+    mods = {"Accumulate_LSTM_no_loss": RN.Accumulate_LSTM_no_loss(), "UNet_inpainter": RN.UNet_inpainter(),
+            "CRN_smaller_fg": RCRN(3, fg=True), "CRN_smaller": RCRN(3),
+            "Propagation3DFlowNet": RPro(9, 32, 2, 3, use_deconv=False),
+            "ImageDiscriminator": RN.ImageDiscriminator(32, 6), "FaceDiscriminator": RN.FaceDiscriminator(32, 6),
+            "ConvLSTM": RConvLSTM((7, 5), 4, [4], [(3, 3)], 1, batch_first=True, bias=True)}
+    schema = {name: [[k, list(v.shape)] for k, v in m.state_dict().items()] for name, m in mods.items()}
+    json.dump(schema, open(os.path.join(GOLD, "state_dict_schema.json"), "w"))
+    report["schema_modules"] = len(schema)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     install_nr_stub()

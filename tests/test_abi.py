@@ -1,0 +1,91 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol include/jafpro_hip.h
+declares, rejects bad arguments before touching a GPU, and plans every layer of the stage-4 networks
+within the LDS budget.  No kernel is launched here."""
+import ctypes
+import os
+
+import pytest
+
+from jafpro_amd import _lib
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in protos if not hasattr(handle, n)]
+    assert not missing, missing
+    assert _lib.lib().jaf_version() == 100
+
+
+def test_header_cites_reference_interfaces():
+    text = open(_lib.HEADER).read()
+    for cite in ("rasterize_cuda.cpp:70-95", "src/convLSTM.py:41-56", "src/crn_model.py:78-87", "src/cal_flow.py:38",
+                 "train/4.convLSTM_flowpro_interval.py:43-76", "rasterize_cuda_kernel.cu:24-169"):
+        assert cite in text, cite
+
+
+def test_bad_arguments_are_rejected_without_a_gpu():
+    L = _lib.lib()
+    assert L.jaf_act_bwd(None, None, None, None, 10, 1, 0.2) == -1
+    assert L.jaf_avgpool_fwd(None, None, None, 1, 8, 8, 4, 4, 3, 2, 1) == -1
+    assert L.jaf_adam_step(None, None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 1) == -1
+    assert L.jaf_texture_warp_fwd(None, None, None, None, 1, 256, 200, 200, 0) == -1
+    d = _lib.ConvDesc()
+    pl = _lib.ConvPlan()
+    assert L.jaf_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(pl)) == -1           # all-zero descriptor
+    assert L.jaf_conv2d_fwd(None, ctypes.byref(d), ctypes.byref(pl), None, None, None, None, None, None) == -1
+    assert L.jaf_conv2d_wgrad(None, ctypes.byref(d), None, None, None, None, None, 0) == -1
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "x")
+
+
+def _desc(N, G, cins, Cout, H, W, k, s, p, dil=1):
+    from jafpro_amd.ops import _make_desc, _out_size
+    specs = [(c, G * c, 0, c) for c in cins]
+    OH, OW = _out_size(H, k, s, p), _out_size(W, k, s, p)
+    return _make_desc(N, G, sum(cins), Cout, H, W, OH, OW, k, k, s, p, p, dil, specs, sum(cins), 0, G * Cout, 0, 0, 0.0)
+
+
+LAYERS = [  # (G, cins, Cout, H, k, s, p): SURVEY Appendix B
+    (24, [3], 12, 200, 5, 1, 2), (24, [12], 24, 200, 3, 2, 1), (24, [24], 24, 100, 3, 1, 1), (24, [24], 48, 50, 3, 2, 1),
+    (24, [48], 96, 25, 3, 2, 1), (24, [96], 96, 13, 3, 1, 1), (24, [96, 48], 48, 25, 3, 1, 1), (24, [12, 12], 6, 200, 3, 1, 1),
+    (24, [6], 3, 200, 3, 1, 1), (24, [96, 72, 48], 96, 25, 3, 1, 1),
+    (1, [3], 64, 256, 3, 1, 1), (1, [256], 256, 256, 3, 1, 1), (1, [3, 64, 512], 256, 128, 3, 1, 1), (1, [3, 512], 512, 4, 3, 1, 1),
+    (1, [3, 256, 512], 512, 8, 3, 1, 1), (1, [256], 3, 256, 1, 1, 0), (1, [9], 32, 262, 7, 1, 0), (1, [32], 1, 262, 7, 1, 0),
+    (1, [6], 32, 256, 3, 2, 1), (1, [128], 256, 8, 3, 2, 1), (1, [512], 512, 16, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("layer", LAYERS)
+def test_plan_covers_stage4_layers(layer):
+    G, cins, Cout, H, k, s, p = layer
+    L = _lib.lib()
+    for N in (1, 8, 32):
+        d = _desc(N, G, cins, Cout, H, H, k, s, p)
+        pl = _lib.ConvPlan()
+        assert L.jaf_conv2d_plan(ctypes.byref(d), 0, ctypes.byref(pl)) == 0
+        assert pl.MT in (1, 2, 3, 4) and pl.NT in (1, 2, 4) and pl.CK % 4 == 0
+        assert pl.lds_bytes <= 160 * 1024 and pl.lds_bytes == (pl.CK * pl.PS + k * k * pl.CK * pl.MRp) * 4
+        assert pl.PS % 32 == 16 and pl.MRp % 32 == 16 and pl.MRp >= 16 * pl.MT
+        assert pl.mblocks * 16 * pl.MT >= Cout and pl.nchunks * pl.CK >= sum(cins)
+        assert pl.tiles_x * pl.tiles_p * 64 * pl.NT >= d.OH * d.OW         # every output pixel is owned by a block
+        assert pl.packed_floats == G * pl.mblocks * pl.nchunks * k * k * pl.CK * pl.MRp
+
+
+def test_lstm_plan_requires_gate_interleaved_tiles():
+    L = _lib.lib()
+    for C, H in ((12, 200), (24, 100), (24, 50), (48, 25), (96, 13)):
+        d = _desc(8, 24, [C, C], 4 * C, H, H, 3, 1, 1)
+        pl = _lib.ConvPlan()
+        assert L.jaf_conv2d_plan(ctypes.byref(d), 1, ctypes.byref(pl)) == 0
+        assert (4 * C) % (16 * pl.MT) == 0
+    d = _desc(1, 1, [5, 5], 20, 8, 8, 3, 1, 1)            # 4C = 20 is not a multiple of 16: rejected
+    assert L.jaf_conv2d_plan(ctypes.byref(d), 1, ctypes.byref(_lib.ConvPlan())) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
+        _lib.lib()

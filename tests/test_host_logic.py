@@ -1,0 +1,116 @@
+"""Host-side logic on CPU: reference-compatible state_dict schemas, the grouped<->per-part key
+mapping, the portable synthetic generator, flat parameter buffers, batch sharding."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from jafpro_amd import synth
+
+
+def _schema(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "state_dict_schema.json")))
+
+
+def _modules():
+    from jafpro_amd.convLSTM import ConvLSTM
+    from jafpro_amd.crn_model import CRN_smaller
+    from jafpro_amd.flow_net import Propagation3DFlowNet
+    from jafpro_amd.networks import Accumulate_LSTM_no_loss, FaceDiscriminator, ImageDiscriminator, UNet_inpainter
+    return {"Accumulate_LSTM_no_loss": Accumulate_LSTM_no_loss, "UNet_inpainter": UNet_inpainter,
+            "CRN_smaller_fg": lambda: CRN_smaller(3, fg=True), "CRN_smaller": lambda: CRN_smaller(3),
+            "Propagation3DFlowNet": lambda: Propagation3DFlowNet(9, 32, 2, 3, use_deconv=False),
+            "ImageDiscriminator": lambda: ImageDiscriminator(32, 6), "FaceDiscriminator": lambda: FaceDiscriminator(32, 6),
+            "ConvLSTM": lambda: ConvLSTM((7, 5), 4, [4], [(3, 3)], 1, batch_first=True, bias=True)}
+
+
+@pytest.mark.parametrize("name", ["Accumulate_LSTM_no_loss", "UNet_inpainter", "CRN_smaller_fg", "CRN_smaller",
+                                  "Propagation3DFlowNet", "ImageDiscriminator", "FaceDiscriminator", "ConvLSTM"])
+def test_state_dict_matches_reference_schema(golden_dir, name):
+    """Keys, order and shapes recorded from the reference modules (oracle/make_golden.py g_schema)."""
+    ref = _schema(golden_dir)[name]
+    sd = _modules()[name]().state_dict()
+    assert [k for k, _ in ref] == list(sd.keys())
+    for k, shape in ref:
+        assert list(sd[k].shape) == shape, k
+
+
+def test_grouped_load_is_the_inverse_of_save():
+    from jafpro_amd.networks import Accumulate_LSTM_no_loss
+    a = synth.load_synth(Accumulate_LSTM_no_loss(), 3)
+    sd = a.state_dict()
+    assert len(sd) == 912 and sum(v.numel() for v in sd.values()) == 28392552
+    # a per-part key addresses the matching slice of the grouped parameter
+    assert torch.equal(sd["Downsampler_list.5.enc3.enconv.0.weight"], a.enc3_w[5 * 24:6 * 24])
+    assert torch.equal(sd["Downsampler_list.7.convLSTM2.cell_list.0.conv.bias"], a.lstm2_b[7 * 96:8 * 96])
+    b = Accumulate_LSTM_no_loss()
+    missing = b.load_state_dict(sd)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    for (ka, va), (kb, vb) in zip(sd.items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    bad = dict(sd)
+    bad.pop("Upsampler_list.3.conv.bias")
+    with pytest.raises(RuntimeError):
+        Accumulate_LSTM_no_loss().load_state_dict(bad)
+
+
+def test_synth_is_deterministic_and_key_order_free():
+    s1 = synth.synth_state_dict({"a.weight": (4, 3, 3, 3), "b.bias": (4,)}, 7)
+    s2 = synth.synth_state_dict({"b.bias": (4,), "a.weight": (4, 3, 3, 3)}, 7)
+    assert np.array_equal(s1["a.weight"], s2["a.weight"]) and np.array_equal(s1["b.bias"], s2["b.bias"])
+    assert not np.array_equal(s1["a.weight"], synth.synth_state_dict({"a.weight": (4, 3, 3, 3)}, 8)["a.weight"])
+    # pinned values: PCG64 streams must not drift between numpy versions / machines
+    assert abs(float(synth.uniform(1, "x", (3,))[0]) - float(np.random.default_rng([1, 0x8cdc1683]).uniform(-1, 1, 3).astype(np.float32)[0])) == 0.0
+
+
+def test_body_mesh_topology():
+    v, f = synth.body_mesh()
+    assert v.shape == (6890, 3) and f.shape == (13776, 3) and f.min() == 0 and f.max() == 6889
+    # closed genus-0 surface: every edge is shared by exactly two faces, F = 2V - 4
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    assert (counts == 2).all() and len(f) == 2 * len(v) - 4
+
+
+def test_stage4_batch_layouts():
+    b = synth.stage4_batch(5, 2)
+    assert b["src_texture_im"].shape == (2, 4, 3, 800, 1200) and b["src_mask_im"].shape == (2, 4, 800, 1200)
+    assert b["tgt_IUV255"].dtype == np.uint8 and b["tgt_IUV255"].shape == (2, 256, 256, 3)
+    I = b["tgt_IUV255"][..., 0]
+    assert I.max() == 24 and 0.25 < (I > 0).mean() < 0.45 and set(np.unique(b["src_mask_im"])) == {0.0, 1.0}
+    assert b["face_bbox"].shape == (2, 4)
+
+
+def test_flat_params_alias_module_parameters():
+    from jafpro_amd.networks import FaceDiscriminator
+    from jafpro_amd.step import FlatParams
+    m = synth.load_synth(FaceDiscriminator(32, 6), 2)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    fp = FlatParams(m)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    p = next(m.parameters())
+    assert p.data_ptr() == fp.flat.data_ptr() and p.grad.data_ptr() == fp.grad.data_ptr()
+    fp.flat.add_(1.0)
+    assert torch.allclose(p, before["main.0.weight"] + 1.0)
+    assert all(q.data_ptr() % 16 == 0 for q in m.parameters())
+
+
+def test_shard_batch():
+    from jafpro_amd.dist import shard_batch
+    b = synth.stage4_batch(5, 4)
+    s0, s1 = shard_batch(b, 0, 2), shard_batch(b, 1, 2)
+    assert s0["tgt_img"].shape[0] == 2 and np.array_equal(np.concatenate([s0["tgt_img"], s1["tgt_img"]]), b["tgt_img"])
+    with pytest.raises(ValueError):
+        shard_batch(b, 0, 3)
+
+
+def test_product_has_no_oracle_dependency():
+    """The product package must never import the oracle (checked on source text)."""
+    root = os.path.join(os.path.dirname(__file__), "..", "jafpro_amd")
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            txt = open(os.path.join(root, fn)).read()
+            assert "import oracle" not in txt and "from oracle" not in txt, fn
