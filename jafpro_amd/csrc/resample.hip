@@ -135,26 +135,50 @@ extern "C" int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t 
     return jaf_launch_status();
 }
 
-// scatter form: dx must be zero-filled by the caller.
+// Gather form of the adjoint (no atomics, deterministic): every input pixel visits the few
+// output rows/columns whose two taps can touch it and re-derives their weights with the same
+// source-index rule as the forward kernel.
+__device__ __forceinline__ void resize_cand(int i, float scale, int out, int align, int& lo, int& hi) {
+    if (scale <= 0.f) { lo = 0; hi = out - 1; return; }
+    const float inv = 1.0f / scale;
+    float a, b;
+    if (align) { a = ((float)i - 1.f) * inv; b = ((float)i + 1.f) * inv; }
+    else { a = ((float)i - 0.5f) * inv - 0.5f; b = ((float)i + 1.5f) * inv - 0.5f; }
+    lo = (int)floorf(a) - 1;
+    hi = (int)ceilf(b) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
 __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
-    const long total = (long)a.N * a.C * a.OH * a.OW;
+    const long total = (long)a.N * a.C * a.H * a.W;
     const long gs = (long)gridDim.x * blockDim.x;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int ox = (int)(e % a.OW);
-        const int oy = (int)((e / a.OW) % a.OH);
-        const long nc = e / ((long)a.OW * a.OH);
-        float* p = dx + nc * a.H * a.W;
-        int y0, y1, x0, x1; float ly, lx;
-        resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
-        resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const float g = dy[e];
-        float* r0 = p + (a.y0 + y0) * a.W + a.x0;
-        float* r1 = p + (a.y0 + y1) * a.W + a.x0;
-        atomicAdd(&r0[x0], g * hy * hx);
-        atomicAdd(&r0[x1], g * hy * lx);
-        atomicAdd(&r1[x0], g * ly * hx);
-        atomicAdd(&r1[x1], g * ly * lx);
+        const int ix = (int)(e % a.W) - a.x0;
+        const int iy = (int)((e / a.W) % a.H) - a.y0;
+        const long nc = e / ((long)a.W * a.H);
+        float acc = 0.f;
+        if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
+            int ylo, yhi, xlo, xhi;
+            resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
+            resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
+            const float* p = dy + nc * a.OH * a.OW;
+            for (int oy = ylo; oy <= yhi; ++oy) {
+                int y0, y1; float ly;
+                resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
+                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;
+                float row = 0.f;
+                for (int ox = xlo; ox <= xhi; ++ox) {
+                    int x0, x1; float lx;
+                    resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
+                    const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                    if (wx != 0.f) row += wx * p[oy * a.OW + ox];
+                }
+                acc += wy * row;
+            }
+        }
+        dx[e] = acc;
     }
 }
 
@@ -165,7 +189,7 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     JAF_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W);
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, 0};
     resize_scales(a);
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_ew_grid((long)N * C * OH * OW)), dim3(256), 0, (hipStream_t)s, dy, dx, a);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_ew_grid((long)N * C * H * W)), dim3(256), 0, (hipStream_t)s, dy, dx, a);
     return jaf_launch_status();
 }
 

@@ -278,27 +278,40 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
 // ---------------------------------------------------------------------------------------------
 // per-channel sum over (n, h, w): bias gradients
 // ---------------------------------------------------------------------------------------------
-__global__ void channel_sum_kernel(const float* x, int N, int ctot, int coff, int C, int HW, float* out,
-                                   int accumulate) {
+__global__ void channel_sum_kernel(const float* x, int N, int ctot, int coff, int C, int HW, float* out, int nsplit) {
     const int c = blockIdx.x;
+    const int split = blockIdx.y;
     double acc = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((long)n * ctot + coff + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) acc += (double)p[i];
+    const long total = (long)N * HW;
+    const long per = (total + nsplit - 1) / nsplit;
+    const long lo = split * per;
+    long hi = lo + per;
+    if (hi > total) hi = total;
+    for (long e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        const long n = e / HW;
+        const long i = e - n * HW;
+        acc += (double)x[(n * ctot + coff + c) * HW + i];
     }
     __shared__ double red[4];
     acc = jaf_wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const double t = red[0] + red[1] + red[2] + red[3];
-        out[c] = (accumulate ? out[c] : 0.f) + (float)t;
-    }
+    if (threadIdx.x == 0) atomicAdd(&out[c], (float)(red[0] + red[1] + red[2] + red[3]));
 }
 
-extern "C" int jaf_channel_sum(jaf_stream_t s, const float* x, int32_t N, int32_t ctot, int32_t coff,
+extern "C" int jaf_channel_sum(jaf_stream_t s_, const float* x, int32_t N, int32_t ctot, int32_t coff,
                                int32_t C, int32_t HW, float* out, int accumulate) {
     JAF_REQUIRE(x && out && N >= 1 && C >= 1 && HW >= 1 && coff >= 0 && coff + C <= ctot);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, x, N, ctot, coff, C, HW, out, accumulate);
+    hipStream_t s = (hipStream_t)s_;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const long total = (long)N * HW;
+    long nsplit = (2048 + C - 1) / C;
+    const long max_split = (total + 4095) / 4096;       // at least 4096 elements per block
+    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit < 1) nsplit = 1;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, (unsigned)nsplit), dim3(256), 0, s, x, N, ctot, coff, C, HW, out, (int)nsplit);
     return jaf_launch_status();
 }

@@ -491,7 +491,7 @@ class _ResizeFn(Function):
         if nearest:
             raise RuntimeError("nearest resize has no backward on this path")
         dy = _c(dy)
-        dx = torch.zeros((N, C, H, W), device=dy.device, dtype=torch.float32)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
         check(lib().jaf_resize_bwd(_s(), _p(dy), _p(dx), N, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0),
               "jaf_resize_bwd")
         return dx, None, None, None, None, None
