@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["f32", "bf16", "bf16x3"],
+                    help="matrix-core arithmetic of the convolutions (tensors stay fp32 in HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -80,6 +82,7 @@ def main():
 
     from jafpro_amd import ops, synth
     from jafpro_amd.step import Stage4Trainer, _to_dev
+    ops.set_precision(args.precision)
     _, fidx = synth.body_mesh()
     M, mods = build_models(fidx)
     M = M.cuda()
@@ -112,7 +115,7 @@ def main():
         "metric": "train-step frames/sec, 256x256 30-frame clips, stage-4",
         "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "stage-4 full train step (G fwd+bwd, VGG+L1, 3x D, face-D, 6x Adam), "
                                "B=%d/GPU, T=4 refs, 256x256, 1 target frame/sample (configs[2] at fp32)" % B,
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,

@@ -61,7 +61,16 @@ typedef struct jaf_conv_desc {
     int32_t out_ctot, out_coff;
     int32_t act;                /* JAF_ACT_* applied after bias */
     float slope;                /* LeakyReLU negative slope */
+    int32_t precision;          /* JAF_PREC_*: arithmetic of the matrix-core contraction */
 } jaf_conv_desc;
+
+/* Matrix-core arithmetic of the convolution family (storage is fp32 in every mode):
+ *   JAF_PREC_F32     v_mfma_f32_16x16x4_f32, exact fp32 products (the <=1e-3 parity path);
+ *   JAF_PREC_BF16    operands rounded to bf16 (RNE) when staged in LDS, fp32 accumulate
+ *                    (v_mfma_f32_16x16x32_bf16; BASELINE.json configs[2] "bf16");
+ *   JAF_PREC_BF16X3  operands split hi+lo in bf16, a*b ~= ah*bh + al*bh + ah*bl, fp32 accumulate:
+ *                    ~2^-17 relative error per product at 3 bf16 MFMAs per k-step.          */
+enum { JAF_PREC_F32 = 0, JAF_PREC_BF16 = 1, JAF_PREC_BF16X3 = 2 };
 
 /* Tiling chosen by the library for a descriptor (jaf_conv2d_plan). */
 typedef struct jaf_conv_plan {
@@ -74,7 +83,14 @@ typedef struct jaf_conv_plan {
     int32_t MRp;                /* LDS pitch of a weight row group */
     int32_t nchunks, mblocks;
     int32_t lds_bytes;
-    int64_t packed_floats;      /* size of the packed-weight buffer for this plan */
+    int64_t packed_floats;      /* size of the packed-weight buffer for this plan, in 4-byte units */
+    /* bf16 matrix-core path (precision != JAF_PREC_F32); CK == 8*NG there */
+    int32_t precision;
+    int32_t NG;                 /* 8-channel groups per LDS chunk (1..4) */
+    int32_t ng_last;            /* groups in the last chunk */
+    int32_t nsteps, nsteps_last;/* 32-deep MFMA k-steps per chunk: ceil(KH*KW*groups/4) */
+    int32_t npos;               /* PH*PW patch positions */
+    int32_t plane;              /* bytes of one (split, group) patch plane, multiple of 256 */
 } jaf_conv_plan;
 
 enum { JAF_PACK_FWD = 0, JAF_PACK_DGRAD = 1, JAF_PACK_LSTM = 2 };

@@ -56,6 +56,7 @@ class ConvDesc(ctypes.Structure):
         ("w_cin_tot", ctypes.c_int32), ("w_cin_off", ctypes.c_int32),
         ("out_ctot", ctypes.c_int32), ("out_coff", ctypes.c_int32),
         ("act", ctypes.c_int32), ("slope", ctypes.c_float),
+        ("precision", ctypes.c_int32),
     ]
 
 
@@ -66,11 +67,15 @@ class ConvPlan(ctypes.Structure):
         ("PH", ctypes.c_int32), ("PW", ctypes.c_int32), ("PWp", ctypes.c_int32), ("PS", ctypes.c_int32),
         ("MRp", ctypes.c_int32), ("nchunks", ctypes.c_int32), ("mblocks", ctypes.c_int32),
         ("lds_bytes", ctypes.c_int32), ("packed_floats", ctypes.c_int64),
+        ("precision", ctypes.c_int32), ("NG", ctypes.c_int32), ("ng_last", ctypes.c_int32),
+        ("nsteps", ctypes.c_int32), ("nsteps_last", ctypes.c_int32), ("npos", ctypes.c_int32),
+        ("plane", ctypes.c_int32),
     ]
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 PACK_FWD, PACK_DGRAD, PACK_LSTM = 0, 1, 2
+PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 
 _LIB = None
 

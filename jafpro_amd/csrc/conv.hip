@@ -16,7 +16,7 @@
 // (row 4c+gate) so that the four accumulator registers of a lane are i,f,o,g of ONE hidden
 // channel at ONE pixel; the cell update runs in the epilogue and the 4C-channel gate tensor
 // is never round-tripped through HBM.
-#include "jaf_common.h"
+#include "conv_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -240,12 +240,16 @@ static bool desc_ok(const jaf_conv_desc* d) {
     if (d->w_cin_off < 0 || d->w_cin_tot < 1) return false;
     if (d->out_coff < 0 || d->out_coff + d->G * d->Cout > d->out_ctot) return false;
     if (d->pad_t < 0 || d->pad_l < 0) return false;
+    if (d->precision < JAF_PREC_F32 || d->precision > JAF_PREC_BF16X3) return false;
     return true;
 }
 
 extern "C" int jaf_conv2d_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan) {
     JAF_REQUIRE(desc_ok(d) && plan);
     if (lstm) JAF_REQUIRE((d->Cout & 3) == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1);
+    if (d->precision != JAF_PREC_F32) return jafb_plan(d, lstm, plan);
+    plan->precision = JAF_PREC_F32;
+    plan->NG = plan->ng_last = plan->nsteps = plan->nsteps_last = plan->npos = plan->plane = 0;
     const int M = d->Cout;
     // rows per workgroup: least padding, then the larger tile (more reuse of the patch)
     int bestMT = 1;
@@ -363,6 +367,7 @@ __global__ void conv_pack_kernel(const PackArgs a) {
 extern "C" int jaf_conv2d_pack(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode,
                                const float* w, int32_t w_rows_tot, float* packed) {
     JAF_REQUIRE(desc_ok(d) && plan && w && packed);
+    if (d->precision != JAF_PREC_F32) return jafb_pack((hipStream_t)s, d, plan, mode, w, w_rows_tot, packed);
     PackArgs a;
     a.w = w;
     a.out = packed;
@@ -440,6 +445,7 @@ static int launch_mt(const ConvArgs& a, hipStream_t s) {
 
 static bool plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     if (!p) return false;
+    if (p->precision != JAF_PREC_F32) return false;
     if (p->MT < 1 || p->MT > 4) return false;
     if (p->NT != 1 && p->NT != 2 && p->NT != 4) return false;
     if (p->CK < 4 || (p->CK & 3)) return false;
@@ -468,9 +474,12 @@ static void fill_args(ConvArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* 
 extern "C" int jaf_conv2d_fwd(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                               const float* src0, const float* src1, const float* src2,
                               const float* packed_w, const float* bias, float* out) {
-    JAF_REQUIRE(desc_ok(d) && plan_ok(d, plan) && src0 && packed_w && out);
+    JAF_REQUIRE(desc_ok(d) && plan && src0 && packed_w && out);
     JAF_REQUIRE(d->nsrc < 2 || src1);
     JAF_REQUIRE(d->nsrc < 3 || src2);
+    if (d->precision != JAF_PREC_F32)
+        return jafb_fwd((hipStream_t)s, d, plan, src0, src1, src2, packed_w, bias, out);
+    JAF_REQUIRE(plan_ok(d, plan));
     ConvArgs a;
     fill_args(a, d, plan);
     a.src[0] = src0;
@@ -487,11 +496,14 @@ extern "C" int jaf_convlstm_cell_fwd(jaf_stream_t s, const jaf_conv_desc* d, con
                                      const float* x, const float* h_prev, const float* packed_w,
                                      const float* bias, const float* c_prev,
                                      float* h_out, float* c_out, float* gates_out) {
-    JAF_REQUIRE(desc_ok(d) && plan_ok(d, plan) && x && packed_w && bias && h_out && c_out);
+    JAF_REQUIRE(desc_ok(d) && plan && x && packed_w && bias && h_out && c_out);
     JAF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->Cout & 3) == 0);
     JAF_REQUIRE(d->Cout % (16 * plan->MT) == 0);
     JAF_REQUIRE((d->nsrc == 2) == (h_prev != nullptr));
     JAF_REQUIRE(d->H == d->OH && d->W == d->OW);
+    if (d->precision != JAF_PREC_F32)
+        return jafb_lstm((hipStream_t)s, d, plan, x, h_prev, packed_w, bias, c_prev, h_out, c_out, gates_out);
+    JAF_REQUIRE(plan_ok(d, plan));
     ConvArgs a;
     fill_args(a, d, plan);
     a.src[0] = x;

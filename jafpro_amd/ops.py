@@ -14,9 +14,9 @@ import torch
 from torch.autograd import Function
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DGRAD, PACK_FWD,
-                   PACK_LSTM, ConvDesc, ConvPlan, check, lib)
+                   PACK_LSTM, PREC_BF16, PREC_BF16X3, PREC_F32, ConvDesc, ConvPlan, check, lib)
 
-__all__ = ["conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
+__all__ = ["set_precision", "get_precision", "conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
            "reflect_pad", "texture_warp", "grid_sample", "blend", "mul_bcast", "part_mask_mul",
            "atlas_to_parts", "vgg_preprocess", "l1_loss", "bce_loss", "linear", "adam_step",
            "project_faces", "rasterize_fim_wim", "bc_transform", "axpby", "ACT_NONE", "ACT_LRELU",
@@ -54,6 +54,33 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 _PLAN_CACHE = {}
 _PACK_CACHE = {}
 _PROF = None
+_PRECISION = PREC_F32
+_PREC_NAMES = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+
+
+def set_precision(name: str) -> str:
+    """Matrix-core arithmetic of every convolution issued from now on (include/jafpro_hip.h
+    JAF_PREC_*): "f32" exact fp32 MFMA (the <=1e-3 parity path), "bf16" bf16 operands / fp32
+    accumulate (BASELINE configs[2]), "bf16x3" split-bf16 (hi+lo) emulation of fp32 products.
+    Tensors stay fp32 in HBM in every mode.  Returns the previous setting."""
+    global _PRECISION
+    if name not in _PREC_NAMES:
+        raise ValueError("precision must be one of %s" % sorted(_PREC_NAMES))
+    prev = get_precision()
+    _PRECISION = _PREC_NAMES[name]
+    return prev
+
+
+def get_precision() -> str:
+    return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
+
+
+def _kname(lstm: bool, KH, KW, pl) -> str:
+    if pl.precision == PREC_F32:
+        return "conv_mfma_kernel<%d, %d, %d, %s>" % (3 if (KH == 3 and KW == 3) else 0, pl.MT, pl.NT,
+                                                      "true" if lstm else "false")
+    return "conv_bf16_kernel<%d, %d, %d, %s>" % (pl.MT, pl.NT, 3 if pl.precision == PREC_BF16X3 else 1,
+                                                  "true" if lstm else "false")
 
 
 class KernelProfiler:
@@ -102,11 +129,12 @@ def _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
     d.w_cin_tot, d.w_cin_off = w_cin_tot, w_cin_off
     d.out_ctot, d.out_coff = out_ctot, out_coff
     d.act, d.slope = act, slope
+    d.precision = _PRECISION
     return d
 
 
 def _plan(key, d: ConvDesc, lstm: int) -> ConvPlan:
-    k = (key, lstm)
+    k = (key, lstm, d.precision)
     pl = _PLAN_CACHE.get(k)
     if pl is None:
         pl = ConvPlan()
@@ -117,7 +145,7 @@ def _plan(key, d: ConvDesc, lstm: int) -> ConvPlan:
 
 def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mode: int, key) -> torch.Tensor:
     """Packs `weight` for (desc, plan, mode); cached while the tensor is not modified."""
-    ck = (weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK)
+    ck = (weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision)
     hit = _PACK_CACHE.get(ck)
     if hit is not None:
         return hit
@@ -151,8 +179,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
     check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
                                _p(out)), "jaf_conv2d_fwd")
     if ev is not None:
-        _PROF.end("conv_mfma_kernel<%d, %d, %d, false>" % (3 if (KH == 3 and KW == 3) else 0, pl.MT, pl.NT),
-                  2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
+        _PROF.end(_kname(False, KH, KW, pl), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
     return out
 
 
@@ -306,7 +333,7 @@ class _ConvLSTMFn(Function):
                                           None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
                                           _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd")
             if ev is not None:
-                _PROF.end("conv_mfma_kernel<3, %d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                _PROF.end(_kname(True, 3, 3, pl), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
         ctx.G = G
         ctx.need_all = need_all
         if keep:

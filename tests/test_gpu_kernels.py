@@ -83,6 +83,58 @@ def test_conv2d_forward_backward(case):
     assert maxerr(bd.grad, br.grad) <= 3e-4 * max(1.0, br.grad.abs().max().item()), "bias grad"
 
 
+def _bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_bf16_matrix_core_modes(case, mode):
+    """The bf16 matrix-core paths (include/jafpro_hip.h JAF_PREC_*).  "bf16": operands are rounded
+    to bf16 (RNE) and products accumulate in fp32, so the result must equal a float64 convolution
+    of the ROUNDED operands up to fp32 accumulation error (2e-5 * scale).  "bf16x3": hi+lo split,
+    must agree with the unrounded fp32 reference to 4e-5 * scale (2^-17 per product)."""
+    ops = _ops()
+    N, G, cins, Cout, H, W, k, s, p, act = case
+    srcs = [R(10 + i, N, G * c, H, W) for i, c in enumerate(cins)]
+    Cin = sum(cins)
+    w = R(3, G * Cout, Cin, k, k, lo=-0.3, hi=0.3)
+    b = R(4, G * Cout)
+    rnd = _bf16r if mode == "bf16" else (lambda t: t.double())
+    xs = [rnd(t).view(N, G, c, H, W) for t, c in zip(srcs, cins)]
+    xcat = torch.cat(xs, 2).reshape(N, G * Cin, H, W).requires_grad_(True)
+    wr = rnd(w).requires_grad_(True)
+    z_ref = F.conv2d(xcat, wr, b.double(), stride=s, padding=p, groups=G)
+    actf = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu, 3: torch.sigmoid}[act]
+    y_ref = actf(z_ref)
+    proj = R(5, *y_ref.shape)
+    # dgrad reference: the kernel rounds dz (not dy) to bf16
+    dz = torch.autograd.grad(y_ref, z_ref, proj.double(), retain_graph=True)[0]
+    gx = torch.autograd.grad(z_ref, xcat, rnd(dz.float()))[0].view(N, G, Cin, H, W)
+    prev = ops.set_precision(mode)
+    try:
+        ds = [dev(t).requires_grad_(True) for t in srcs]
+        wd, bd = dev(w).requires_grad_(True), dev(b).requires_grad_(True)
+        y = ops.conv2d(ds, wd, bd, stride=s, pad=p, act=act, slope=0.2, groups=G)
+        (y * dev(proj)).sum().backward()
+    finally:
+        ops.set_precision(prev)
+    tol = 2e-5 if mode == "bf16" else 4e-5
+    scale = max(1.0, z_ref.abs().max().item())
+    assert maxerr(y, y_ref) <= tol * scale
+    off = 0
+    for t, c in zip(ds, cins):
+        ref = gx[:, :, off:off + c].reshape(N, G * c, H, W)
+        # dz is rounded to bf16 on the GPU from an fp32 value that differs from the float64
+        # reference in the last bits: a handful of round-to-nearest ties flip (one bf16 ulp of
+        # one dz element); everything else must be at accumulation-order accuracy.
+        err = (t.grad.detach().cpu().double() - ref).abs()
+        sc = max(1.0, ref.abs().max().item())
+        assert (err > 2 * tol * sc).double().mean().item() <= 2e-3, "dgrad source at %d" % off
+        assert err.max().item() <= 8e-3 * sc, "dgrad source at %d" % off
+        off += c
+
+
 def test_conv2d_shared_source():
     """inpainter dec1: the 72-channel global embed is read by all 24 groups (src/networks.py:1164)."""
     ops = _ops()
