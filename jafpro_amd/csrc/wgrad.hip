@@ -9,7 +9,7 @@
 // (image, pixel-tile) list accumulating in registers, and finishes with fp32 atomics -- the
 // column index is the memory order of the weight tensor, so each atomic wave-instruction
 // covers 4 rows x 64 contiguous bytes.
-#include "jaf_common.h"
+#include "conv_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -199,6 +199,11 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
     }
     hipStream_t s = (hipStream_t)s_;
     const int KHW = d->KH * d->KW;
+    JAF_REQUIRE(d->precision >= JAF_PREC_F32 && d->precision <= JAF_PREC_BF16X3);
+    // bf16 matrix cores for the 3x3 layers (all but a handful of first/last layers); BF16X3 keeps
+    // the exact fp32 kernel here: weight gradients only feed Adam, not the generated frame.
+    if (d->precision == JAF_PREC_BF16 && d->KH == 3 && d->KW == 3)
+        return jafb_wgrad(s, d, src0, src1, src2, dz, dw, accumulate, nullptr, 0);
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->G * d->Cout * d->w_cin_tot * KHW, s);
         if (e != hipSuccess) return (int)e;

@@ -110,7 +110,8 @@ def test_conv2d_bf16_matrix_core_modes(case, mode):
     proj = R(5, *y_ref.shape)
     # dgrad reference: the kernel rounds dz (not dy) to bf16
     dz = torch.autograd.grad(y_ref, z_ref, proj.double(), retain_graph=True)[0]
-    gx = torch.autograd.grad(z_ref, xcat, rnd(dz.float()))[0].view(N, G, Cin, H, W)
+    gx, gw = torch.autograd.grad(z_ref, [xcat, wr], rnd(dz.float()))
+    gx = gx.view(N, G, Cin, H, W)
     prev = ops.set_precision(mode)
     try:
         ds = [dev(t).requires_grad_(True) for t in srcs]
@@ -133,6 +134,16 @@ def test_conv2d_bf16_matrix_core_modes(case, mode):
         assert (err > 2 * tol * sc).double().mean().item() <= 2e-3, "dgrad source at %d" % off
         assert err.max().item() <= 8e-3 * sc, "dgrad source at %d" % off
         off += c
+    # weight gradient: bf16 matrix cores for 3x3 layers in "bf16" mode (x and dz rounded), the exact
+    # fp32 kernel otherwise -- either way it must match the float64 reference of what was rounded.
+    if mode == "bf16" and k != 3:
+        gw = torch.autograd.grad(F.conv2d(torch.cat([t.double().view(N, G, c, H, W) for t, c in zip(srcs, cins)], 2)
+                                          .reshape(N, G * Cin, H, W), wr, None, stride=s, padding=p, groups=G),
+                                 wr, dz)[0]
+    err = (wd.grad.detach().cpu().double() - gw).abs()
+    sc = max(1.0, gw.abs().max().item())
+    assert (err > 4 * tol * sc).double().mean().item() <= 2e-3, "wgrad"
+    assert err.max().item() <= 8e-3 * sc, "wgrad"
 
 
 def test_conv2d_shared_source():
