@@ -8,6 +8,7 @@ CHECK_CONTIGUOUS, rasterize_cuda.cpp:66-68).
 from __future__ import annotations
 
 import ctypes
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -144,17 +145,18 @@ def _plan(key, d: ConvDesc, lstm: int) -> ConvPlan:
 
 
 def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mode: int, key) -> torch.Tensor:
-    """Packs `weight` for (desc, plan, mode); cached while the tensor is not modified."""
-    ck = (weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision)
+    """Packs `weight` for (desc, plan, mode); cached while the SAME tensor object is not modified
+    (the entry holds a weak reference: a new tensor that reuses a freed address must not hit)."""
+    ck = (id(weight), weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision)
     hit = _PACK_CACHE.get(ck)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[0]() is weight:
+        return hit[1]
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
     buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
     check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
           "jaf_conv2d_pack")
-    _PACK_CACHE[ck] = buf
+    _PACK_CACHE[ck] = (weakref.ref(weight), buf)
     return buf
 
 
