@@ -169,14 +169,14 @@ int jaf_layernorm_lrelu_bwd(jaf_stream_t s, const float* dy, const float* x, con
  * stats = {mean[C], rstd[C]} (2*C floats).  training=0 normalises with running stats.          */
 int jaf_batchnorm_stats(jaf_stream_t s, const float* x, int32_t N, int32_t C, int32_t HW,
                         float eps, float momentum, float* running_mean, float* running_var,
-                        float* stats, int training);
+                        float* stats, int training, double* workspace /* 2*C doubles */);
 int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float* stats, const float* weight,
                           const float* bias, const float* residual, float* y, int32_t N,
                           int32_t C, int32_t HW, int act, float slope);
 int jaf_batchnorm_act_bwd(jaf_stream_t s, const float* dy, const float* x, const float* y,
                           const float* stats, const float* weight, float* dx, float* dweight,
                           float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
-                          int training);
+                          int training, double* workspace /* 2*C doubles */);
 
 /* ------------------------------------------------------------------------------------------
  * Resampling.

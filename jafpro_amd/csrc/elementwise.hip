@@ -6,54 +6,95 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ activation backward
+__device__ __forceinline__ float act_grad(float yv, int act, float slope) {
+    switch (act) {
+        case JAF_ACT_LRELU: return yv > 0.f ? 1.f : slope;
+        case JAF_ACT_RELU: return yv > 0.f ? 1.f : 0.f;
+        case JAF_ACT_SIGMOID: return yv * (1.f - yv);
+        case JAF_ACT_TANH: return 1.f - yv * yv;
+        default: return 1.f;
+    }
+}
+
 __global__ void act_bwd_kernel(const float* dy, const float* y, float* dz, long n, int act, float slope) {
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float yv = y[i];
-        float g;
-        switch (act) {
-            case JAF_ACT_LRELU: g = yv > 0.f ? 1.f : slope; break;
-            case JAF_ACT_RELU: g = yv > 0.f ? 1.f : 0.f; break;
-            case JAF_ACT_SIGMOID: g = yv * (1.f - yv); break;
-            case JAF_ACT_TANH: g = 1.f - yv * yv; break;
-            default: g = 1.f;
-        }
-        dz[i] = dy[i] * g;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dz[i] = dy[i] * act_grad(y[i], act, slope);
+}
+
+// 16 bytes per lane (cdna_hip_programming.md Guideline 13): the vector memory pipe works per
+// instruction, a dword-per-lane stream reaches a fraction of the HBM rate.
+__global__ void act_bwd_kernel4(const f32x4* dy, const f32x4* y, f32x4* dz, long n4, int act, float slope) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 g = dy[i], yv = y[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = g[k] * act_grad(yv[k], act, slope);
+        dz[i] = o;
     }
+}
+
+static inline bool jaf_al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
 }
 
 extern "C" int jaf_act_bwd(jaf_stream_t s, const float* dy, const float* y, float* dz, int64_t n, int act, float slope) {
     JAF_REQUIRE(dy && y && dz && n >= 0);
     if (n == 0) return JAF_OK;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, y, dz, (long)n, act, slope);
+    if ((n & 3) == 0 && jaf_al16(dy, y, dz))
+        hipLaunchKernelGGL(act_bwd_kernel4, dim3(jaf_ew_grid(n >> 2)), dim3(256), 0, (hipStream_t)s, (const f32x4*)dy,
+                           (const f32x4*)y, (f32x4*)dz, (long)(n >> 2), act, slope);
+    else
+        hipLaunchKernelGGL(act_bwd_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, dy, y, dz, (long)n, act, slope);
     return jaf_launch_status();
 }
 
 // ------------------------------------------------------------------ ConvLSTM gate backward
 // gates: [N, G*4C, HW] (i,f,o,g per group), h/c tensors: [N, G*C, HW]  (src/convLSTM.py:48-54)
-__global__ void lstm_gates_bwd_kernel(int N, int G, int C, int HW, const float* dh, const float* dc_next,
-                                      float* gates, const float* c_prev, const float* c_cur, float* dc_prev) {
-    const long total = (long)N * G * C * HW;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int pix = (int)(e % HW);
-        const long nc = e / HW;            // n*G*C + g*C + c
-        const int c = (int)(nc % C);
-        const long ng = nc / C;            // n*G + g
-        float* gp = gates + (ng * 4 * C + c) * HW + pix;
-        const long cs = (long)C * HW;
-        const float gi = gp[0], gf = gp[cs], go = gp[2 * cs], gg = gp[3 * cs];
-        const float cc = c_cur[e];
-        const float tc = jaf_tanh(cc);
-        const float dhv = dh[e];
-        float dc = dhv * go * (1.f - tc * tc);
-        if (dc_next) dc += dc_next[e];
-        const float cp = c_prev ? c_prev[e] : 0.f;
-        gp[0] = dc * gg * gi * (1.f - gi);
-        gp[cs] = dc * cp * gf * (1.f - gf);
-        gp[2 * cs] = dhv * tc * go * (1.f - go);
-        gp[3 * cs] = dc * gi * (1.f - gg * gg);
-        dc_prev[e] = dc * gf;
+// grid: (pixel blocks, C, N*G); V = 4 pixels per lane when HW % 4 == 0.
+template <int V>
+__global__ void lstm_gates_bwd_kernel(int C, int HW, const float* dh, const float* dc_next, float* gates,
+                                      const float* c_prev, const float* c_cur, float* dc_prev) {
+    typedef float fv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
+    const int c = blockIdx.y;
+    const long ng = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const long e = (ng * C + c) * (long)HW + pix;
+    float* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
+    const long cs = (long)C * HW;
+    float gi[V], gf[V], go[V], gg[V], cc[V], dhv[V], dcn[V], cp[V];
+    if (V == 4) {
+        *(f32x4*)gi = *(const f32x4*)gp; *(f32x4*)gf = *(const f32x4*)(gp + cs);
+        *(f32x4*)go = *(const f32x4*)(gp + 2 * cs); *(f32x4*)gg = *(const f32x4*)(gp + 3 * cs);
+        *(f32x4*)cc = *(const f32x4*)(c_cur + e); *(f32x4*)dhv = *(const f32x4*)(dh + e);
+        if (dc_next) *(f32x4*)dcn = *(const f32x4*)(dc_next + e);
+        if (c_prev) *(f32x4*)cp = *(const f32x4*)(c_prev + e);
+    } else {
+        gi[0] = gp[0]; gf[0] = gp[cs]; go[0] = gp[2 * cs]; gg[0] = gp[3 * cs];
+        cc[0] = c_cur[e]; dhv[0] = dh[e];
+        if (dc_next) dcn[0] = dc_next[e];
+        if (c_prev) cp[0] = c_prev[e];
+    }
+    float o0[V], o1[V], o2[V], o3[V], o4[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const float tc = jaf_tanh(cc[k]);
+        float dc = dhv[k] * go[k] * (1.f - tc * tc);
+        if (dc_next) dc += dcn[k];
+        const float cpv = c_prev ? cp[k] : 0.f;
+        o0[k] = dc * gg[k] * gi[k] * (1.f - gi[k]);
+        o1[k] = dc * cpv * gf[k] * (1.f - gf[k]);
+        o2[k] = dhv[k] * tc * go[k] * (1.f - go[k]);
+        o3[k] = dc * gi[k] * (1.f - gg[k] * gg[k]);
+        o4[k] = dc * gf[k];
+    }
+    if (V == 4) {
+        *(f32x4*)gp = *(f32x4*)o0; *(f32x4*)(gp + cs) = *(f32x4*)o1;
+        *(f32x4*)(gp + 2 * cs) = *(f32x4*)o2; *(f32x4*)(gp + 3 * cs) = *(f32x4*)o3;
+        *(f32x4*)(dc_prev + e) = *(f32x4*)o4;
+    } else {
+        gp[0] = o0[0]; gp[cs] = o1[0]; gp[2 * cs] = o2[0]; gp[3 * cs] = o3[0]; dc_prev[e] = o4[0];
     }
 }
 
@@ -61,9 +102,14 @@ extern "C" int jaf_convlstm_gates_bwd(jaf_stream_t s, int32_t N, int32_t G, int3
                                       const float* dh, const float* dc_next, float* gates,
                                       const float* c_prev, const float* c_cur, float* dc_prev) {
     JAF_REQUIRE(dh && gates && c_cur && dc_prev && N >= 1 && G >= 1 && C >= 1 && HW >= 1);
-    const long total = (long)N * G * C * HW;
-    hipLaunchKernelGGL(lstm_gates_bwd_kernel, dim3(jaf_ew_grid(total)), dim3(256), 0, (hipStream_t)s,
-                       N, G, C, HW, dh, dc_next, gates, c_prev, c_cur, dc_prev);
+    JAF_REQUIRE(C <= 65535 && (long)N * G <= 65535);
+    const bool v4 = (HW % 4 == 0) && jaf_al16(dh, gates, c_cur, dc_prev) && jaf_al16(dc_next, c_prev);
+    if (v4)
+        hipLaunchKernelGGL(lstm_gates_bwd_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N * G), dim3(256), 0, (hipStream_t)s,
+                           C, HW, dh, dc_next, gates, c_prev, c_cur, dc_prev);
+    else
+        hipLaunchKernelGGL(lstm_gates_bwd_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N * G), dim3(256), 0, (hipStream_t)s,
+                           C, HW, dh, dc_next, gates, c_prev, c_cur, dc_prev);
     return jaf_launch_status();
 }
 

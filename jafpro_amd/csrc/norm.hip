@@ -2,29 +2,55 @@
 //  * CRN LayerNorm (src/crn_model.py:67-87): per-sample statistics over C*H*W, Bessel-corrected
 //    std, eps added to the std, per-channel affine, followed by LeakyReLU(0.01) (:100).
 //  * BatchNorm2d in training mode (propagater and discriminators), SURVEY F9.
-// Reductions run in fp64 (sum and sum of squares of up to 16.7 M fp32 values per sample).
+// All kernels are HBM-bound: 16 bytes per lane whenever H*W % 4 == 0, (pixel block, channel,
+// image) grids so that no lane divides, reductions split over enough workgroups to fill 256 CUs
+// and finished with fp64 atomics (sums of up to 16.7 M fp32 values per sample).
 #include "jaf_common.h"
 
-// ------------------------------------------------------------------ LayerNorm
-__global__ void ln_partial_kernel(const float* x, long chw, double* ws) {
-    const int n = blockIdx.y;
-    const float* p = x + (long)n * chw;
-    double s = 0.0, ss = 0.0;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += stride) {
-        const double v = (double)p[i];
-        s += v;
-        ss += v * v;
-    }
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline bool al16(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr) {
+    return ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c) | ((uintptr_t)d)) & 15) == 0;
+}
+
+__device__ __forceinline__ void block_sum2_atomic(double s, double ss, double* out_s, double* out_ss) {
     __shared__ double rs[4], rss[4];
     s = jaf_wave_sum(s);
     ss = jaf_wave_sum(ss);
     if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rss[threadIdx.x >> 6] = ss; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&ws[2 * n], rs[0] + rs[1] + rs[2] + rs[3]);
-        atomicAdd(&ws[2 * n + 1], rss[0] + rss[1] + rss[2] + rss[3]);
+        atomicAdd(out_s, rs[0] + rs[1] + rs[2] + rs[3]);
+        atomicAdd(out_ss, rss[0] + rss[1] + rss[2] + rss[3]);
     }
+}
+
+// ------------------------------------------------------------------ LayerNorm
+template <int V>
+__global__ void ln_partial_kernel(const float* x, long chw, double* ws) {
+    const int n = blockIdx.y;
+    const float* p = x + (long)n * chw;
+    double s = 0.0, ss = 0.0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (V == 4) {
+        const f32x4* p4 = (const f32x4*)p;
+        const long n4 = chw >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+            const f32x4 v = p4[i];
+            // pairwise in fp32 first (4 values), then fp64: one conversion per 16 bytes
+            const float a = v[0] + v[1], b = v[2] + v[3];
+            const float qa = v[0] * v[0] + v[1] * v[1], qb = v[2] * v[2] + v[3] * v[3];
+            s += (double)a + (double)b;
+            ss += (double)qa + (double)qb;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chw; i += stride) {
+            const double v = (double)p[i];
+            s += v;
+            ss += v * v;
+        }
+    }
+    block_sum2_atomic(s, ss, &ws[2 * n], &ws[2 * n + 1]);
 }
 
 __global__ void ln_finalize_kernel(const double* ws, int N, long chw, float eps, float* stats) {
@@ -41,41 +67,59 @@ __global__ void ln_finalize_kernel(const double* ws, int N, long chw, float eps,
 
 extern "C" int jaf_layernorm_stats(jaf_stream_t s_, const float* x, int32_t N, int64_t chw, float eps,
                                    double* workspace, float* stats) {
-    JAF_REQUIRE(x && workspace && stats && N >= 1 && chw >= 1);
+    JAF_REQUIRE(x && workspace && stats && N >= 1 && chw >= 1 && N <= 65535);
     hipStream_t s = (hipStream_t)s_;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * N, s);
     if (e != hipSuccess) return (int)e;
-    int gx = jaf_ew_grid(chw, 8);
-    if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(ln_partial_kernel, dim3(gx, N), dim3(256), 0, s, x, (long)chw, workspace);
+    const bool v4 = (chw % 4 == 0) && al16(x);
+    int gx = jaf_ew_grid(v4 ? chw / 4 : chw, 4);
+    const int cap = 2048 / N < 8 ? 8 : 2048 / N;
+    if (gx > cap) gx = cap;
+    if (v4) hipLaunchKernelGGL(ln_partial_kernel<4>, dim3(gx, N), dim3(256), 0, s, x, (long)chw, workspace);
+    else hipLaunchKernelGGL(ln_partial_kernel<1>, dim3(gx, N), dim3(256), 0, s, x, (long)chw, workspace);
     hipLaunchKernelGGL(ln_finalize_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N, (long)chw, eps, stats);
     return jaf_launch_status();
 }
 
+// grid (pixel blocks, C, N)
+template <int V>
 __global__ void ln_lrelu_fwd_kernel(const float* x, const float* stats, const float* gamma, const float* beta,
-                                    float* y, int N, int C, int HW, float slope) {
-    const long total = (long)N * C * HW;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const long nc = e / HW;
-        const int c = (int)(nc % C);
-        const int n = (int)(nc / C);
-        const float xh = (x[e] - stats[2 * n]) * stats[2 * n + 1];
-        const float z = xh * gamma[c] + beta[c];
+                                    float* y, int C, int HW, float slope) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const long e = ((long)n * C + c) * HW + pix;
+    const float mean = stats[2 * n], r = stats[2 * n + 1], g = gamma[c], b = beta[c];
+    if (V == 4) {
+        const f32x4 xv = *(const f32x4*)(x + e);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z = (xv[k] - mean) * r * g + b;
+            o[k] = z > 0.f ? z : z * slope;
+        }
+        *(f32x4*)(y + e) = o;
+    } else {
+        const float z = (x[e] - mean) * r * g + b;
         y[e] = z > 0.f ? z : z * slope;
     }
 }
 
 extern "C" int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                                        const float* beta, float* y, int32_t N, int32_t C, int32_t HW, float slope) {
-    JAF_REQUIRE(x && stats && gamma && beta && y && N >= 1 && C >= 1 && HW >= 1);
-    hipLaunchKernelGGL(ln_lrelu_fwd_kernel, dim3(jaf_ew_grid((long)N * C * HW)), dim3(256), 0, (hipStream_t)s,
-                       x, stats, gamma, beta, y, N, C, HW, slope);
+    JAF_REQUIRE(x && stats && gamma && beta && y && N >= 1 && C >= 1 && HW >= 1 && C <= 65535 && N <= 65535);
+    if ((HW % 4 == 0) && al16(x, y))
+        hipLaunchKernelGGL(ln_lrelu_fwd_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, (hipStream_t)s, x, stats,
+                           gamma, beta, y, C, HW, slope);
+    else
+        hipLaunchKernelGGL(ln_lrelu_fwd_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, (hipStream_t)s, x, stats,
+                           gamma, beta, y, C, HW, slope);
     return jaf_launch_status();
 }
 
 // pass A: per (c, n) block: a = sum dz, b = sum dz*xhat ; dbeta[c] += a, dgamma[c] += b,
 // ws[2n] += gamma_c*a (S1), ws[2n+1] += gamma_c*b (S2).
+template <int V>
 __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const float* stats, const float* gamma,
                                      const float* beta, float* dgamma, float* dbeta, double* ws, int C, int HW,
                                      float slope) {
@@ -85,12 +129,31 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
     const float mean = stats[2 * n], r = stats[2 * n + 1];
     const float g = gamma[c], b = beta[c];
     double sa = 0.0, sb = 0.0;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-        const float xh = (x[base + i] - mean) * r;
-        const float z = xh * g + b;
-        const float dz = dy[base + i] * (z > 0.f ? 1.f : slope);
-        sa += (double)dz;
-        sb += (double)dz * (double)xh;
+    if (V == 4) {
+        const f32x4* x4 = (const f32x4*)(x + base);
+        const f32x4* d4 = (const f32x4*)(dy + base);
+        for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
+            const f32x4 xv = x4[i], dv = d4[i];
+            float pa = 0.f, pb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[k] - mean) * r;
+                const float z = xh * g + b;
+                const float dz = dv[k] * (z > 0.f ? 1.f : slope);
+                pa += dz;
+                pb += dz * xh;
+            }
+            sa += (double)pa;
+            sb += (double)pb;
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const float xh = (x[base + i] - mean) * r;
+            const float z = xh * g + b;
+            const float dz = dy[base + i] * (z > 0.f ? 1.f : slope);
+            sa += (double)dz;
+            sb += (double)dz * (double)xh;
+        }
     }
     __shared__ double ra[4], rb[4];
     sa = jaf_wave_sum(sa);
@@ -107,25 +170,38 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
     }
 }
 
+// grid (pixel blocks, C, N)
+template <int V>
 __global__ void ln_bwd_apply_kernel(const float* dy, const float* x, const float* stats, const float* gamma,
-                                    const float* beta, const double* ws, float* dx, int N, int C, int HW,
-                                    float slope, float eps) {
-    const long total = (long)N * C * HW;
-    const long stride = (long)gridDim.x * blockDim.x;
+                                    const float* beta, const double* ws, float* dx, int C, int HW, float slope,
+                                    float eps) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const long e = ((long)n * C + c) * HW + pix;
     const double M = (double)C * (double)HW;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const long nc = e / HW;
-        const int c = (int)(nc % C);
-        const int n = (int)(nc / C);
-        const float mean = stats[2 * n], r = stats[2 * n + 1];
-        const float sigma = 1.0f / r - eps;
-        const float m1 = (float)(ws[2 * n] / M);
-        // S2 / ((M-1) * sigma * r)
-        const float k = (sigma > 0.f) ? (float)(ws[2 * n + 1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
+    const float mean = stats[2 * n], r = stats[2 * n + 1];
+    const float sigma = 1.0f / r - eps;
+    const float m1 = (float)(ws[2 * n] / M);
+    // S2 / ((M-1) * sigma * r)
+    const float kk = (sigma > 0.f) ? (float)(ws[2 * n + 1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
+    const float g = gamma[c], b = beta[c];
+    if (V == 4) {
+        const f32x4 xv = *(const f32x4*)(x + e), dv = *(const f32x4*)(dy + e);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (xv[k] - mean) * r;
+            const float z = xh * g + b;
+            const float dxh = dv[k] * (z > 0.f ? 1.f : slope) * g;
+            o[k] = r * (dxh - m1 - xh * kk);
+        }
+        *(f32x4*)(dx + e) = o;
+    } else {
         const float xh = (x[e] - mean) * r;
-        const float z = xh * gamma[c] + beta[c];
-        const float dxh = dy[e] * (z > 0.f ? 1.f : slope) * gamma[c];
-        dx[e] = r * (dxh - m1 - xh * k);
+        const float z = xh * g + b;
+        const float dxh = dy[e] * (z > 0.f ? 1.f : slope) * g;
+        dx[e] = r * (dxh - m1 - xh * kk);
     }
 }
 
@@ -134,77 +210,127 @@ extern "C" int jaf_layernorm_lrelu_bwd(jaf_stream_t s_, const float* dy, const f
                                        float* dbeta, double* workspace, int32_t N, int32_t C, int32_t HW,
                                        float slope, float eps) {
     JAF_REQUIRE(dy && x && stats && gamma && beta && dx && dgamma && dbeta && workspace);
-    JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535);
+    JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535 && C <= 65535);
     hipStream_t s = (hipStream_t)s_;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * N, s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                       workspace, C, HW, slope);
-    hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(jaf_ew_grid((long)N * C * HW)), dim3(256), 0, s, dy, x, stats, gamma,
-                       beta, workspace, dx, N, C, HW, slope, eps);
+    if ((HW % 4 == 0) && al16(dy, x, dx)) {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel<4>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
+                           workspace, C, HW, slope);
+        hipLaunchKernelGGL(ln_bwd_apply_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
+                           beta, workspace, dx, C, HW, slope, eps);
+    } else {
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel<1>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
+                           workspace, C, HW, slope);
+        hipLaunchKernelGGL(ln_bwd_apply_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
+                           beta, workspace, dx, C, HW, slope, eps);
+    }
     return jaf_launch_status();
 }
 
 // ------------------------------------------------------------------ BatchNorm2d
-__global__ void bn_stats_kernel(const float* x, int N, int C, int HW, float eps, float momentum,
-                                float* running_mean, float* running_var, float* stats, int training) {
+// Per-channel reductions: grid (C, nsplit); a workgroup walks items = (image, 4096-element chunk of
+// the plane) in strides of nsplit and adds its partial sums to ws[2c], ws[2c+1] (fp64 atomics).
+#define BN_CHUNK 4096
+
+static int bn_nsplit(int C, int N, int HW) {
+    const long items = (long)N * jaf_cdiv(HW, BN_CHUNK);
+    long ns = (1024 + C - 1) / C;
+    if (ns > items) ns = items;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+template <int V>
+__global__ void bn_stats_partial_kernel(const float* x, int N, int C, int HW, double* ws) {
     const int c = blockIdx.x;
-    if (!training) {
-        if (threadIdx.x == 0) {
-            stats[c] = running_mean[c];
-            stats[C + c] = 1.0f / sqrtf(running_var[c] + eps);
+    const int chunks = (HW + BN_CHUNK - 1) / BN_CHUNK;
+    const int items = N * chunks;
+    double s = 0.0, ss = 0.0;
+    for (int item = blockIdx.y; item < items; item += gridDim.y) {
+        const int n = item / chunks;
+        const int ch = item - n * chunks;
+        const float* p = x + ((long)n * C + c) * HW;
+        const int lo = ch * BN_CHUNK;
+        const int hi = lo + BN_CHUNK < HW ? lo + BN_CHUNK : HW;
+        if (V == 4) {
+            for (int i = lo + threadIdx.x * 4; i < hi; i += blockDim.x * 4) {
+                const f32x4 v = *(const f32x4*)(p + i);
+                s += (double)((v[0] + v[1]) + (v[2] + v[3]));
+                ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            }
+        } else {
+            for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const double v = (double)p[i];
+                s += v;
+                ss += v * v;
+            }
         }
+    }
+    block_sum2_atomic(s, ss, &ws[2 * c], &ws[2 * c + 1]);
+}
+
+__global__ void bn_stats_finalize_kernel(const double* ws, int N, int C, int HW, float eps, float momentum,
+                                         float* running_mean, float* running_var, float* stats, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (!training) {
+        stats[c] = running_mean[c];
+        stats[C + c] = 1.0f / sqrtf(running_var[c] + eps);
         return;
     }
-    double s = 0.0, ss = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((long)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const double v = (double)p[i];
-            s += v;
-            ss += v * v;
-        }
-    }
-    __shared__ double rs[4], rss[4];
-    s = jaf_wave_sum(s);
-    ss = jaf_wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rss[threadIdx.x >> 6] = ss; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double cnt = (double)N * (double)HW;
-        const double S = rs[0] + rs[1] + rs[2] + rs[3];
-        const double SS = rss[0] + rss[1] + rss[2] + rss[3];
-        const double mean = S / cnt;
-        double var = SS / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[c] = (float)mean;
-        stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
+    const double cnt = (double)N * (double)HW;
+    const double mean = ws[2 * c] / cnt;
+    double var = ws[2 * c + 1] / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[c] = (float)mean;
+    stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
 
-extern "C" int jaf_batchnorm_stats(jaf_stream_t s, const float* x, int32_t N, int32_t C, int32_t HW, float eps,
+extern "C" int jaf_batchnorm_stats(jaf_stream_t s_, const float* x, int32_t N, int32_t C, int32_t HW, float eps,
                                    float momentum, float* running_mean, float* running_var, float* stats,
-                                   int training) {
-    JAF_REQUIRE(x && stats && N >= 1 && C >= 1 && HW >= 1);
+                                   int training, double* workspace) {
+    JAF_REQUIRE(x && stats && workspace && N >= 1 && C >= 1 && HW >= 1);
     JAF_REQUIRE(training || (running_mean && running_var));
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)s, x, N, C, HW, eps, momentum, running_mean,
-                       running_var, stats, training);
+    hipStream_t s = (hipStream_t)s_;
+    if (training) {
+        hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, s);
+        if (e != hipSuccess) return (int)e;
+        const int ns = bn_nsplit(C, N, HW);
+        if ((HW % 4 == 0) && al16(x))
+            hipLaunchKernelGGL(bn_stats_partial_kernel<4>, dim3(C, ns), dim3(256), 0, s, x, N, C, HW, workspace);
+        else
+            hipLaunchKernelGGL(bn_stats_partial_kernel<1>, dim3(C, ns), dim3(256), 0, s, x, N, C, HW, workspace);
+    }
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, workspace, N, C, HW, eps, momentum,
+                       running_mean, running_var, stats, training);
     return jaf_launch_status();
 }
 
+// grid (pixel blocks, C, N)
+template <int V>
 __global__ void bn_act_fwd_kernel(const float* x, const float* stats, const float* w, const float* b,
-                                  const float* residual, float* y, int N, int C, int HW, int act, float slope) {
-    const long total = (long)N * C * HW;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int c = (int)((e / HW) % C);
-        float v = (x[e] - stats[c]) * stats[C + c] * w[c] + b[c];
-        v = jaf_act(v, act, slope);
+                                  const float* residual, float* y, int C, int HW, int act, float slope) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const long e = ((long)n * C + c) * HW + pix;
+    const float mean = stats[c], sc = stats[C + c] * w[c], bb = b[c];
+    if (V == 4) {
+        const f32x4 xv = *(const f32x4*)(x + e);
+        f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+        if (residual) rv = *(const f32x4*)(residual + e);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[k] - mean) * sc + bb, act, slope) + rv[k];
+        *(f32x4*)(y + e) = o;
+    } else {
+        float v = jaf_act((x[e] - mean) * sc + bb, act, slope);
         if (residual) v += residual[e];
         y[e] = v;
     }
@@ -213,10 +339,14 @@ __global__ void bn_act_fwd_kernel(const float* x, const float* stats, const floa
 extern "C" int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float* stats, const float* weight,
                                      const float* bias, const float* residual, float* y, int32_t N, int32_t C,
                                      int32_t HW, int act, float slope) {
-    JAF_REQUIRE(x && stats && weight && bias && y && N >= 1 && C >= 1 && HW >= 1);
+    JAF_REQUIRE(x && stats && weight && bias && y && N >= 1 && C >= 1 && HW >= 1 && C <= 65535 && N <= 65535);
     JAF_REQUIRE(!residual || act == JAF_ACT_NONE);
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(jaf_ew_grid((long)N * C * HW)), dim3(256), 0, (hipStream_t)s, x, stats,
-                       weight, bias, residual, y, N, C, HW, act, slope);
+    if ((HW % 4 == 0) && al16(x, y, residual))
+        hipLaunchKernelGGL(bn_act_fwd_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, (hipStream_t)s, x, stats,
+                           weight, bias, residual, y, C, HW, act, slope);
+    else
+        hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, (hipStream_t)s, x, stats,
+                           weight, bias, residual, y, C, HW, act, slope);
     return jaf_launch_status();
 }
 
@@ -229,57 +359,99 @@ __device__ __forceinline__ float bn_dz(float dy, float y, int act, float slope) 
     }
 }
 
-__global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const float* y, const float* stats,
-                                     float* dweight, float* dbias, int N, int C, int HW, int act, float slope) {
+template <int V>
+__global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const float* y, const float* stats, double* ws,
+                                     int N, int C, int HW, int act, float slope) {
     const int c = blockIdx.x;
     const float mean = stats[c], r = stats[C + c];
+    const int chunks = (HW + BN_CHUNK - 1) / BN_CHUNK;
+    const int items = N * chunks;
     double sa = 0.0, sb = 0.0;
-    for (int n = 0; n < N; ++n) {
+    for (int item = blockIdx.y; item < items; item += gridDim.y) {
+        const int n = item / chunks;
+        const int ch = item - n * chunks;
         const long base = ((long)n * C + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float dz = bn_dz(dy[base + i], y[base + i], act, slope);
-            sa += (double)dz;
-            sb += (double)dz * (double)((x[base + i] - mean) * r);
+        const int lo = ch * BN_CHUNK;
+        const int hi = lo + BN_CHUNK < HW ? lo + BN_CHUNK : HW;
+        if (V == 4) {
+            for (int i = lo + threadIdx.x * 4; i < hi; i += blockDim.x * 4) {
+                const f32x4 dv = *(const f32x4*)(dy + base + i), xv = *(const f32x4*)(x + base + i);
+                const f32x4 yv = *(const f32x4*)(y + base + i);
+                float pa = 0.f, pb = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = bn_dz(dv[k], yv[k], act, slope);
+                    pa += dz;
+                    pb += dz * ((xv[k] - mean) * r);
+                }
+                sa += (double)pa;
+                sb += (double)pb;
+            }
+        } else {
+            for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+                const float dz = bn_dz(dy[base + i], y[base + i], act, slope);
+                sa += (double)dz;
+                sb += (double)dz * (double)((x[base + i] - mean) * r);
+            }
         }
     }
-    __shared__ double ra[4], rb[4];
-    sa = jaf_wave_sum(sa);
-    sb = jaf_wave_sum(sb);
-    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rb[threadIdx.x >> 6] = sb; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        dbias[c] = (float)(ra[0] + ra[1] + ra[2] + ra[3]);
-        dweight[c] = (float)(rb[0] + rb[1] + rb[2] + rb[3]);
-    }
+    block_sum2_atomic(sa, sb, &ws[2 * c], &ws[2 * c + 1]);
 }
 
+__global__ void bn_bwd_finalize_kernel(const double* ws, float* dweight, float* dbias, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbias[c] = (float)ws[2 * c];
+    dweight[c] = (float)ws[2 * c + 1];
+}
+
+// grid (pixel blocks, C, N)
+template <int V>
 __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float* y, const float* stats,
-                                    const float* w, const float* dweight, const float* dbias, float* dx, int N,
-                                    int C, int HW, int act, float slope, int training) {
-    const long total = (long)N * C * HW;
-    const long stride = (long)gridDim.x * blockDim.x;
+                                    const float* w, const double* ws, float* dx, int N, int C, int HW, int act,
+                                    float slope, int training) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const long e = ((long)n * C + c) * HW + pix;
     const float inv_cnt = 1.0f / ((float)N * (float)HW);
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        const int c = (int)((e / HW) % C);
-        const float r = stats[C + c];
-        const float dz = bn_dz(dy[e], y[e], act, slope);
-        if (training) {
-            const float xh = (x[e] - stats[c]) * r;
-            dx[e] = w[c] * r * (dz - dbias[c] * inv_cnt - xh * dweight[c] * inv_cnt);
-        } else {
-            dx[e] = w[c] * r * dz;
+    const float mean = stats[c], r = stats[C + c], wr = w[c] * r;
+    const float db = training ? (float)ws[2 * c] * inv_cnt : 0.f;
+    const float dw = training ? (float)ws[2 * c + 1] * inv_cnt : 0.f;
+    if (V == 4) {
+        const f32x4 dv = *(const f32x4*)(dy + e), xv = *(const f32x4*)(x + e), yv = *(const f32x4*)(y + e);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dz = bn_dz(dv[k], yv[k], act, slope);
+            o[k] = wr * (dz - db - (xv[k] - mean) * r * dw);
         }
+        *(f32x4*)(dx + e) = o;
+    } else {
+        const float dz = bn_dz(dy[e], y[e], act, slope);
+        dx[e] = wr * (dz - db - (x[e] - mean) * r * dw);
     }
 }
 
 extern "C" int jaf_batchnorm_act_bwd(jaf_stream_t s_, const float* dy, const float* x, const float* y,
                                      const float* stats, const float* weight, float* dx, float* dweight,
                                      float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
-                                     int training) {
-    JAF_REQUIRE(dy && x && y && stats && weight && dx && dweight && dbias && N >= 1 && C >= 1 && HW >= 1);
+                                     int training, double* workspace) {
+    JAF_REQUIRE(dy && x && y && stats && weight && dx && dweight && dbias && workspace && N >= 1 && C >= 1 && HW >= 1);
+    JAF_REQUIRE(C <= 65535 && N <= 65535);
     hipStream_t s = (hipStream_t)s_;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C), dim3(256), 0, s, dy, x, y, stats, dweight, dbias, N, C, HW, act, slope);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(jaf_ew_grid((long)N * C * HW)), dim3(256), 0, s, dy, x, y, stats, weight,
-                       dweight, dbias, dx, N, C, HW, act, slope, training);
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, s);
+    if (e != hipSuccess) return (int)e;
+    const bool v4 = (HW % 4 == 0) && al16(dy, x, y, dx);
+    const int ns = bn_nsplit(C, N, HW);
+    if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, ns), dim3(256), 0, s, dy, x, y, stats, workspace, N, C, HW, act, slope);
+    else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, ns), dim3(256), 0, s, dy, x, y, stats, workspace, N, C, HW, act, slope);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, workspace, dweight, dbias, C);
+    if (v4)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, s, dy, x, y, stats, weight,
+                           workspace, dx, N, C, HW, act, slope, training);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, s, dy, x, y, stats, weight,
+                           workspace, dx, N, C, HW, act, slope, training);
     return jaf_launch_status();
 }

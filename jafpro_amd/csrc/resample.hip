@@ -3,69 +3,68 @@
 
 // ------------------------------------------------------------------ average pooling
 // count_include_pad=True semantics (F.avg_pool2d default, src/crn_model.py:268-273): divisor k*k.
-__global__ void avgpool_fwd_kernel(const float* x, float* y, int NC, int H, int W, int OH, int OW, int k,
-                                   int stride, int pad) {
-    const long total = (long)NC * OH * OW;
-    const long gs = (long)gridDim.x * blockDim.x;
+// grid (x blocks, output rows, planes): no lane divides.
+__global__ void avgpool_fwd_kernel(const float* x, float* y, int H, int W, int OH, int OW, int k, int stride, int pad) {
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= OW) return;
+    const int oy = blockIdx.y;
+    const long nc = blockIdx.z;
     const float inv = 1.0f / (float)(k * k);
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int ox = (int)(e % OW);
-        const int oy = (int)((e / OW) % OH);
-        const long nc = e / ((long)OW * OH);
-        const float* p = x + nc * H * W;
-        float acc = 0.f;
-        for (int ky = 0; ky < k; ++ky) {
-            const int iy = oy * stride - pad + ky;
-            if (iy < 0 || iy >= H) continue;
-            for (int kx = 0; kx < k; ++kx) {
-                const int ix = ox * stride - pad + kx;
-                if (ix < 0 || ix >= W) continue;
-                acc += p[iy * W + ix];
-            }
+    const float* p = x + nc * H * W;
+    float acc = 0.f;
+    for (int ky = 0; ky < k; ++ky) {
+        const int iy = oy * stride - pad + ky;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+            const int ix = ox * stride - pad + kx;
+            if (ix < 0 || ix >= W) continue;
+            acc += p[iy * W + ix];
         }
-        y[e] = acc * inv;
     }
+    y[(nc * OH + oy) * OW + ox] = acc * inv;
 }
+
+static inline int row_threads(int w) { return w >= 192 ? 256 : (w >= 96 ? 128 : 64); }
 
 extern "C" int jaf_avgpool_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W,
                                int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad) {
     JAF_REQUIRE(x && y && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
     JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(jaf_ew_grid((long)NC * OH * OW)), dim3(256), 0, (hipStream_t)s, x, y, NC, H, W, OH, OW, k, stride, pad);
+    JAF_REQUIRE(OH <= 65535 && NC <= 65535);
+    const int t = row_threads(OW);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(jaf_cdiv(OW, t), OH, NC), dim3(t), 0, (hipStream_t)s, x, y, H, W, OH, OW, k, stride, pad);
     return jaf_launch_status();
 }
 
-__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int NC, int H, int W, int OH, int OW, int k,
-                                   int stride, int pad) {
-    const long total = (long)NC * H * W;
-    const long gs = (long)gridDim.x * blockDim.x;
+__global__ void avgpool_bwd_kernel(const float* dy, float* dx, int H, int W, int OH, int OW, int k, int stride, int pad) {
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ix >= W) return;
+    const int iy = blockIdx.y;
+    const long nc = blockIdx.z;
     const float inv = 1.0f / (float)(k * k);
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int ix = (int)(e % W);
-        const int iy = (int)((e / W) % H);
-        const long nc = e / ((long)W * H);
-        const float* p = dy + nc * OH * OW;
-        // outputs oy with oy*stride - pad <= iy <= oy*stride - pad + k - 1
-        int oy_lo = (iy + pad - k + 1 + stride - 1);
-        oy_lo = oy_lo <= 0 ? 0 : oy_lo / stride;
-        int oy_hi = (iy + pad) / stride;
-        if (oy_hi > OH - 1) oy_hi = OH - 1;
-        int ox_lo = (ix + pad - k + 1 + stride - 1);
-        ox_lo = ox_lo <= 0 ? 0 : ox_lo / stride;
-        int ox_hi = (ix + pad) / stride;
-        if (ox_hi > OW - 1) ox_hi = OW - 1;
-        float acc = 0.f;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy)
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += p[oy * OW + ox];
-        dx[e] = acc * inv;
-    }
+    const float* p = dy + nc * OH * OW;
+    // outputs oy with oy*stride - pad <= iy <= oy*stride - pad + k - 1
+    int oy_lo = (iy + pad - k + 1 + stride - 1);
+    oy_lo = oy_lo <= 0 ? 0 : oy_lo / stride;
+    int oy_hi = (iy + pad) / stride;
+    if (oy_hi > OH - 1) oy_hi = OH - 1;
+    int ox_lo = (ix + pad - k + 1 + stride - 1);
+    ox_lo = ox_lo <= 0 ? 0 : ox_lo / stride;
+    int ox_hi = (ix + pad) / stride;
+    if (ox_hi > OW - 1) ox_hi = OW - 1;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += p[oy * OW + ox];
+    dx[(nc * H + iy) * W + ix] = acc * inv;
 }
 
 extern "C" int jaf_avgpool_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
                                int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad) {
     JAF_REQUIRE(dy && dx && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
     JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(jaf_ew_grid((long)NC * H * W)), dim3(256), 0, (hipStream_t)s, dy, dx, NC, H, W, OH, OW, k, stride, pad);
+    JAF_REQUIRE(H <= 65535 && NC <= 65535);
+    const int t = row_threads(W);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(jaf_cdiv(W, t), H, NC), dim3(t), 0, (hipStream_t)s, dy, dx, H, W, OH, OW, k, stride, pad);
     return jaf_launch_status();
 }
 
@@ -87,27 +86,26 @@ __device__ __forceinline__ void resize_src(int o, float scale, int in, int align
     l = src - (float)i0;
 }
 
+// grid (x blocks, output rows, planes)
 __global__ void resize_fwd_kernel(const float* x, float* y, ResizeArgs a) {
-    const long total = (long)a.N * a.C * a.OH * a.OW;
-    const long gs = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int ox = (int)(e % a.OW);
-        const int oy = (int)((e / a.OW) % a.OH);
-        const long nc = e / ((long)a.OW * a.OH);
-        const float* p = x + nc * a.H * a.W;
-        if (a.nearest) {
-            int iy = (int)floorf((float)oy * a.sy); if (iy > a.ch - 1) iy = a.ch - 1;
-            int ix = (int)floorf((float)ox * a.sx); if (ix > a.cw - 1) ix = a.cw - 1;
-            y[e] = p[(a.y0 + iy) * a.W + a.x0 + ix];
-        } else {
-            int y0, y1, x0, x1; float ly, lx;
-            resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
-            resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const float* r0 = p + (a.y0 + y0) * a.W + a.x0;
-            const float* r1 = p + (a.y0 + y1) * a.W + a.x0;
-            y[e] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
-        }
+    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ox >= a.OW) return;
+    const int oy = blockIdx.y;
+    const long nc = blockIdx.z;
+    const float* p = x + nc * a.H * a.W;
+    float* q = y + (nc * a.OH + oy) * a.OW + ox;
+    if (a.nearest) {
+        int iy = (int)floorf((float)oy * a.sy); if (iy > a.ch - 1) iy = a.ch - 1;
+        int ix = (int)floorf((float)ox * a.sx); if (ix > a.cw - 1) ix = a.cw - 1;
+        *q = p[(a.y0 + iy) * a.W + a.x0 + ix];
+    } else {
+        int y0, y1, x0, x1; float ly, lx;
+        resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
+        resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* r0 = p + (a.y0 + y0) * a.W + a.x0;
+        const float* r1 = p + (a.y0 + y1) * a.W + a.x0;
+        *q = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
     }
 }
 
@@ -131,7 +129,9 @@ extern "C" int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t 
     JAF_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W);
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, nearest};
     resize_scales(a);
-    hipLaunchKernelGGL(resize_fwd_kernel, dim3(jaf_ew_grid((long)N * C * OH * OW)), dim3(256), 0, (hipStream_t)s, x, y, a);
+    JAF_REQUIRE(OH <= 65535 && (long)N * C <= 65535);
+    const int t = row_threads(OW);
+    hipLaunchKernelGGL(resize_fwd_kernel, dim3(jaf_cdiv(OW, t), OH, N * C), dim3(t), 0, (hipStream_t)s, x, y, a);
     return jaf_launch_status();
 }
 
@@ -150,19 +150,47 @@ __device__ __forceinline__ void resize_cand(int i, float scale, int out, int ali
     if (hi > out - 1) hi = out - 1;
 }
 
+// grid (x blocks, input rows, planes).  The x candidates and their weights depend only on the
+// lane's column: they are resolved once (at most RB_MAXC non-zero taps) and reused for every row.
+#define RB_MAXC 8
 __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
-    const long total = (long)a.N * a.C * a.H * a.W;
-    const long gs = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int ix = (int)(e % a.W) - a.x0;
-        const int iy = (int)((e / a.W) % a.H) - a.y0;
-        const long nc = e / ((long)a.W * a.H);
-        float acc = 0.f;
-        if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
-            int ylo, yhi, xlo, xhi;
-            resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
-            resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
-            const float* p = dy + nc * a.OH * a.OW;
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gx >= a.W) return;
+    const int gy = blockIdx.y;
+    const long nc = blockIdx.z;
+    const int ix = gx - a.x0, iy = gy - a.y0;
+    float acc = 0.f;
+    if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
+        int ylo, yhi, xlo, xhi;
+        resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
+        resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
+        const float* p = dy + nc * a.OH * a.OW;
+        if (xhi - xlo + 1 <= RB_MAXC) {
+            float wx[RB_MAXC];
+#pragma unroll
+            for (int j = 0; j < RB_MAXC; ++j) {
+                const int ox = xlo + j;
+                float w = 0.f;
+                if (ox <= xhi) {
+                    int x0, x1; float lx;
+                    resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
+                    w = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                }
+                wx[j] = w;
+            }
+            for (int oy = ylo; oy <= yhi; ++oy) {
+                int y0, y1; float ly;
+                resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
+                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;
+                const float* r = p + oy * a.OW + xlo;
+                float row = 0.f;
+#pragma unroll
+                for (int j = 0; j < RB_MAXC; ++j)
+                    if (wx[j] != 0.f) row += wx[j] * r[j];
+                acc += wy * row;
+            }
+        } else {
             for (int oy = ylo; oy <= yhi; ++oy) {
                 int y0, y1; float ly;
                 resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
@@ -178,8 +206,8 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
                 acc += wy * row;
             }
         }
-        dx[e] = acc;
     }
+    dx[(nc * a.H + gy) * a.W + gx] = acc;
 }
 
 extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -189,7 +217,9 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     JAF_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W);
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, 0};
     resize_scales(a);
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_ew_grid((long)N * C * H * W)), dim3(256), 0, (hipStream_t)s, dy, dx, a);
+    JAF_REQUIRE(H <= 65535 && (long)N * C <= 65535);
+    const int t = row_threads(W);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_cdiv(W, t), H, N * C), dim3(t), 0, (hipStream_t)s, dy, dx, a);
     return jaf_launch_status();
 }
 

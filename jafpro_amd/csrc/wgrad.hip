@@ -281,21 +281,32 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-channel sum over (n, h, w): bias gradients
+// per-channel sum over (n, h, w): bias gradients.  grid (C, nsplit): a workgroup walks items =
+// (image, 4096-element chunk of the plane) in strides of nsplit, 16 bytes per lane.
 // ---------------------------------------------------------------------------------------------
-__global__ void channel_sum_kernel(const float* x, int N, int ctot, int coff, int C, int HW, float* out, int nsplit) {
+#define CS_CHUNK 4096
+template <int V>
+__global__ void channel_sum_kernel(const float* x, int N, int ctot, int coff, int HW, float* out) {
     const int c = blockIdx.x;
-    const int split = blockIdx.y;
+    const int chunks = (HW + CS_CHUNK - 1) / CS_CHUNK;
+    const int items = N * chunks;
     double acc = 0.0;
-    const long total = (long)N * HW;
-    const long per = (total + nsplit - 1) / nsplit;
-    const long lo = split * per;
-    long hi = lo + per;
-    if (hi > total) hi = total;
-    for (long e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        const long n = e / HW;
-        const long i = e - n * HW;
-        acc += (double)x[(n * ctot + coff + c) * HW + i];
+    for (int item = blockIdx.y; item < items; item += gridDim.y) {
+        const int n = item / chunks;
+        const int ch = item - n * chunks;
+        const float* p = x + ((long)n * ctot + coff + c) * HW;
+        const int lo = ch * CS_CHUNK;
+        const int hi = lo + CS_CHUNK < HW ? lo + CS_CHUNK : HW;
+        if (V == 4) {
+            float part = 0.f;
+            for (int i = lo + threadIdx.x * 4; i < hi; i += blockDim.x * 4) {
+                const f32x4 v = *(const f32x4*)(p + i);
+                part += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            acc += (double)part;      // at most 16 fp32 adds per lane before widening
+        } else {
+            for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) acc += (double)p[i];
+        }
     }
     __shared__ double red[4];
     acc = jaf_wave_sum(acc);
@@ -312,11 +323,14 @@ extern "C" int jaf_channel_sum(jaf_stream_t s_, const float* x, int32_t N, int32
         hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)C, s);
         if (e != hipSuccess) return (int)e;
     }
-    const long total = (long)N * HW;
+    const long items = (long)N * jaf_cdiv(HW, CS_CHUNK);
     long nsplit = (2048 + C - 1) / C;
-    const long max_split = (total + 4095) / 4096;       // at least 4096 elements per block
-    if (nsplit > max_split) nsplit = max_split;
+    if (nsplit > items) nsplit = items;
     if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, (unsigned)nsplit), dim3(256), 0, s, x, N, ctot, coff, C, HW, out, (int)nsplit);
+    if (nsplit > 65535) nsplit = 65535;
+    if ((HW % 4 == 0) && (((uintptr_t)x) & 15) == 0)
+        hipLaunchKernelGGL(channel_sum_kernel<4>, dim3(C, (unsigned)nsplit), dim3(256), 0, s, x, N, ctot, coff, HW, out);
+    else
+        hipLaunchKernelGGL(channel_sum_kernel<1>, dim3(C, (unsigned)nsplit), dim3(256), 0, s, x, N, ctot, coff, HW, out);
     return jaf_launch_status();
 }

@@ -185,6 +185,11 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
     return out
 
 
+def _grad_inplace(p: torch.Tensor) -> bool:
+    g = p.grad
+    return g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape
+
+
 class _ConvMeta:
     __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
                  "KH", "KW", "cin_tot")
@@ -198,6 +203,7 @@ class _ConvFn(Function):
                       m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope)
         ctx.meta = m
         ctx.has_bias = bias is not None
+        ctx.bias_ref = bias
         ctx.save_for_backward(weight, y if m.act != ACT_NONE else None, *srcs)
         return y
 
@@ -230,19 +236,29 @@ class _ConvFn(Function):
                 dsrcs.append(None)
             coff += c
         dw = db = None
+        bias = ctx.bias_ref
         if ctx.needs_input_grad[0]:
-            dw = torch.empty_like(weight)
+            # a parameter whose .grad buffer already exists (step.FlatParams) is accumulated in place
+            # by the kernel: no temporary, no memset, no separate AccumulateGrad add launch
+            inplace = _grad_inplace(weight)
+            dw = weight.grad if inplace else torch.empty_like(weight)
             d = _make_desc(m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW, m.KH, m.KW, m.stride, m.pad, m.pad, 1,
                            m.specs, m.cin_tot, 0, m.G * m.Cout, 0, ACT_NONE, 0.0)
             ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
             ev = _PROF.begin() if _PROF is not None else None
-            check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 0), "jaf_conv2d_wgrad")
+            check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
+                  "jaf_conv2d_wgrad")
             if ev is not None:
                 _PROF.end("conv_wgrad_kernel", 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
+            if inplace:
+                dw = None
         if ctx.has_bias and ctx.needs_input_grad[1]:
-            db = torch.empty(m.G * m.Cout, device=dy.device, dtype=torch.float32)
-            check(L.jaf_channel_sum(_s(), _p(dz), m.N, m.G * m.Cout, 0, m.G * m.Cout, m.OH * m.OW, _p(db), 0),
-                  "jaf_channel_sum")
+            inplace = bias is not None and _grad_inplace(bias)
+            db = bias.grad if inplace else torch.empty(m.G * m.Cout, device=dy.device, dtype=torch.float32)
+            check(L.jaf_channel_sum(_s(), _p(dz), m.N, m.G * m.Cout, 0, m.G * m.Cout, m.OH * m.OW, _p(db),
+                                    1 if inplace else 0), "jaf_channel_sum")
+            if inplace:
+                db = None
         return (dw, db, None) + tuple(dsrcs)
 
 
@@ -338,6 +354,7 @@ class _ConvLSTMFn(Function):
                 _PROF.end(_kname(True, 3, 3, pl), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
         ctx.G = G
         ctx.need_all = need_all
+        ctx.bias_ref = bias
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates)
         c_last = cs[T - 1].clone()
@@ -355,8 +372,10 @@ class _ConvLSTMFn(Function):
         L = lib()
         dh_out = _c(dh_out)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        dw = torch.empty_like(weight)
-        db = torch.empty(4 * GC, device=x.device, dtype=torch.float32)
+        bias = ctx.bias_ref
+        w_inplace, b_inplace = _grad_inplace(weight), _grad_inplace(bias)
+        dw = weight.grad if w_inplace else torch.empty_like(weight)
+        db = bias.grad if b_inplace else torch.empty(4 * GC, device=x.device, dtype=torch.float32)
         dc = None
         dh = None
         for t in range(T - 1, -1, -1):
@@ -378,10 +397,11 @@ class _ConvLSTMFn(Function):
             acc = 0 if t == T - 1 else 1
             ev = _PROF.begin() if _PROF is not None else None
             check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None, _p(gt),
-                                     _p(dw), acc), "jaf_conv2d_wgrad")
+                                     _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
             if ev is not None:
                 _PROF.end("conv_wgrad_kernel", 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
-            check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), acc), "jaf_channel_sum")
+            check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
+                  "jaf_channel_sum")
             gspec = [(4 * C, 4 * GC, 0, 4 * C)]
             if dx is not None:
                 _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1, 1,
@@ -390,7 +410,7 @@ class _ConvLSTMFn(Function):
                 dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                1, 2 * C, C, ACT_NONE, 0.0)
             dc = dc_prev
-        return dx, dw, db, None, None
+        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None
 
 
 def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int = 1, return_all: bool = False):
@@ -445,8 +465,9 @@ class _BatchNormActFn(Function):
         N, C, H, W = x.shape
         L = lib()
         stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
         check(L.jaf_batchnorm_stats(_s(), _p(x), N, C, H * W, eps, momentum, _p(running_mean), _p(running_var),
-                                    _p(stats), 1 if training else 0), "jaf_batchnorm_stats")
+                                    _p(stats), 1 if training else 0, _p(ws)), "jaf_batchnorm_stats")
         y = torch.empty_like(x)
         check(L.jaf_batchnorm_act_fwd(_s(), _p(x), _p(stats), _p(weight), _p(bias), _p(residual), _p(y), N, C, H * W,
                                       act, slope), "jaf_batchnorm_act_fwd")
@@ -463,8 +484,9 @@ class _BatchNormActFn(Function):
         dx = torch.empty_like(x)
         dw = torch.empty_like(weight)
         db = torch.empty_like(weight)
+        ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
         check(lib().jaf_batchnorm_act_bwd(_s(), _p(dy), _p(x), _p(y), _p(stats), _p(weight), _p(dx), _p(dw), _p(db), N,
-                                          C, H * W, act, slope, 1 if training else 0), "jaf_batchnorm_act_bwd")
+                                          C, H * W, act, slope, 1 if training else 0, _p(ws)), "jaf_batchnorm_act_bwd")
         return dx, dw, db, None, None, None, None, None, (dy if has_res else None), None, None
 
 
