@@ -168,6 +168,35 @@ def test_conv2d_shared_source():
         assert maxerr(t.grad, r.grad) <= 3e-4 * max(1.0, r.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 2e-4), ("bf16", 3e-2)])
+def test_convlstm_sequence_matrix_core_modes(mode, tol):
+    """ConvLSTM on the bf16 matrix-core paths vs the fp32 oracle (h_T and the input gradient)."""
+    from oracle import torch_oracle as O
+    ops = _ops()
+    T, B, G, C, H, W = 3, 2, 2, 12, 20, 20
+    x = R(1, T, B, G * C, H, W)
+    w = R(2, G * 4 * C, 2 * C, 3, 3, lo=-0.3, hi=0.3)
+    b = R(3, G * 4 * C, lo=-0.2, hi=0.2)
+    xr = x.clone().requires_grad_(True)
+    hT = []
+    for g in range(G):
+        seq = [xr[t][:, g * C:(g + 1) * C] for t in range(T)]
+        _, (h, c) = O.convlstm(w[g * 4 * C:(g + 1) * 4 * C], b[g * 4 * C:(g + 1) * 4 * C], seq)
+        hT.append(h)
+    h_ref = torch.cat(hT, 1)
+    proj = R(4, *h_ref.shape)
+    (h_ref * proj).sum().backward()
+    prev = ops.set_precision(mode)
+    try:
+        xd = dev(x).requires_grad_(True)
+        h, _ = ops.convlstm(xd, dev(w).requires_grad_(True), dev(b).requires_grad_(True), groups=G)
+        (h * dev(proj)).sum().backward()
+    finally:
+        ops.set_precision(prev)
+    assert maxerr(h, h_ref) <= tol
+    assert maxerr(xd.grad, xr.grad) <= 4 * tol * max(1.0, xr.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("shape", [(3, 2, 1, 4, 7, 5), (4, 1, 3, 12, 20, 20), (2, 2, 2, 24, 13, 13)])
 def test_convlstm_sequence(shape):
     from oracle import torch_oracle as O
