@@ -6,8 +6,9 @@
 A step = one full stage-4 train step (generator forward, VGG+L1 loss, face-D update, 3 D updates,
 generator backward, 6 Adam updates, gradient all-reduce when N > 1) over a synthetic batch of
 B=8 samples per GPU that is already resident in HBM.  One target frame is generated per sample
-(SURVEY F4), so frames/s = global batch / step time.  fp32 end to end (fp32 MFMA).
-Rank 0 prints ONE JSON line.
+(SURVEY F4), so frames/s = global batch / step time.  Default arithmetic is BASELINE configs[2]'s:
+bf16 matrix-core operands, fp32 accumulation, fp32 tensors in HBM (--precision f32 / bf16x3 select
+the exact-fp32 and the split-bf16 parity-grade paths).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -21,7 +22,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_MFMA_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+# MI355X_MICROARCH.md: dense MFMA peaks.  bf16x3 issues 3 bf16 MFMAs per algorithmic product.
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0}
 SEEDS = {"accu": 1301, "inpaint": 1302, "bg": 1303, "refine": 1304, "flow": 1305, "D": 1306, "face": 1307, "vgg": 1308}
 
 
@@ -61,6 +63,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
     ap.add_argument("--precision", default="bf16", choices=["f32", "bf16", "bf16x3"],
                     help="matrix-core arithmetic of the convolutions (tensors stay fp32 in HBM)")
+    ap.add_argument("--parity-mode-steps", type=int, default=3,
+                    help="N=1 only: also time this many steps in the bf16x3 parity-grade mode (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -117,7 +121,8 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "stage-4 full train step (G fwd+bwd, VGG+L1, 3x D, face-D, 6x Adam), "
-                               "B=%d/GPU, T=4 refs, 256x256, 1 target frame/sample (configs[2] at fp32)" % B,
+                               "B=%d/GPU, T=4 refs, 256x256, 1 target frame/sample (BASELINE configs[2]); "
+                               "%s matrix-core arithmetic, fp32 accumulate, fp32 tensors in HBM" % (B, args.precision),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                    "clips_per_s": frames_per_s / 30.0,
                    "algorithmic_tflop_per_step": 2.2788 * world * B,
@@ -136,8 +141,8 @@ def main():
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["flops"] for v in summ.values())
         result["roofline"] = {
-            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+            "bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+            "frac": achieved / MFMA_PEAK_TFLOPS[args.precision], "traffic": None,
             "kernel": name, "launches_per_step": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
             "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
             "all_mfma_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
@@ -145,6 +150,19 @@ def main():
             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)} for k, v in sorted(summ.items())},
         }
+    if rank == 0 and world == 1 and args.parity_mode_steps > 0 and args.precision == "bf16":
+        # the parity-grade mode (frame <= 1e-3 L-inf vs the fp32 oracle, tests/test_gpu_step.py) timed beside it
+        ops.set_precision("bf16x3")
+        trainer.train_step(batch)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.parity_mode_steps):
+            trainer.train_step(batch)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / args.parity_mode_steps
+        ops.set_precision(args.precision)
+        result["config"]["bf16x3_parity_mode"] = {"ms_per_step": dt * 1e3, "frames_per_s": B / dt,
+                                                  "steps": args.parity_mode_steps}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(mods, fidx)
     if rank == 0:

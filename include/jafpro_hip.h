@@ -115,6 +115,28 @@ int jaf_conv2d_fwd_direct(jaf_stream_t s, const jaf_conv_desc* d,
                           const float* src0, const float* src1, const float* src2,
                           const float* w, const float* bias, float* out);
 
+/* Packed-input path of JAF_PREC_BF16 (csrc/conv_dma.hip).  jaf_conv2d_pack_input converts the
+ * (concatenated, grouped) fp32 input of a descriptor ONCE into bf16
+ * [N][G][ceil(Cin/8)][H][W][8 channels]; jaf_conv2d_fwd_packed / jaf_convlstm_cell_fwd_packed then
+ * stage their LDS patches by DMA with no per-element work.  Plans come from jaf_conv2d_plan_packed;
+ * weights are packed by jaf_conv2d_pack with that plan.  The forward conv and the weight gradient
+ * of a layer share one packed input; dgrad and wgrad share one packed dz.                      */
+int64_t jaf_conv2d_packed_input_bytes(const jaf_conv_desc* d);
+int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
+                          const float* src2, void* packed);
+int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
+int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                          const void* packed_in, const void* packed_w, const float* bias, float* out);
+int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                 const void* packed_in, const void* packed_w, const float* bias,
+                                 const float* c_prev, float* h_out, float* c_out, float* gates_out);
+
+/* 3x3 weight gradient from the packed input of the forward conv and the packed dz of the data
+ * gradient (csrc/wgrad_dma.hip).  Returns JAF_EUNSUPPORTED for shapes it does not cover (stride-2
+ * layers with more than 16 input channels): use jaf_conv2d_wgrad there.                          */
+int jaf_conv2d_wgrad_packed(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x,
+                            const void* packed_dz, float* dw, int accumulate);
+
 /* dW[G][Cout][w_cin_tot][KH][KW] (+)= sum over n,pixels of dz * input patch; dz is laid out as
  * the forward output (out_ctot/out_coff).  accumulate=0 zeroes the touched slice first.        */
 int jaf_conv2d_wgrad(jaf_stream_t s, const jaf_conv_desc* d,

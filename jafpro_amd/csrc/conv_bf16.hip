@@ -512,7 +512,11 @@ __global__ void conv_pack_bf16_kernel(const PackBArgs a) {
 
 int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
               int32_t w_rows_tot, void* packed) {
-    JAF_REQUIRE(planb_ok(d, plan) && w && packed);
+    // the packed-input kernel (conv_dma.hip) shares this weight image: only the fields that shape it are checked
+    JAF_REQUIRE(plan && w && packed && plan->precision == d->precision && plan->MT >= 1 && plan->MT <= 4 &&
+                plan->NG >= 1 && plan->NG <= 4 && plan->nchunks == jaf_cdiv(jaf_cdiv(d->Cin, 8), plan->NG) &&
+                plan->ng_last == jaf_cdiv(d->Cin, 8) - (plan->nchunks - 1) * plan->NG &&
+                plan->nsteps == jaf_cdiv(d->KH * d->KW * plan->NG, 4) && plan->mblocks == jaf_cdiv(d->Cout, 16 * plan->MT));
     PackBArgs a;
     a.w = w;
     a.out = (unsigned short*)packed;

@@ -1,0 +1,592 @@
+// Packed-input convolution: the bf16 matrix-core kernel of conv_bf16.hip with its staging done by
+// the DMA path (buffer_load ... lds) instead of vector loads + conversion + ds_write.
+//
+// The input is first re-laid out ONCE per tensor by jaf_conv2d_pack_input into
+//     packed[n][g][group8][y][x][8 channels]   (bf16, channel counts padded to 8 with zeros),
+// i.e. exactly the 16-byte (position, 8 channels) items of the LDS patch image.  The forward
+// convolution and the weight-gradient of a layer share one packed input, the data-gradient and the
+// weight-gradient share one packed dz, so every tensor is converted to bf16 once instead of once
+// per consumer and per Cout block.
+//
+// In the kernel a patch plane is filled by 16-byte-per-lane buffer loads that land directly in LDS:
+// lane l of round r supplies slot 64*r + l, its source offset (or an out-of-range offset for
+// padding, which the buffer unit turns into zeros -- measured, scratch/t/dma_test.hip) is chunk
+// invariant, and the plane (wave-uniform) is a scalar buffer resource.  Per 32-channel chunk a wave
+// issues <= 8 patch DMAs and <= 3 weight DMAs and no VALU staging work at all; the previous
+// kernel spent ~800 of its ~1100 instructions per chunk there.
+#include "conv_internal.h"
+#include <stdlib.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define CD_OOB 0x40000000
+#define CD_RPW 2          // patch DMA rounds per wave (4 waves x 2 rounds x 64 lanes = 512 slots max)
+
+struct ConvDArgs {
+    const unsigned char* xp;       // packed input
+    const unsigned char* wpk;      // packed weights (jaf_conv2d_pack, bf16 image order)
+    const float* bias;
+    float* out;
+    const float* c_prev;
+    float* c_out;
+    float* h_out;
+    float* gates_out;
+    jaf_conv_desc d;
+    jaf_conv_plan p;
+    int off_w, off_tab;
+    int ntiles, ngroups8;
+    float inv_pw, inv_twin;
+};
+
+__device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);
+    return __builtin_bit_cast(unsigned int, r);
+}
+
+// ---------------------------------------------------------------------------------------------
+// input packing: fp32 NCHW (up to three concatenated sources, grouped) -> bf16 [n][g][group8][y][x][8]
+// grid (x blocks, H, N*G*ngroups8); V = 4 columns per lane when W % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+struct PackInArgs {
+    const float* src[3];
+    unsigned char* out;
+    jaf_conv_desc d;
+    int ngroups8;
+};
+
+template <int V>
+__global__ void conv_pack_input_kernel(const PackInArgs a) {
+    const jaf_conv_desc& d = a.d;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (x >= d.W) return;
+    const int y = blockIdx.y;
+    int z = blockIdx.z;
+    const int cg = z % a.ngroups8;
+    z /= a.ngroups8;
+    const int g = z % d.G;
+    const int n = z / d.G;
+    const int c0 = d.src_c[0];
+    const int c01 = c0 + (d.nsrc > 1 ? d.src_c[1] : 0);
+    const long HW = (long)d.H * d.W;
+    float v[8][V];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[j][i] = 0.f;
+        if (c < d.Cin) {
+            const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
+            const int cl = (s == 0) ? c : ((s == 1) ? c - c0 : c - c01);
+            const float* sp = (s == 0) ? a.src[0] : ((s == 1) ? a.src[1] : a.src[2]);
+            const float* p = sp + ((long)n * d.src_ctot[s] + d.src_coff[s] + g * d.src_gstride[s] + cl) * HW + (long)y * d.W + x;
+            if (V == 4) {
+                const f32x4 t = *(const f32x4*)p;
+                v[j][0] = t[0]; v[j][1] = t[1]; v[j][2] = t[2]; v[j][3] = t[3];
+            } else {
+                v[j][0] = p[0];
+            }
+        }
+    }
+    unsigned char* o = a.out + ((((long)n * d.G + g) * a.ngroups8 + cg) * HW + (long)y * d.W + x) * 16;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        u32x4 w;
+        w[0] = cd_pack2(v[0][i], v[1][i]);
+        w[1] = cd_pack2(v[2][i], v[3][i]);
+        w[2] = cd_pack2(v[4][i], v[5][i]);
+        w[3] = cd_pack2(v[6][i], v[7][i]);
+        *(u32x4*)(o + i * 16) = w;
+    }
+}
+
+static bool pack_desc_ok(const jaf_conv_desc* d) {
+    if (!d) return false;
+    if (d->N < 1 || d->G < 1 || d->Cin < 1 || d->H < 1 || d->W < 1) return false;
+    if (d->nsrc < 1 || d->nsrc > 3) return false;
+    int c = 0;
+    for (int i = 0; i < d->nsrc; ++i) {
+        if (d->src_c[i] < 1 || d->src_ctot[i] < 1 || d->src_coff[i] < 0 || d->src_gstride[i] < 0) return false;
+        if (d->src_coff[i] + (d->G - 1) * d->src_gstride[i] + d->src_c[i] > d->src_ctot[i]) return false;
+        c += d->src_c[i];
+    }
+    return c == d->Cin;
+}
+
+extern "C" int64_t jaf_conv2d_packed_input_bytes(const jaf_conv_desc* d) {
+    if (!pack_desc_ok(d)) return -1;
+    return (int64_t)d->N * d->G * jaf_cdiv(d->Cin, 8) * d->H * d->W * 16;
+}
+
+extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
+                                     const float* src2, void* packed) {
+    JAF_REQUIRE(pack_desc_ok(d) && src0 && packed);
+    JAF_REQUIRE(d->nsrc < 2 || src1);
+    JAF_REQUIRE(d->nsrc < 3 || src2);
+    PackInArgs a;
+    a.src[0] = src0; a.src[1] = src1; a.src[2] = src2;
+    a.out = (unsigned char*)packed;
+    a.d = *d;
+    a.ngroups8 = jaf_cdiv(d->Cin, 8);
+    const long nz = (long)d->N * d->G * a.ngroups8;
+    if (nz > 65535 || d->H > 65535) return JAF_EUNSUPPORTED;
+    const bool v4 = (d->W % 4 == 0) && ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
+    if (v4) {
+        const int t = d->W / 4 >= 64 ? 64 : 32;
+        hipLaunchKernelGGL(conv_pack_input_kernel<4>, dim3(jaf_cdiv(d->W / 4, t), d->H, (unsigned)nz), dim3(t), 0, (hipStream_t)s, a);
+    } else {
+        const int t = d->W >= 128 ? 128 : 64;
+        hipLaunchKernelGGL(conv_pack_input_kernel<1>, dim3(jaf_cdiv(d->W, t), d->H, (unsigned)nz), dim3(t), 0, (hipStream_t)s, a);
+    }
+    return jaf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// the convolution kernel
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, bool LSTM>
+__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const jaf_conv_desc& d = a.d;
+    const jaf_conv_plan& P = a.p;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int q = lane >> 4;
+    constexpr int MR = 16 * MT;
+    const int NG = P.NG;
+    const int npos = P.npos, plane = P.plane, PW = P.PW;
+
+    unsigned char* s_patch = smem;
+    unsigned char* s_w = smem + a.off_w;
+    int* s_tab = (int*)(smem + a.off_tab);
+
+    // ---- block -> (row block, pixel tile, image, group), XCD-contiguous ----
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, j = bid >> 3, qn = nblk >> 3, rn = nblk & 7;
+        L = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+    }
+    const int mb = L % P.mblocks;
+    L /= P.mblocks;
+    const int tile = L % a.ntiles;
+    const int ngi = L / a.ntiles;
+    const int n = ngi / d.G;
+    const int g = ngi - n * d.G;
+    const int tx = tile % P.tiles_x;
+    const int tb = tile / P.tiles_x;
+    const int x0 = tx * P.TWIN;
+    const int pbase = tb * (64 * NT);
+    const int oy0 = pbase / P.TWIN;
+    const int iy0 = oy0 * d.stride - d.pad_t;
+    const int ix0 = x0 * d.stride - d.pad_l;
+    const int OHW = d.OH * d.OW;
+    const int HW = d.H * d.W;
+
+    // ---- one-time table: slot -> patch byte offset (full chunk, last chunk) ----
+    {
+        const int taps = d.KH * d.KW;
+        const float inv_kw = 1.0f / (float)d.KW;
+        for (int e = tid; e < 2 * 4 * P.nsteps; e += 256) {
+            const int which = e >= 4 * P.nsteps;
+            const int s = e - which * 4 * P.nsteps;
+            const int ngc = which ? P.ng_last : NG;
+            int v = 0;
+            if (s < taps * ngc) {
+                const int tap = (int)(((float)s + 0.5f) / (float)ngc), grp = s - tap * ngc;
+                const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - ky * d.KW;
+                v = grp * plane + (ky * PW + kx) * 16;
+            }
+            s_tab[e] = v;
+        }
+    }
+
+    // ---- per-lane output pixels ----
+    int boff[NT];
+    int opix[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = pbase + (wave * NT + nt) * 16 + li;
+        const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
+        const int ox = x0 + (p - oy * P.TWIN);
+        const bool valid = (oy < d.OH) && (ox < d.OW);
+        boff[nt] = valid ? (((oy - oy0) * d.stride * PW + (ox - x0) * d.stride) * 16) : 0;
+        opix[nt] = valid ? (oy * d.OW + ox) : -1;
+    }
+
+    // ---- DMA source offsets: wave w fills rounds w and w+4 (64 slots each) of every group plane ----
+    const int nrounds = (npos + 63) >> 6;
+    int dvoff[CD_RPW];
+    {
+        const int dil = d.dil_in;
+        const int Hd = (d.H - 1) * dil + 1;
+        const int Wd = (d.W - 1) * dil + 1;
+#pragma unroll
+        for (int j = 0; j < CD_RPW; ++j) {
+            const int pos = lane + 64 * (wave + 4 * j);
+            const int r = (int)(((float)pos + 0.5f) * a.inv_pw);
+            const int x = pos - r * PW;
+            const int iyd = iy0 + r, ixd = ix0 + x;
+            bool ok = (pos < npos) && (iyd >= 0) && (ixd >= 0) && (iyd < Hd) && (ixd < Wd);
+            int iy = iyd, ix = ixd;
+            if (dil == 2) {
+                ok = ok && !((iyd | ixd) & 1);
+                iy = iyd >> 1;
+                ix = ixd >> 1;
+            }
+            dvoff[j] = ok ? ((iy * d.W + ix) * 16) : CD_OOB;
+        }
+    }
+    // plane (group8 = 0) of this (image, group); consecutive group8 planes are HW*16 bytes apart
+    const unsigned char* xbase = a.xp + (((long)n * d.G + g) * a.ngroups8) * (long)HW * 16;
+    const int plane_bytes = HW * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long wchunk_bytes = (long)P.nsteps * MT * 1024;
+    const unsigned char* wbase = a.wpk + ((long)(g * P.mblocks + mb) * P.nchunks) * wchunk_bytes;
+
+    for (int chunk = 0; chunk < P.nchunks; ++chunk) {
+        const bool last = (chunk == P.nchunks - 1);
+        const int ngc = last ? P.ng_last : NG;
+        const int nst = last ? P.nsteps_last : P.nsteps;
+        __syncthreads();   // previous chunk consumed (first pass: slot table visible)
+
+        // ---- weights and patch: DMA straight into LDS.  Overlap with the matrix cores comes from the
+        // 2-6 workgroups resident per CU (LDS/VGPR footprint is small); an intra-workgroup second
+        // buffer measured slower than the extra resident workgroup it costs. ----
+        {
+            const unsigned char* wsrc = wbase + (long)chunk * wchunk_bytes;
+            for (int e = wave; e < nst * MT; e += 4)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + e * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
+            const unsigned char* cbase = xbase + (long)(chunk * NG) * plane_bytes;
+            for (int grp = 0; grp < ngc; ++grp) {
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)grp * plane_bytes), 0, plane_bytes, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < CD_RPW; ++j) {
+                    const int round = wave + 4 * j;
+                    if (round < nrounds)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(s_patch + grp * plane + round * 1024),
+                                                                 16, dvoff[j], 0, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
+        __syncthreads();
+
+        // ---- MFMA over the chunk's steps ----
+        const int* tab = s_tab + (last ? 4 * P.nsteps : 0);
+        for (int st = 0; st < nst; ++st) {
+            const int off = tab[4 * st + q];
+            bf16x8 bh[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off + boff[nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 ah = *(const bf16x8*)(s_w + (st * MT + mt) * 1024 + lane * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel) ----
+    if (!LSTM) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = mb * MR + mt * 16 + q * 4 + j;
+                if (co >= d.Cout) continue;
+                const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;
+                float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (opix[nt] < 0) continue;
+                    op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, d.act, d.slope);
+                }
+            }
+        }
+    } else {
+        const int C = d.Cout >> 2;   // hidden channels per group (rows are gate-interleaved: 4c+gate)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ch = ((mb * MR + mt * 16) >> 2) + q;
+            if (ch >= C) continue;
+            const float* bp = a.bias + g * d.Cout;
+            const float bi = bp[ch], bf = bp[C + ch], bo = bp[2 * C + ch], bg = bp[3 * C + ch];
+            const long hc = ((long)n * d.G + g) * C + ch;
+            const long gc = ((long)n * d.G + g) * d.Cout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if (opix[nt] < 0) continue;
+                const float gi = jaf_sigmoid(acc[mt][nt][0] + bi);
+                const float gf = jaf_sigmoid(acc[mt][nt][1] + bf);
+                const float go = jaf_sigmoid(acc[mt][nt][2] + bo);
+                const float gg = jaf_tanh(acc[mt][nt][3] + bg);
+                const float cp = a.c_prev ? a.c_prev[hc * OHW + opix[nt]] : 0.f;
+                const float cc = gf * cp + gi * gg;
+                a.c_out[hc * OHW + opix[nt]] = cc;
+                a.h_out[hc * OHW + opix[nt]] = go * jaf_tanh(cc);
+                if (a.gates_out) {
+                    float* gp = a.gates_out + gc * OHW + opix[nt];
+                    gp[(long)(ch)*OHW] = gi;
+                    gp[(long)(C + ch) * OHW] = gf;
+                    gp[(long)(2 * C + ch) * OHW] = go;
+                    gp[(long)(3 * C + ch) * OHW] = gg;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// planning (same tiling vocabulary as conv_bf16.hip; the patch must fit 512 DMA slots)
+// ---------------------------------------------------------------------------------------------
+static inline int rup_d(int v, int m) { return (v + m - 1) / m * m; }
+
+static bool cd_desc_ok(const jaf_conv_desc* d) {
+    if (!pack_desc_ok(d)) return false;
+    if (d->Cout < 1 || d->OH < 1 || d->OW < 1) return false;
+    if (d->KH < 1 || d->KW < 1 || d->KH > 7 || d->KW > 7) return false;
+    if (d->stride < 1 || d->stride > 2) return false;
+    if (d->dil_in != 1 && d->dil_in != 2) return false;
+    if (d->dil_in == 2 && d->stride != 1) return false;
+    if (d->w_cin_off < 0 || d->w_cin_tot < 1) return false;
+    if (d->out_coff < 0 || d->out_coff + d->G * d->Cout > d->out_ctot) return false;
+    if (d->pad_t < 0 || d->pad_l < 0) return false;
+    if (d->precision != JAF_PREC_BF16) return false;
+    return true;
+}
+
+extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan) {
+    JAF_REQUIRE(cd_desc_ok(d) && plan);
+    if (lstm) JAF_REQUIRE((d->Cout & 3) == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1);
+    const int M = d->Cout;
+    const int taps = d->KH * d->KW;
+    int bestMT = 1;
+    long bestPad = 1L << 60;
+    for (int mt = 4; mt >= 1; --mt) {
+        long pad = (long)jaf_cdiv(M, 16 * mt) * 16 * mt;
+        if (pad < bestPad) { bestPad = pad; bestMT = mt; }
+    }
+    int MT = bestMT;
+    if (lstm) {
+        MT = (M % 48 == 0) ? 3 : ((M % 64 == 0) ? 4 : ((M % 32 == 0) ? 2 : 1));
+        JAF_REQUIRE(M % (16 * MT) == 0);
+    }
+    const int groups = jaf_cdiv(d->Cin, 8);
+    const long OHW = (long)d->OH * d->OW;
+
+    double bestCost = 1e300;
+    int bTW = 0, bNT = 0, bNG = 0;
+    static int ngcap = 0;
+    if (!ngcap) { const char* e = getenv("JAF_CD_NGCAP"); ngcap = e ? atoi(e) : 4; if (ngcap < 1 || ngcap > 4) ngcap = 4; }
+    const int cand_tw[4] = {16, 32, 64, d->OW};
+    for (int ci = 0; ci < 4; ++ci) {
+        const int TW = cand_tw[ci];
+        if (ci < 3 && TW >= d->OW) continue;
+        for (int NT = 4; NT >= 1; NT >>= 1) {
+            const int Pn = 64 * NT;
+            int rows_span, tiles_x, tiles_p;
+            if (ci < 3) {
+                if (Pn % TW) continue;
+                rows_span = Pn / TW;
+                tiles_x = jaf_cdiv(d->OW, TW);
+                tiles_p = jaf_cdiv(d->OH, rows_span);
+            } else {
+                rows_span = (Pn % TW == 0) ? Pn / TW : (Pn + TW - 2) / TW + 1;
+                if (rows_span > d->OH) rows_span = d->OH;
+                tiles_x = 1;
+                tiles_p = jaf_cdiv(OHW, Pn);
+            }
+            const int PH = (rows_span - 1) * d->stride + d->KH;
+            const int PW = (TW - 1) * d->stride + d->KW;
+            const int npos = PH * PW;
+            if (npos > 64 * 4 * CD_RPW) continue;
+            const int plane = rup_d(npos * 16, 1024);
+            for (int NG = (groups < ngcap ? groups : ngcap); NG >= 1; --NG) {
+                const int nchunks = jaf_cdiv(groups, NG);
+                const int ng_last = groups - (nchunks - 1) * NG;
+                const int nsteps = jaf_cdiv(taps * NG, 4);
+                const int nsteps_last = jaf_cdiv(taps * ng_last, 4);
+                const long lds = (long)NG * plane + (long)nsteps * MT * 1024 + 2L * 4 * nsteps * 4 + 64;
+                if (lds > 150 * 1024) continue;
+                const double total_steps = (double)(nchunks - 1) * nsteps + nsteps_last;
+                const double mfma = (double)MT * NT * 16.0;
+                const double ldsrd = 4.0 * (MT + NT) * 4.0;
+                const double t_step = (mfma > ldsrd ? mfma : ldsrd) + 40.0;
+                const double stage = 600.0 + ((double)npos * NG * 16.0 + (double)nsteps * MT * 1024.0) / 48.0;
+                const int blocks_cu = (int)(160 * 1024 / lds);
+                const int bl = blocks_cu > 6 ? 6 : blocks_cu;
+                const double overlap = 1.0 / (double)(bl < 1 ? 1 : bl);   // resident workgroups hide each other's staging
+                const double occ_pen = bl >= 3 ? 1.0 : (bl == 2 ? 1.1 : 1.4);
+                const double fixed = 2500.0 + 60.0 * MT * NT;
+                const double cost = (double)tiles_x * tiles_p * (total_steps * t_step * occ_pen + nchunks * (stage * overlap + 250.0) + fixed);
+                if (cost < bestCost) { bestCost = cost; bTW = TW; bNT = NT; bNG = NG; }
+            }
+        }
+    }
+    JAF_REQUIRE(bTW > 0);
+    const int Pn = 64 * bNT;
+    const bool linear = (bTW == d->OW);
+    int rows_span;
+    if (!linear) {
+        rows_span = Pn / bTW;
+        plan->tiles_x = jaf_cdiv(d->OW, bTW);
+        plan->tiles_p = jaf_cdiv(d->OH, rows_span);
+    } else {
+        rows_span = (Pn % bTW == 0) ? Pn / bTW : (Pn + bTW - 2) / bTW + 1;
+        if (rows_span > d->OH) rows_span = d->OH;
+        plan->tiles_x = 1;
+        plan->tiles_p = jaf_cdiv(OHW, Pn);
+    }
+    plan->precision = JAF_PREC_BF16;
+    plan->MT = MT;
+    plan->NT = bNT;
+    plan->NG = bNG;
+    plan->CK = 8 * bNG;
+    plan->TWIN = bTW;
+    plan->PH = (rows_span - 1) * d->stride + d->KH;
+    plan->PW = (bTW - 1) * d->stride + d->KW;
+    plan->PWp = plan->PW;
+    plan->npos = plan->PH * plan->PW;
+    plan->plane = rup_d(plan->npos * 16, 1024);
+    plan->PS = plan->plane;
+    plan->MRp = 16 * MT;
+    plan->nchunks = jaf_cdiv(groups, bNG);
+    plan->ng_last = groups - (plan->nchunks - 1) * bNG;
+    plan->nsteps = jaf_cdiv(taps * bNG, 4);
+    plan->nsteps_last = jaf_cdiv(taps * plan->ng_last, 4);
+    plan->mblocks = jaf_cdiv(M, 16 * MT);
+    plan->lds_bytes = (int)((long)bNG * plan->plane + (long)plan->nsteps * MT * 1024 + 2L * 4 * plan->nsteps * 4 + 64);
+    plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * plan->nsteps * MT * 1024) / 4;
+    return JAF_OK;
+}
+
+static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
+    if (!p || p->precision != JAF_PREC_BF16) return false;
+    if (p->MT < 1 || p->MT > 4) return false;
+    if (p->NT != 1 && p->NT != 2 && p->NT != 4) return false;
+    if (p->NG < 1 || p->NG > 4) return false;
+    const int groups = jaf_cdiv(d->Cin, 8);
+    if (p->nchunks != jaf_cdiv(groups, p->NG)) return false;
+    if (p->ng_last != groups - (p->nchunks - 1) * p->NG) return false;
+    const int taps = d->KH * d->KW;
+    if (p->nsteps != jaf_cdiv(taps * p->NG, 4) || p->nsteps_last != jaf_cdiv(taps * p->ng_last, 4)) return false;
+    if (p->mblocks != jaf_cdiv(d->Cout, 16 * p->MT)) return false;
+    if (p->npos != p->PH * p->PW || p->npos > 64 * 4 * CD_RPW) return false;
+    if (p->plane < ((p->npos + 63) / 64) * 1024 || (p->plane & 1023)) return false;
+    if (p->TWIN < 1 || p->tiles_x < 1 || p->tiles_p < 1) return false;
+    const int Pn = 64 * p->NT;
+    int rows_span;
+    if (p->TWIN == d->OW && p->tiles_x == 1) {
+        rows_span = (Pn % p->TWIN == 0) ? Pn / p->TWIN : (Pn + p->TWIN - 2) / p->TWIN + 1;
+        if (rows_span > d->OH) rows_span = d->OH;
+    } else {
+        if (Pn % p->TWIN) return false;
+        rows_span = Pn / p->TWIN;
+    }
+    if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
+    if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
+    if (p->lds_bytes < p->NG * p->plane + p->nsteps * p->MT * 1024 + 2 * 4 * p->nsteps * 4) return false;
+    if (p->lds_bytes > 160 * 1024) return false;
+    if ((long)d->H * d->W * 16 >= CD_OOB) return false;
+    return true;
+}
+
+template <int MT, int NT, bool LSTM>
+static int cd_launch_one(const ConvDArgs& a, hipStream_t s) {
+    auto k = conv_dma_kernel<MT, NT, LSTM>;
+    static int attr_set = 0;
+    const int lds = a.p.lds_bytes;
+    if (lds > 48 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = 1;
+    }
+    const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
+    if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+    return jaf_launch_status();
+}
+
+template <int MT, bool LSTM>
+static int cd_launch_nt(const ConvDArgs& a, hipStream_t s) {
+    switch (a.p.NT) {
+        case 1: return cd_launch_one<MT, 1, LSTM>(a, s);
+        case 2: return cd_launch_one<MT, 2, LSTM>(a, s);
+        case 4: return cd_launch_one<MT, 4, LSTM>(a, s);
+    }
+    return JAF_EINVAL;
+}
+
+template <bool LSTM>
+static int cd_launch_mt(const ConvDArgs& a, hipStream_t s) {
+    switch (a.p.MT) {
+        case 1: return cd_launch_nt<1, LSTM>(a, s);
+        case 2: return cd_launch_nt<2, LSTM>(a, s);
+        case 3: return cd_launch_nt<3, LSTM>(a, s);
+        case 4: return cd_launch_nt<4, LSTM>(a, s);
+    }
+    return JAF_EINVAL;
+}
+
+static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* plan) {
+    a.d = *d;
+    a.p = *plan;
+    a.off_w = plan->NG * plan->plane;
+    a.off_tab = a.off_w + plan->nsteps * plan->MT * 1024;
+    a.ntiles = plan->tiles_x * plan->tiles_p;
+    a.ngroups8 = jaf_cdiv(d->Cin, 8);
+    a.inv_pw = 1.0f / (float)plan->PW;
+    a.inv_twin = 1.0f / (float)plan->TWIN;
+    a.c_prev = nullptr;
+    a.c_out = nullptr;
+    a.h_out = nullptr;
+    a.gates_out = nullptr;
+}
+
+extern "C" int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                     const void* packed_in, const void* packed_w, const float* bias, float* out) {
+    JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && out);
+    ConvDArgs a;
+    cd_fill(a, d, plan);
+    a.xp = (const unsigned char*)packed_in;
+    a.wpk = (const unsigned char*)packed_w;
+    a.bias = bias;
+    a.out = out;
+    return cd_launch_mt<false>(a, (hipStream_t)s);
+}
+
+extern "C" int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                            const void* packed_in, const void* packed_w, const float* bias,
+                                            const float* c_prev, float* h_out, float* c_out, float* gates_out) {
+    JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && bias && h_out && c_out);
+    JAF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->Cout & 3) == 0);
+    JAF_REQUIRE(d->Cout % (16 * plan->MT) == 0 && d->H == d->OH && d->W == d->OW);
+    ConvDArgs a;
+    cd_fill(a, d, plan);
+    a.xp = (const unsigned char*)packed_in;
+    a.wpk = (const unsigned char*)packed_w;
+    a.bias = bias;
+    a.out = nullptr;
+    a.c_prev = c_prev;
+    a.c_out = c_out;
+    a.h_out = h_out;
+    a.gates_out = gates_out;
+    return cd_launch_mt<true>(a, (hipStream_t)s);
+}

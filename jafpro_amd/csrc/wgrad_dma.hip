@@ -1,0 +1,312 @@
+// Weight gradient of 3x3 convolutions from PACKED bf16 operands (csrc/conv_dma.hip layout
+// [n][g][group8][y][x][8 channels]): the kernel of wgrad_bf16.hip with both tiles staged by DMA.
+//
+//   dW[co][ci][tap] = sum over images n and output pixels p of  dz[n][co][p] * X[n][ci][p*s + tap]
+//
+// * the forward input's packed image is the one the forward convolution already made, the packed dz
+//   is the one the data gradient already made: no conversion work is left in this kernel;
+// * input patch in LDS: [ci tile][position][16 channels] = two packed 16-byte items side by side per
+//   position; dz tile in LDS: [co tile][pixel][16 channels].  Both are consumed with transposed
+//   reads (ds_read_b64_tr_b16): 8 consecutive PIXELS of one channel per lane for A and B alike;
+// * bit 7 of an LDS byte address is XORed with bit 3 of the patch column (bit 3 of the pixel index
+//   for dz) so that the two 16-lane groups of a half-wave, 8 rows apart, hit different banks.  The
+//   DMA destination is lane-linear, so the swizzle is applied to the SOURCE: lane -> slot ->
+//   unswizzled (position, half) -> global offset (cdna_hip_programming.md rule 21);
+// * out-of-image positions / pixels get an out-of-range buffer offset and arrive as zeros.
+#include "conv_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+
+#define WD_TW 16
+#define WD_TH 8
+#define WD_XI 8         // patch DMA instructions per wave per tile (upper bound)
+#define WD_EP 145
+#define WD_OOB 0x7ffffff0
+
+struct WgDArgs {
+    const unsigned char* xp;
+    const unsigned char* dzp;
+    float* dw;
+    jaf_conv_desc d;
+    int WC, WK;
+    int coblocks, ciblocks, nsplit;
+    int tiles_x, tiles_y;
+    int PH, PW, PWp;
+    int xplane;            // bytes of one ci-tile plane: PH*PWp*32
+    int nx;                // DMA instructions per ci-tile plane
+    int off_dz;
+    int ngin8, ngout8;
+    float inv_pwp;
+};
+
+template <int MTW>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const jaf_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int q = lane >> 4;
+    const int WC = a.WC, WK = a.WK;
+    const int wc = wave % WC;
+    const int wk = wave / WC;
+    const int s = d.stride;
+    const int PWp = a.PWp;
+
+    unsigned char* s_x = smem;
+    unsigned char* s_dz = smem + a.off_dz;
+
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, j = bid >> 3, qn = nblk >> 3, rn = nblk & 7;
+        L = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+    }
+    const int cib = L % a.ciblocks;
+    L /= a.ciblocks;
+    const int cob = L % a.coblocks;
+    L /= a.coblocks;
+    const int split = L % a.nsplit;
+    const int g = L / a.nsplit;
+    const int ci0 = cib * 16 * WC;
+    const int co0 = cob * 16 * MTW;
+    const int HW = d.H * d.W;
+    const int OHW = d.OH * d.OW;
+
+    // ---- DMA lane constants.  Patch: instruction i = wave + 4*j covers slots [64*(i % nx), +64) of ci
+    // tile i / nx; a slot is 16 bytes: (position, half) after undoing the bit-7 swizzle. ----
+    const int nxi = WC * a.nx;                 // patch DMA instructions per tile
+    int x_rc[WD_XI], x_goff[WD_XI];
+#pragma unroll
+    for (int j = 0; j < WD_XI; ++j) {
+        const int i = wave + 4 * j;
+        const int tci = i / a.nx;
+        const int slot = (i - tci * a.nx) * 64 + lane;
+        const int addr = slot * 16;
+        const int posq = addr >> 5;
+        const int rq = (int)(((float)posq + 0.5f) * a.inv_pwp);
+        const int cq = posq - rq * PWp;
+        const int raw = addr ^ ((cq & 8) << 4);
+        const int pos = raw >> 5;
+        const int half = (raw >> 4) & 1;
+        const int r = (int)(((float)pos + 0.5f) * a.inv_pwp);
+        const int c = pos - r * PWp;
+        const int grp8 = (ci0 >> 3) + 2 * tci + half;
+        const bool live = (i < nxi) && (r < a.PH) && (c < a.PW) && (grp8 < a.ngin8);
+        x_rc[j] = live ? ((r << 16) | c) : -1;
+        x_goff[j] = (grp8 * HW + r * d.W + c) * 16;
+    }
+    // dz: instruction (co tile j, chunk = wave) covers slots [64*wave, +64) of co tile j (256 slots)
+    int z_yx, z_goff, z_half;
+    {
+        const int addr = (wave * 64 + lane) * 16;
+        const int kq = addr >> 5;
+        const int raw = addr ^ ((kq & 8) << 4);
+        const int k = raw >> 5;
+        z_half = (raw >> 4) & 1;
+        const int y = k >> 4, x = k & 15;
+        z_yx = (y << 16) | x;
+        z_goff = (z_half * OHW + y * d.OW + x) * 16;
+    }
+
+    // ---- per-lane constants of the transposed reads: lane = 16q + 4q' + p supplies the address of
+    // row (pixel) 8q + 4h + q', channels 4p..4p+3 ----
+    const int qp = (lane >> 2) & 3;
+    const int pp = lane & 3;
+    int bbase[2][3], bswz[2][3], abase[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c0h = (8 * (q & 1) + 4 * h + qp) * s;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            bbase[h][kx] = ((q >> 1) * s * PWp + c0h + kx) * 32 + pp * 8 + wc * a.xplane;
+            bswz[h][kx] = ((c0h + kx) & 8) << 4;
+        }
+        const int k = 8 * q + 4 * h + qp;                 // pixel within a 32-pixel k-step
+        abase[h] = ((k * 32) ^ ((k & 8) << 4)) + pp * 8;
+    }
+
+    f32x4 acc[MTW][9];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int items = d.N * tiles;
+    const int xbytes = a.ngin8 * HW * 16;
+    const int zbytes = a.ngout8 * OHW * 16;
+
+    for (int item = split; item < items; item += a.nsplit) {
+        const int n = item / tiles;
+        const int tile = item - n * tiles;
+        const int ty = tile / a.tiles_x;
+        const int tx = tile - ty * a.tiles_x;
+        const int oy0 = ty * WD_TH, ox0 = tx * WD_TW;
+        const int iy0 = oy0 * s - d.pad_t;
+        const int ix0 = ox0 * s - d.pad_l;
+
+        __syncthreads();   // previous tile consumed
+
+        {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.xp + ((long)n * d.G + g) * (long)xbytes), 0, xbytes, 0x00020000);
+            const int tbase = (iy0 * d.W + ix0) * 16;
+#pragma unroll
+            for (int j = 0; j < WD_XI; ++j) {
+                const int i = wave + 4 * j;
+                if (i < nxi) {
+                    const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
+                    const int tci = i / a.nx;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rx, (__attribute__((address_space(3))) void*)(s_x + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
+                        ok ? x_goff[j] + tbase : WD_OOB, 0, 0, 0);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.dzp + ((long)n * d.G + g) * (long)zbytes), 0, zbytes, 0x00020000);
+            const int y = z_yx >> 16, x = z_yx & 0xffff;
+            const bool okp = (oy0 + y < d.OH) && (ox0 + x < d.OW);
+            const int zb = z_goff + (oy0 * d.OW + ox0) * 16;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int grp8 = (co0 >> 3) + 2 * mt + z_half;
+                const bool ok = okp && (grp8 < a.ngout8);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rz, (__attribute__((address_space(3))) void*)(s_dz + mt * 4096 + wave * 1024), 16,
+                    ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB, 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+
+        for (int ks = wk; ks < 4; ks += WK) {
+            bf16x8 af[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const unsigned char* ap = s_dz + mt * 4096 + ks * 1024;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[0]));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[1]));
+                af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int rowoff = ((2 * ks * s + ky) * PWp) * 32;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int a0 = (bbase[0][kx] + rowoff) ^ bswz[0][kx];
+                    const int a1 = (bbase[1][kx] + rowoff) ^ bswz[1][kx];
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a0));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a1));
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        acc[mt][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][ky * 3 + kx], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: transpose through LDS, then atomics along dW's memory order ----
+    float* s_ep = (float*)smem + wave * (16 * WD_EP);
+    const int cit = ci0 + wc * 16;
+    const int nrem = (d.Cin - cit) * 9;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_ep[(q * 4 + j) * WD_EP + li * 9 + t] = acc[mt][t][j];
+        __syncthreads();
+        for (int e = lane; e < 16 * 144; e += 64) {
+            const int row = e / 144;
+            const int rem = e - row * 144;
+            const int co = co0 + mt * 16 + row;
+            if (co < d.Cout && rem < nrem) {
+                float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
+                atomicAdd(p, s_ep[row * WD_EP + rem]);
+            }
+        }
+    }
+}
+
+static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x,
+                                       const void* packed_dz, float* dw, int accumulate) {
+    JAF_REQUIRE(d && packed_x && packed_dz && dw);
+    JAF_REQUIRE(d->KH == 3 && d->KW == 3 && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
+    JAF_REQUIRE(d->N >= 1 && d->G >= 1 && d->Cin >= 1 && d->Cout >= 1 && d->w_cin_off >= 0 && d->w_cin_off + d->Cin <= d->w_cin_tot);
+    hipStream_t s = (hipStream_t)s_;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->G * d->Cout * d->w_cin_tot * 9, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    WgDArgs a;
+    a.xp = (const unsigned char*)packed_x;
+    a.dzp = (const unsigned char*)packed_dz;
+    a.dw = dw;
+    a.d = *d;
+    int MTW = 1;
+    long bestPad = 1L << 60;
+    for (int mt = 4; mt >= 1; --mt) {
+        long pad = (long)jaf_cdiv(d->Cout, 16 * mt) * 16 * mt;
+        if (pad < bestPad) { bestPad = pad; MTW = mt; }
+    }
+    a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
+    a.WK = 4 / a.WC;
+    a.coblocks = jaf_cdiv(d->Cout, 16 * MTW);
+    a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);
+    a.tiles_x = jaf_cdiv(d->OW, WD_TW);
+    a.tiles_y = jaf_cdiv(d->OH, WD_TH);
+    a.PH = (WD_TH - 1) * d->stride + 3;
+    a.PW = (WD_TW - 1) * d->stride + 3;
+    a.PWp = rup_w(a.PW, 8);
+    a.xplane = rup_w(a.PH * a.PWp * 32, 1024);
+    a.nx = a.xplane / 1024;
+    if (jaf_cdiv(a.WC * a.nx, 4) > WD_XI) return JAF_EUNSUPPORTED;   // stride-2 patches of wide layers: caller falls back
+    a.off_dz = a.WC * a.xplane;
+    a.ngin8 = jaf_cdiv(d->Cin, 8);
+    a.ngout8 = jaf_cdiv(d->Cout, 8);
+    a.inv_pwp = 1.0f / (float)a.PWp;
+    JAF_REQUIRE((long)a.ngin8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
+    int lds = a.off_dz + MTW * 4096;
+    const int lds_ep = 4 * 16 * WD_EP * 4;
+    if (lds < lds_ep) lds = lds_ep;
+    JAF_REQUIRE(lds <= 160 * 1024);
+    const long items = (long)d->N * a.tiles_x * a.tiles_y;
+    const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
+    long nsplit = (1536 + outblocks - 1) / outblocks;
+    if (nsplit > items) nsplit = items;
+    if (nsplit < 1) nsplit = 1;
+    a.nsplit = (int)nsplit;
+    const long nblk = outblocks * nsplit;
+    JAF_REQUIRE(nblk <= 0x7fffffffL);
+#define JAF_WGD(MT_)                                                                                   \
+    do {                                                                                               \
+        auto k = conv_wgrad_dma_kernel<MT_>;                                                           \
+        static int attr_set = 0;                                                                       \
+        if (lds > 48 * 1024 && !attr_set) {                                                            \
+            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) return (int)e;                                                        \
+            attr_set = 1;                                                                              \
+        }                                                                                              \
+        hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
+    } while (0)
+    switch (MTW) {
+        case 1: JAF_WGD(1); break;
+        case 2: JAF_WGD(2); break;
+        case 3: JAF_WGD(3); break;
+        default: JAF_WGD(4); break;
+    }
+#undef JAF_WGD
+    return jaf_launch_status();
+}

@@ -8,6 +8,7 @@ CHECK_CONTIGUOUS, rasterize_cuda.cpp:66-68).
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
 
@@ -56,6 +57,9 @@ _PLAN_CACHE = {}
 _PACK_CACHE = {}
 _PROF = None
 _PRECISION = PREC_F32
+# JAF_PREC_BF16 runs on the packed-input (DMA-staged) kernels of csrc/conv_dma.hip; JAF_NO_PACKED=1 keeps
+# the fp32-input bf16 kernel (conv_bf16.hip) for A/B measurements.
+_USE_PACKED = os.environ.get("JAF_NO_PACKED") is None
 _PREC_NAMES = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
 
@@ -74,6 +78,10 @@ def set_precision(name: str) -> str:
 
 def get_precision() -> str:
     return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
+
+
+def _wgrad_name(KH, KW) -> str:
+    return "conv_wgrad_bf16_kernel" if (_PRECISION == PREC_BF16 and KH == 3 and KW == 3) else "conv_wgrad_kernel"
 
 
 def _kname(lstm: bool, KH, KW, pl) -> str:
@@ -134,20 +142,40 @@ def _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
     return d
 
 
+def _packed_path(d: ConvDesc) -> bool:
+    return _USE_PACKED and d.precision == PREC_BF16
+
+
 def _plan(key, d: ConvDesc, lstm: int) -> ConvPlan:
-    k = (key, lstm, d.precision)
+    packed = _packed_path(d)
+    k = (key, lstm, d.precision, packed)
     pl = _PLAN_CACHE.get(k)
     if pl is None:
         pl = ConvPlan()
-        check(lib().jaf_conv2d_plan(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan")
+        if packed:
+            check(lib().jaf_conv2d_plan_packed(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan_packed")
+        else:
+            check(lib().jaf_conv2d_plan(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan")
         _PLAN_CACHE[k] = pl
     return pl
+
+
+def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc) -> torch.Tensor:
+    """bf16 [N][G][ceil(Cin/8)][H][W][8] image of a descriptor's (concatenated, grouped) input: converted
+    once, consumed by the forward conv and the weight gradient (or by dgrad and wgrad for a dz)."""
+    nbytes = int(lib().jaf_conv2d_packed_input_bytes(ctypes.byref(d)))
+    if nbytes <= 0:
+        raise RuntimeError("jaf_conv2d_packed_input_bytes: invalid descriptor")
+    xp = torch.empty(nbytes, device=srcs[0].device, dtype=torch.uint8)
+    ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+    check(lib().jaf_conv2d_pack_input(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(xp)), "jaf_conv2d_pack_input")
+    return xp
 
 
 def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mode: int, key) -> torch.Tensor:
     """Packs `weight` for (desc, plan, mode); cached while the SAME tensor object is not modified
     (the entry holds a weak reference: a new tensor that reuses a freed address must not hit)."""
-    ck = (id(weight), weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision)
+    ck = (id(weight), weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision, pl.nsteps, pl.plane)
     hit = _PACK_CACHE.get(ck)
     if hit is not None and hit[0]() is weight:
         return hit[1]
@@ -166,7 +194,8 @@ def _out_size(n, k, s, p):
 
 def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_tot: int, mode: int,
               bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
-              w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0):
+              w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
+              xp: Optional[torch.Tensor] = None, want_xp: bool = False):
     if out is None:
         out_ctot = G * Cout
         out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
@@ -176,13 +205,26 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
                    out_ctot, out_coff, act, slope)
     pl = _plan(key, d, 0)
     wpk = _packed(weight, w_rows_tot, d, pl, mode, key[:17])
+    if _packed_path(d):
+        if xp is None:
+            xp = pack_input(srcs, d)
+        ev = _PROF.begin() if _PROF is not None else None
+        check(lib().jaf_conv2d_fwd_packed(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out)),
+              "jaf_conv2d_fwd_packed")
+        if ev is not None:
+            _PROF.end("conv_dma_kernel<%d, %d, false>" % (pl.MT, pl.NT), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
+        return (out, xp) if want_xp else out
     ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
     ev = _PROF.begin() if _PROF is not None else None
     check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
                                _p(out)), "jaf_conv2d_fwd")
     if ev is not None:
         _PROF.end(_kname(False, KH, KW, pl), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
-    return out
+    return (out, None) if want_xp else out
+
+
+def _wgrad_packed_ok(m) -> bool:
+    return m.KH == 3 and m.KW == 3 and (m.stride == 1 or m.Cin <= 16)
 
 
 def _grad_inplace(p: torch.Tensor) -> bool:
@@ -199,8 +241,10 @@ class _ConvFn(Function):
     @staticmethod
     def forward(ctx, weight, bias, meta: _ConvMeta, *srcs):
         m = meta
-        y = _conv_raw(srcs, m.specs, weight, m.Cout, PACK_FWD, bias, m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW,
-                      m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope)
+        y, xp = _conv_raw(srcs, m.specs, weight, m.Cout, PACK_FWD, bias, m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW,
+                          m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True)
+        # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
+        ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.meta = m
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
@@ -222,13 +266,15 @@ class _ConvFn(Function):
         dsrcs: List[Optional[torch.Tensor]] = []
         pad_d = m.KH - 1 - m.pad
         coff = 0
+        dzp = None       # packed dz: shared by the data gradients of all sources
         for i, t in enumerate(srcs):
             c, ctot, _, gs = m.specs[i]
             if ctx.needs_input_grad[3 + i]:
                 # transposed convolution: rows = this source's channels, reduction = Cout
                 spec = [(m.Cout, m.G * m.Cout, 0, m.Cout)]
-                g = _conv_raw([dz], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
-                              m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0)
+                g, dzp = _conv_raw([dz], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
+                                   m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0, xp=dzp,
+                                   want_xp=True)
                 if gs == 0:      # source shared by all groups: sum the per-group gradients
                     g = g.view(m.N, m.G, c, m.H, m.W).sum(1)
                 dsrcs.append(g)
@@ -246,10 +292,20 @@ class _ConvFn(Function):
                            m.specs, m.cin_tot, 0, m.G * m.Cout, 0, ACT_NONE, 0.0)
             ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
             ev = _PROF.begin() if _PROF is not None else None
-            check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
-                  "jaf_conv2d_wgrad")
+            if ctx.xp is not None and _packed_path(d):
+                if dzp is None:
+                    dzd = _make_desc(m.N, m.G, m.Cout, 1, m.OH, m.OW, m.OH, m.OW, 1, 1, 1, 0, 0, 1,
+                                     [(m.Cout, m.G * m.Cout, 0, m.Cout)], 1, 0, m.G, 0, ACT_NONE, 0.0)
+                    dzp = pack_input([dz], dzd)
+                check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xp), _p(dzp), _p(dw), 1 if inplace else 0),
+                      "jaf_conv2d_wgrad_packed")
+                wname = "conv_wgrad_dma_kernel"
+            else:
+                check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
+                      "jaf_conv2d_wgrad")
+                wname = _wgrad_name(m.KH, m.KW)
             if ev is not None:
-                _PROF.end("conv_wgrad_kernel", 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
+                _PROF.end(wname, 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
             if inplace:
                 dw = None
         if ctx.has_bias and ctx.needs_input_grad[1]:
@@ -337,6 +393,7 @@ class _ConvLSTMFn(Function):
         hs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
         cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
         gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.float32) if keep else None
+        xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
         for t in range(T):
             first = t == 0
             specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
@@ -346,6 +403,16 @@ class _ConvLSTMFn(Function):
             pl = _plan(key, d, 1)
             wpk = _packed(weight, 4 * C, d, pl, PACK_LSTM, key)
             ev = _PROF.begin() if _PROF is not None else None
+            if _packed_path(d):
+                xp = pack_input([x[t]] if first else [x[t], hs[t - 1]], d)
+                if keep:
+                    xps.append(xp)
+                check(L.jaf_convlstm_cell_fwd_packed(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
+                                                     None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
+                                                     _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd_packed")
+                if ev is not None:
+                    _PROF.end("conv_dma_kernel<%d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                continue
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
                                           None if first else _p(hs[t - 1]), _p(wpk), _p(bias),
                                           None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
@@ -355,6 +422,7 @@ class _ConvLSTMFn(Function):
         ctx.G = G
         ctx.need_all = need_all
         ctx.bias_ref = bias
+        ctx.xps = xps if (keep and len(xps) == T) else None
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates)
         c_last = cs[T - 1].clone()
@@ -395,20 +463,29 @@ class _ConvLSTMFn(Function):
             Cin = C if first else 2 * C
             d = _make_desc(N, G, Cin, 4 * C, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, 2 * C, 0, 4 * GC, 0, ACT_NONE, 0.0)
             acc = 0 if t == T - 1 else 1
+            gspec = [(4 * C, 4 * GC, 0, 4 * C)]
+            gtp = None       # packed gate gradients: shared by the weight gradient and the two data gradients
             ev = _PROF.begin() if _PROF is not None else None
-            check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None, _p(gt),
-                                     _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
+            if ctx.xps is not None and _packed_path(d):
+                gd = _make_desc(N, G, 4 * C, 1, H, W, H, W, 1, 1, 1, 0, 0, 1, gspec, 1, 0, G, 0, ACT_NONE, 0.0)
+                gtp = pack_input([gt], gd)
+                check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
+                                                1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
+                wname = "conv_wgrad_dma_kernel"
+            else:
+                check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None, _p(gt),
+                                         _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
+                wname = _wgrad_name(3, 3)
             if ev is not None:
-                _PROF.end("conv_wgrad_kernel", 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                _PROF.end(wname, 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
             check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
                   "jaf_channel_sum")
-            gspec = [(4 * C, 4 * GC, 0, 4 * C)]
             if dx is not None:
-                _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1, 1,
-                          2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0)
+                _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
+                                   1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True)
             if not first:
                 dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
-                               1, 2 * C, C, ACT_NONE, 0.0)
+                               1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
             dc = dc_prev
         return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None
 
