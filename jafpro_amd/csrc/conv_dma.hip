@@ -63,8 +63,8 @@ template <int V>
 __global__ void conv_pack_input_kernel(const PackInArgs a) {
     const jaf_conv_desc& d = a.d;
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * V;
-    if (x >= d.W) return;
-    const int y = blockIdx.y;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= d.W || y >= d.H) return;
     int z = blockIdx.z;
     const int cg = z % a.ngroups8;
     z /= a.ngroups8;
@@ -135,13 +135,15 @@ extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, con
     const long nz = (long)d->N * d->G * a.ngroups8;
     if (nz > 65535 || d->H > 65535) return JAF_EUNSUPPORTED;
     const bool v4 = (d->W % 4 == 0) && ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
-    if (v4) {
-        const int t = d->W / 4 >= 64 ? 64 : 32;
-        hipLaunchKernelGGL(conv_pack_input_kernel<4>, dim3(jaf_cdiv(d->W / 4, t), d->H, (unsigned)nz), dim3(t), 0, (hipStream_t)s, a);
-    } else {
-        const int t = d->W >= 128 ? 128 : 64;
-        hipLaunchKernelGGL(conv_pack_input_kernel<1>, dim3(jaf_cdiv(d->W, t), d->H, (unsigned)nz), dim3(t), 0, (hipStream_t)s, a);
-    }
+    // 256-thread workgroups: tx lanes along x (a power of two covering the row when it is short), ty rows
+    const int wx = v4 ? d->W / 4 : d->W;
+    int tx = 64;
+    while (tx > 1 && (tx >> 1) >= wx) tx >>= 1;
+    if (tx < 8) tx = 8;
+    const int ty = 256 / tx;
+    const dim3 grid(jaf_cdiv(wx, tx), jaf_cdiv(d->H, ty), (unsigned)nz);
+    if (v4) hipLaunchKernelGGL(conv_pack_input_kernel<4>, grid, dim3(tx, ty), 0, (hipStream_t)s, a);
+    else hipLaunchKernelGGL(conv_pack_input_kernel<1>, grid, dim3(tx, ty), 0, (hipStream_t)s, a);
     return jaf_launch_status();
 }
 

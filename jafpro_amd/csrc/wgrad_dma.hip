@@ -43,8 +43,9 @@ struct WgDArgs {
     float inv_pwp;
 };
 
-template <int MTW>
+template <int MTW, int KS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
+    constexpr int NTAP = KS * KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -118,12 +119,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     // row (pixel) 8q + 4h + q', channels 4p..4p+3 ----
     const int qp = (lane >> 2) & 3;
     const int pp = lane & 3;
-    int bbase[2][3], bswz[2][3], abase[2];
+    int bbase[2][KS], bswz[2][KS], abase[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int c0h = (8 * (q & 1) + 4 * h + qp) * s;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int kx = 0; kx < KS; ++kx) {
             bbase[h][kx] = ((q >> 1) * s * PWp + c0h + kx) * 32 + pp * 8 + wc * a.xplane;
             bswz[h][kx] = ((c0h + kx) & 8) << 4;
         }
@@ -131,11 +132,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         abase[h] = ((k * 32) ^ ((k & 8) << 4)) + pp * 8;
     }
 
-    f32x4 acc[MTW][9];
+    f32x4 acc[MTW][NTAP];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NTAP; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
@@ -197,10 +198,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < KS; ++ky) {
                 const int rowoff = ((2 * ks * s + ky) * PWp) * 32;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
+                for (int kx = 0; kx < KS; ++kx) {
                     const int a0 = (bbase[0][kx] + rowoff) ^ bswz[0][kx];
                     const int a1 = (bbase[1][kx] + rowoff) ^ bswz[1][kx];
                     const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a0));
@@ -208,31 +209,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
-                        acc[mt][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][ky * 3 + kx], 0, 0, 0);
+                        acc[mt][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][ky * KS + kx], 0, 0, 0);
                 }
             }
         }
     }
 
-    // ---- epilogue: transpose through LDS, then atomics along dW's memory order ----
-    float* s_ep = (float*)smem + wave * (16 * WD_EP);
+    // ---- epilogue.  3x3: transpose through LDS, then atomics along dW's memory order.  5x5 / 7x7 (a few
+    // tiny first/last layers): the gradient tensor is a few KB, direct atomics. ----
     const int cit = ci0 + wc * 16;
-    const int nrem = (d.Cin - cit) * 9;
+    if (KS == 3) {
+        float* s_ep = (float*)smem + wave * (16 * WD_EP);
+        const int nrem = (d.Cin - cit) * 9;
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) {
-        __syncthreads();
+        for (int mt = 0; mt < MTW; ++mt) {
+            __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s_ep[(q * 4 + j) * WD_EP + li * 9 + t] = acc[mt][t][j];
-        __syncthreads();
-        for (int e = lane; e < 16 * 144; e += 64) {
-            const int row = e / 144;
-            const int rem = e - row * 144;
-            const int co = co0 + mt * 16 + row;
-            if (co < d.Cout && rem < nrem) {
-                float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
-                atomicAdd(p, s_ep[row * WD_EP + rem]);
+                for (int j = 0; j < 4; ++j) s_ep[(q * 4 + j) * WD_EP + li * 9 + t] = acc[mt][t][j];
+            __syncthreads();
+            for (int e = lane; e < 16 * 144; e += 64) {
+                const int row = e / 144;
+                const int rem = e - row * 144;
+                const int co = co0 + mt * 16 + row;
+                if (co < d.Cout && rem < nrem) {
+                    float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
+                    atomicAdd(p, s_ep[row * WD_EP + rem]);
+                }
+            }
+        }
+    } else {
+        const int ci = cit + li;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + mt * 16 + q * 4 + j;
+                if (co < d.Cout && ci < d.Cin) {
+                    float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + ci) * NTAP;
+#pragma unroll
+                    for (int t = 0; t < NTAP; ++t) atomicAdd(p + t, acc[mt][t][j]);
+                }
             }
         }
     }
@@ -243,11 +261,12 @@ static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x,
                                        const void* packed_dz, float* dw, int accumulate) {
     JAF_REQUIRE(d && packed_x && packed_dz && dw);
-    JAF_REQUIRE(d->KH == 3 && d->KW == 3 && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
+    JAF_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5) && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
+    const int KS = d->KH;
     JAF_REQUIRE(d->N >= 1 && d->G >= 1 && d->Cin >= 1 && d->Cout >= 1 && d->w_cin_off >= 0 && d->w_cin_off + d->Cin <= d->w_cin_tot);
     hipStream_t s = (hipStream_t)s_;
     if (!accumulate) {
-        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->G * d->Cout * d->w_cin_tot * 9, s);
+        hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->G * d->Cout * d->w_cin_tot * KS * KS, s);
         if (e != hipSuccess) return (int)e;
     }
     WgDArgs a;
@@ -257,7 +276,7 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     a.d = *d;
     int MTW = 1;
     long bestPad = 1L << 60;
-    for (int mt = 4; mt >= 1; --mt) {
+    for (int mt = (KS == 5 ? 1 : 4); mt >= 1; --mt) {
         long pad = (long)jaf_cdiv(d->Cout, 16 * mt) * 16 * mt;
         if (pad < bestPad) { bestPad = pad; MTW = mt; }
     }
@@ -267,8 +286,8 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);
     a.tiles_x = jaf_cdiv(d->OW, WD_TW);
     a.tiles_y = jaf_cdiv(d->OH, WD_TH);
-    a.PH = (WD_TH - 1) * d->stride + 3;
-    a.PW = (WD_TW - 1) * d->stride + 3;
+    a.PH = (WD_TH - 1) * d->stride + KS;
+    a.PW = (WD_TW - 1) * d->stride + KS;
     a.PWp = rup_w(a.PW, 8);
     a.xplane = rup_w(a.PH * a.PWp * 32, 1024);
     a.nx = a.xplane / 1024;
@@ -280,7 +299,7 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     JAF_REQUIRE((long)a.ngin8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
     int lds = a.off_dz + MTW * 4096;
     const int lds_ep = 4 * 16 * WD_EP * 4;
-    if (lds < lds_ep) lds = lds_ep;
+    if (KS == 3 && lds < lds_ep) lds = lds_ep;
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
@@ -290,9 +309,9 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     a.nsplit = (int)nsplit;
     const long nblk = outblocks * nsplit;
     JAF_REQUIRE(nblk <= 0x7fffffffL);
-#define JAF_WGD(MT_)                                                                                   \
+#define JAF_WGD(MT_, KS_)                                                                              \
     do {                                                                                               \
-        auto k = conv_wgrad_dma_kernel<MT_>;                                                           \
+        auto k = conv_wgrad_dma_kernel<MT_, KS_>;                                                      \
         static int attr_set = 0;                                                                       \
         if (lds > 48 * 1024 && !attr_set) {                                                            \
             hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -301,11 +320,18 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
         }                                                                                              \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)
-    switch (MTW) {
-        case 1: JAF_WGD(1); break;
-        case 2: JAF_WGD(2); break;
-        case 3: JAF_WGD(3); break;
-        default: JAF_WGD(4); break;
+    if (KS == 5) JAF_WGD(1, 5);
+    else if (KS == 1) switch (MTW) {
+        case 1: JAF_WGD(1, 1); break;
+        case 2: JAF_WGD(2, 1); break;
+        case 3: JAF_WGD(3, 1); break;
+        default: JAF_WGD(4, 1); break;
+    }
+    else switch (MTW) {
+        case 1: JAF_WGD(1, 3); break;
+        case 2: JAF_WGD(2, 3); break;
+        case 3: JAF_WGD(3, 3); break;
+        default: JAF_WGD(4, 3); break;
     }
 #undef JAF_WGD
     return jaf_launch_status();

@@ -224,7 +224,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
 
 
 def _wgrad_packed_ok(m) -> bool:
-    return m.KH == 3 and m.KW == 3 and (m.stride == 1 or m.Cin <= 16)
+    return m.KH == m.KW and m.KH in (1, 3, 5) and (m.stride == 1 or m.Cin <= 16)
 
 
 def _grad_inplace(p: torch.Tensor) -> bool:

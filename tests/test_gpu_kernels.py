@@ -134,9 +134,9 @@ def test_conv2d_bf16_matrix_core_modes(case, mode):
         assert (err > 2 * tol * sc).double().mean().item() <= 2e-3, "dgrad source at %d" % off
         assert err.max().item() <= 8e-3 * sc, "dgrad source at %d" % off
         off += c
-    # weight gradient: bf16 matrix cores for 3x3 layers in "bf16" mode (x and dz rounded), the exact
-    # fp32 kernel otherwise -- either way it must match the float64 reference of what was rounded.
-    if mode == "bf16" and k != 3:
+    # weight gradient: bf16 matrix cores for 1x1 / 3x3 / 5x5 layers in "bf16" mode (x and dz rounded), the
+    # exact fp32 kernel otherwise -- either way it must match the float64 reference of what was rounded.
+    if mode == "bf16" and k not in (1, 3, 5):
         gw = torch.autograd.grad(F.conv2d(torch.cat([t.double().view(N, G, c, H, W) for t, c in zip(srcs, cins)], 2)
                                           .reshape(N, G * Cin, H, W), wr, None, stride=s, padding=p, groups=G),
                                  wr, dz)[0]
