@@ -124,6 +124,13 @@ int jaf_conv2d_fwd_direct(jaf_stream_t s, const jaf_conv_desc* d,
 int64_t jaf_conv2d_packed_input_bytes(const jaf_conv_desc* d);
 int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
                           const float* src2, void* packed);
+/* Backward-pass companion of jaf_conv2d_pack_input for a conv output gradient dy [N, G*C, H, W]:
+ * dz = dy * act'(y) (y = the activation output, nullable for JAF_ACT_NONE), written as the packed bf16
+ * image; dbias[G*C] += per-channel sum of dz (nullable); dz (nullable) receives the fp32 dz for the
+ * few layers whose weight gradient still runs on jaf_conv2d_wgrad.  One pass instead of
+ * jaf_act_bwd + jaf_channel_sum + jaf_conv2d_pack_input.                                         */
+int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t N, int32_t G, int32_t C,
+                       int32_t H, int32_t W, int act, float slope, void* packed, float* dz, float* dbias);
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                           const void* packed_in, const void* packed_w, const float* bias, float* out);

@@ -148,6 +148,124 @@ extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// dz packing for the backward pass: dz = dy * act'(y) (activation backward), its packed bf16 image for
+// the data / weight gradient kernels, the bias gradient (per-channel sum of dz) and -- only when a
+// non-packed kernel still needs it -- the fp32 dz, all in ONE pass over dy (and y).
+// Replaces act_bwd + channel_sum + pack_input (three passes) for every packed layer.
+// grid (x blocks, row blocks, N*G*ngroups8), block (tx, ty) = 256 threads of one (image, group, group8).
+// ---------------------------------------------------------------------------------------------
+struct PackDzArgs {
+    const float* dy;
+    const float* y;        // activation output (nullable when act == NONE)
+    unsigned char* out;    // packed dz
+    float* dz;             // fp32 dz (nullable)
+    float* dbias;          // [G*C] += sum over n, pixels (nullable)
+    int N, G, C, H, W, ngroups8, act;
+    float slope;
+};
+
+__device__ __forceinline__ float dz_of(float g, float yv, int act, float slope) {
+    switch (act) {
+        case JAF_ACT_LRELU: return g * (yv > 0.f ? 1.f : slope);
+        case JAF_ACT_RELU: return g * (yv > 0.f ? 1.f : 0.f);
+        case JAF_ACT_SIGMOID: return g * yv * (1.f - yv);
+        case JAF_ACT_TANH: return g * (1.f - yv * yv);
+        default: return g;
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int yy = blockIdx.y * blockDim.y + threadIdx.y;
+    int z = blockIdx.z;
+    const int cg = z % a.ngroups8;
+    z /= a.ngroups8;
+    const int g = z % a.G;
+    const int n = z / a.G;
+    const bool live = (x < a.W) && (yy < a.H);
+    const long HW = (long)a.H * a.W;
+    float v[8][V];
+    float part[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        part[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[j][i] = 0.f;
+        if (live && c < a.C) {
+            const long e = ((long)n * a.G * a.C + (long)g * a.C + c) * HW + (long)yy * a.W + x;
+            if (V == 4) {
+                const f32x4 gq = *(const f32x4*)(a.dy + e);
+                f32x4 yq = {0.f, 0.f, 0.f, 0.f};
+                if (a.act != JAF_ACT_NONE) yq = *(const f32x4*)(a.y + e);
+                f32x4 o;
+                o[0] = dz_of(gq[0], yq[0], a.act, a.slope);
+                o[1] = dz_of(gq[1], yq[1], a.act, a.slope);
+                o[2] = dz_of(gq[2], yq[2], a.act, a.slope);
+                o[3] = dz_of(gq[3], yq[3], a.act, a.slope);
+                v[j][0] = o[0]; v[j][1] = o[1]; v[j][2] = o[2]; v[j][3] = o[3];
+                if (a.dz) *(f32x4*)(a.dz + e) = o;
+                part[j] = (o[0] + o[1]) + (o[2] + o[3]);
+            } else {
+                const float o = dz_of(a.dy[e], a.act != JAF_ACT_NONE ? a.y[e] : 0.f, a.act, a.slope);
+                v[j][0] = o;
+                if (a.dz) a.dz[e] = o;
+                part[j] = o;
+            }
+        }
+    }
+    if (live) {
+        unsigned char* o = a.out + ((((long)n * a.G + g) * a.ngroups8 + cg) * HW + (long)yy * a.W + x) * 16;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            u32x4 w;
+            w[0] = cd_pack2(v[0][i], v[1][i]);
+            w[1] = cd_pack2(v[2][i], v[3][i]);
+            w[2] = cd_pack2(v[4][i], v[5][i]);
+            w[3] = cd_pack2(v[6][i], v[7][i]);
+            *(u32x4*)(o + i * 16) = w;
+        }
+    }
+    if (a.dbias) {
+        __shared__ float red[4][8];
+        const int t = threadIdx.y * blockDim.x + threadIdx.x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[j] = jaf_wave_sum(part[j]);
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[t >> 6][j] = part[j];
+        }
+        __syncthreads();
+        if (t < 8) {
+            const int c = cg * 8 + t;
+            if (c < a.C) atomicAdd(&a.dbias[g * a.C + c], (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]));
+        }
+    }
+}
+
+extern "C" int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t N, int32_t G, int32_t C,
+                                  int32_t H, int32_t W, int act, float slope, void* packed, float* dz, float* dbias) {
+    JAF_REQUIRE(dy && packed && N >= 1 && G >= 1 && C >= 1 && H >= 1 && W >= 1);
+    JAF_REQUIRE(act == JAF_ACT_NONE || y);
+    PackDzArgs a;
+    a.dy = dy; a.y = y; a.out = (unsigned char*)packed; a.dz = dz; a.dbias = dbias;
+    a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;
+    const long nz = (long)N * G * a.ngroups8;
+    if (nz > 65535 || H > 65535) return JAF_EUNSUPPORTED;
+    const bool v4 = (W % 4 == 0) && ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
+    const int wx = v4 ? W / 4 : W;
+    int tx = 64;
+    while (tx > 1 && (tx >> 1) >= wx) tx >>= 1;
+    if (tx < 8) tx = 8;
+    const int ty = 256 / tx;
+    const dim3 grid(jaf_cdiv(wx, tx), jaf_cdiv(H, ty), (unsigned)nz);
+    if (v4) hipLaunchKernelGGL(conv_pack_dz_kernel<4>, grid, dim3(tx, ty), 0, (hipStream_t)s, a);
+    else hipLaunchKernelGGL(conv_pack_dz_kernel<1>, grid, dim3(tx, ty), 0, (hipStream_t)s, a);
+    return jaf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // the convolution kernel
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, bool LSTM>

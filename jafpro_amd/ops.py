@@ -258,7 +258,28 @@ class _ConvFn(Function):
         srcs = ctx.saved_tensors[2:]
         dy = _c(dy)
         L = lib()
-        if m.act != ACT_NONE:
+        bias = ctx.bias_ref
+        want_db = ctx.has_bias and ctx.needs_input_grad[1]
+        db = None
+        db_done = False
+        dzp = None       # packed dz: shared by the data gradients of all sources and the weight gradient
+        if _USE_PACKED and _PRECISION == PREC_BF16:
+            # one pass: activation backward + bias gradient + packed bf16 dz (+ fp32 dz only if the
+            # weight gradient of this layer still runs on the fp32-input kernel)
+            need_f32 = ctx.needs_input_grad[0] and ctx.xp is None
+            dz = torch.empty_like(dy) if need_f32 else None
+            dbt = None
+            if want_db:
+                if _grad_inplace(bias):
+                    dbt = bias.grad
+                else:
+                    dbt = db = torch.zeros(m.G * m.Cout, device=dy.device, dtype=torch.float32)
+                db_done = True
+            ng8 = (m.Cout + 7) // 8
+            dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16, device=dy.device, dtype=torch.uint8)
+            check(L.jaf_conv2d_pack_dz(_s(), _p(dy), _p(y) if m.act != ACT_NONE else None, m.N, m.G, m.Cout, m.OH, m.OW,
+                                       m.act, m.slope, _p(dzp), _p(dz), _p(dbt)), "jaf_conv2d_pack_dz")
+        elif m.act != ACT_NONE:
             dz = torch.empty_like(dy)
             check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
         else:
@@ -266,13 +287,12 @@ class _ConvFn(Function):
         dsrcs: List[Optional[torch.Tensor]] = []
         pad_d = m.KH - 1 - m.pad
         coff = 0
-        dzp = None       # packed dz: shared by the data gradients of all sources
         for i, t in enumerate(srcs):
             c, ctot, _, gs = m.specs[i]
             if ctx.needs_input_grad[3 + i]:
                 # transposed convolution: rows = this source's channels, reduction = Cout
                 spec = [(m.Cout, m.G * m.Cout, 0, m.Cout)]
-                g, dzp = _conv_raw([dz], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
+                g, dzp = _conv_raw([dz] if dz is not None else [dy], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
                                    m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0, xp=dzp,
                                    want_xp=True)
                 if gs == 0:      # source shared by all groups: sum the per-group gradients
@@ -281,8 +301,7 @@ class _ConvFn(Function):
             else:
                 dsrcs.append(None)
             coff += c
-        dw = db = None
-        bias = ctx.bias_ref
+        dw = None
         if ctx.needs_input_grad[0]:
             # a parameter whose .grad buffer already exists (step.FlatParams) is accumulated in place
             # by the kernel: no temporary, no memset, no separate AccumulateGrad add launch
@@ -308,7 +327,7 @@ class _ConvFn(Function):
                 _PROF.end(wname, 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
             if inplace:
                 dw = None
-        if ctx.has_bias and ctx.needs_input_grad[1]:
+        if want_db and not db_done:
             inplace = bias is not None and _grad_inplace(bias)
             db = bias.grad if inplace else torch.empty(m.G * m.Cout, device=dy.device, dtype=torch.float32)
             check(L.jaf_channel_sum(_s(), _p(dz), m.N, m.G * m.Cout, 0, m.G * m.Cout, m.OH * m.OW, _p(db),

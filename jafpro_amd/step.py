@@ -80,11 +80,32 @@ class Stage4Models(nn.Module):
             p.requires_grad = False
 
 
+_HOST_KEYS = ("face_bbox",)      # host integers (src/data.py:702-716): reading them must not sync the device
+
+
 def _to_dev(batch: Dict[str, np.ndarray], device) -> Dict[str, torch.Tensor]:
     out = {}
     for k, v in batch.items():
-        out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device) if isinstance(v, np.ndarray) else v
+        if k in _HOST_KEYS:
+            out[k] = np.asarray(v)
+        else:
+            out[k] = torch.from_numpy(np.ascontiguousarray(v)).to(device) if isinstance(v, np.ndarray) else v
     return out
+
+
+_FLAG_CACHE = {}
+
+
+def _used_flags(T_all: int, used, device) -> torch.Tensor:
+    """int32 [T_all] mask of the reference frames in use, resident on the device (no per-step H2D copy)."""
+    k = (T_all, tuple(used), str(device))
+    t = _FLAG_CACHE.get(k)
+    if t is None:
+        f = torch.zeros(T_all, dtype=torch.int32)
+        f[list(used)] = 1
+        t = f.to(device)
+        _FLAG_CACHE[k] = t
+    return t
 
 
 def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequence[int], prosrc: int,
@@ -96,9 +117,7 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
     x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
     accu = M.Accu_model.forward_grouped(x, len(used))                           # :278
-    flags = torch.zeros(T_all, dtype=torch.int32)
-    flags[used] = 1
-    masked = ops.part_mask_mul(accu, b["src_mask_im"].contiguous(), flags.to(accu.device))   # :283-298
+    masked = ops.part_mask_mul(accu, b["src_mask_im"].contiguous(), _used_flags(T_all, used, accu.device))   # :283-298
     inpaint = M.inpaint_model.forward_grouped(masked)                           # :300
     inpaint_warp = ops.texture_warp(inpaint, b["tgt_IUV255"], align_corners)    # :309-312
     refine_output, fg_mask = M.refine_model(inpaint_warp, S)                    # :318
@@ -206,9 +225,7 @@ def forward_clip(M: Stage4Models, clip: Dict[str, torch.Tensor], used: Sequence[
     used = list(used)
     tex = clip["src_texture_im"] if len(used) == T_all else clip["src_texture_im"][:, used].contiguous()
     accu = M.Accu_model.forward_grouped(ops.atlas_to_parts(tex.contiguous()), len(used))
-    flags = torch.zeros(T_all, dtype=torch.int32)
-    flags[used] = 1
-    masked = ops.part_mask_mul(accu, clip["src_mask_im"].contiguous(), flags.to(accu.device))
+    masked = ops.part_mask_mul(accu, clip["src_mask_im"].contiguous(), _used_flags(T_all, used, accu.device))
     inpaint = M.inpaint_model.forward_grouped(masked)
     src0 = clip["src_img"][:, 0].contiguous()
     bg_mask = 1.0 - clip["src_mask_in_image0"]
