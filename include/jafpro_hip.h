@@ -205,7 +205,8 @@ int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float* stats, co
 int jaf_batchnorm_act_bwd(jaf_stream_t s, const float* dy, const float* x, const float* y,
                           const float* stats, const float* weight, float* dx, float* dweight,
                           float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
-                          int training, double* workspace /* 2*C doubles */);
+                          int training, double* workspace /* 2*C doubles */,
+                          int accumulate /* 1: dweight/dbias += (parameter .grad buffers) */);
 
 /* ------------------------------------------------------------------------------------------
  * Resampling.

@@ -398,11 +398,11 @@ __global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const floa
     block_sum2_atomic(sa, sb, &ws[2 * c], &ws[2 * c + 1]);
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* ws, float* dweight, float* dbias, int C) {
+__global__ void bn_bwd_finalize_kernel(const double* ws, float* dweight, float* dbias, int C, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    dbias[c] = (float)ws[2 * c];
-    dweight[c] = (float)ws[2 * c + 1];
+    dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)ws[2 * c];
+    dweight[c] = (accumulate ? dweight[c] : 0.f) + (float)ws[2 * c + 1];
 }
 
 // grid (pixel blocks, C, N)
@@ -436,7 +436,7 @@ __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float
 extern "C" int jaf_batchnorm_act_bwd(jaf_stream_t s_, const float* dy, const float* x, const float* y,
                                      const float* stats, const float* weight, float* dx, float* dweight,
                                      float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
-                                     int training, double* workspace) {
+                                     int training, double* workspace, int accumulate) {
     JAF_REQUIRE(dy && x && y && stats && weight && dx && dweight && dbias && workspace && N >= 1 && C >= 1 && HW >= 1);
     JAF_REQUIRE(C <= 65535 && N <= 65535);
     hipStream_t s = (hipStream_t)s_;
@@ -446,7 +446,7 @@ extern "C" int jaf_batchnorm_act_bwd(jaf_stream_t s_, const float* dy, const flo
     const int ns = bn_nsplit(C, N, HW);
     if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, ns), dim3(256), 0, s, dy, x, y, stats, workspace, N, C, HW, act, slope);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, ns), dim3(256), 0, s, dy, x, y, stats, workspace, N, C, HW, act, slope);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, workspace, dweight, dbias, C);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, workspace, dweight, dbias, C, accumulate);
     if (v4)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, s, dy, x, y, stats, weight,
                            workspace, dx, N, C, HW, act, slope, training);

@@ -540,13 +540,15 @@ class _LayerNormLReLUFn(Function):
         N, C, H, W = x.shape
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(beta)
+        # the kernel accumulates (+=): parameters that already own a .grad buffer are updated in place
+        gi, bi = _grad_inplace(gamma), _grad_inplace(beta)
+        dgamma = gamma.grad if gi else torch.zeros_like(gamma)
+        dbeta = beta.grad if bi else torch.zeros_like(beta)
         ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
         check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
                                             _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
               "jaf_layernorm_lrelu_bwd")
-        return dx, dgamma, dbeta, None, None
+        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None
 
 
 def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01):
@@ -568,6 +570,7 @@ class _BatchNormActFn(Function):
         check(L.jaf_batchnorm_act_fwd(_s(), _p(x), _p(stats), _p(weight), _p(bias), _p(residual), _p(y), N, C, H * W,
                                       act, slope), "jaf_batchnorm_act_fwd")
         ctx.cfg = (training, act, slope, residual is not None)
+        ctx.bias_ref = bias
         ctx.save_for_backward(x, y, weight, stats)
         return y
 
@@ -578,12 +581,16 @@ class _BatchNormActFn(Function):
         N, C, H, W = x.shape
         dy = _c(dy)
         dx = torch.empty_like(x)
-        dw = torch.empty_like(weight)
-        db = torch.empty_like(weight)
+        bias = ctx.bias_ref
+        inplace = _grad_inplace(weight) and bias is not None and _grad_inplace(bias)
+        dw = weight.grad if inplace else torch.empty_like(weight)
+        db = bias.grad if inplace else torch.empty_like(weight)
         ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
         check(lib().jaf_batchnorm_act_bwd(_s(), _p(dy), _p(x), _p(y), _p(stats), _p(weight), _p(dx), _p(dw), _p(db), N,
-                                          C, H * W, act, slope, 1 if training else 0, _p(ws)), "jaf_batchnorm_act_bwd")
-        return dx, dw, db, None, None, None, None, None, (dy if has_res else None), None, None
+                                          C, H * W, act, slope, 1 if training else 0, _p(ws), 1 if inplace else 0),
+              "jaf_batchnorm_act_bwd")
+        return dx, (None if inplace else dw), (None if inplace else db), None, None, None, None, None, \
+            (dy if has_res else None), None, None
 
 
 def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, act=ACT_NONE, slope=0.0, residual=None,

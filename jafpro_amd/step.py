@@ -94,6 +94,16 @@ def _to_dev(batch: Dict[str, np.ndarray], device) -> Dict[str, torch.Tensor]:
 
 
 _FLAG_CACHE = {}
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    k = str(device)
+    st = _SIDE_STREAMS.get(k)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[k] = st
+    return st
 
 
 def _used_flags(T_all: int, used, device) -> torch.Tensor:
@@ -114,6 +124,21 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     B, T_all = b["src_img"].shape[0], b["src_img"].shape[1]
     S = M.image_size
     used = list(used)
+    # The frozen background CRN and the SMPL rasterise -> flow -> warp chain depend only on the batch:
+    # they run on a side HIP stream beside the texture pipeline (whose deep 13x13 / 25x25 levels
+    # launch grids far smaller than the chip) and are joined before the fusion blend.
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        src0 = b["src_img"][:, 0].contiguous()
+        bg_mask = 1.0 - b["src_mask_in_image0"]                                 # :230-231 (input prep)
+        bg_incomplete = (bg_mask * src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
+        with torch.no_grad():
+            bg_output = M.bg_model(bg_incomplete, S)                            # :319-320
+        prev_img = b["src_img"][:, prosrc].contiguous()
+        tsf = M.flow_calculator(prev_img, [b["src_cam"], None, b["src_verts"], None],
+                                [b["tgt_cam"], None, b["tgt_verts"], None])      # :325
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
     x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
     accu = M.Accu_model.forward_grouped(x, len(used))                           # :278
@@ -121,15 +146,10 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     inpaint = M.inpaint_model.forward_grouped(masked)                           # :300
     inpaint_warp = ops.texture_warp(inpaint, b["tgt_IUV255"], align_corners)    # :309-312
     refine_output, fg_mask = M.refine_model(inpaint_warp, S)                    # :318
-    src0 = b["src_img"][:, 0].contiguous()
-    bg_mask = 1.0 - b["src_mask_in_image0"]                                     # :230-231 (input prep)
-    bg_incomplete = (bg_mask * src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
-    with torch.no_grad():
-        bg_output = M.bg_model(bg_incomplete, S)                                # :319-320
+    main.wait_stream(side)
+    for t in (bg_output, tsf, src0):
+        t.record_stream(main)
     fusion = ops.blend(refine_output, bg_output, fg_mask)                       # :321
-    prev_img = b["src_img"][:, prosrc].contiguous()
-    tsf = M.flow_calculator(prev_img, [b["src_cam"], None, b["src_verts"], None],
-                            [b["tgt_cam"], None, b["tgt_verts"], None])          # :325
     pro = M.propagater({"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
                         "tgt_smpl_mask": b["smpl_real_mask"], "tgt_IUV": b["tgt_IUV"], "use_IUV": True})
     return {"final_output": pro["pred_target"], "final_mask": pro["weight"], "fusion_output": fusion,
