@@ -131,6 +131,12 @@ int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* s
  * jaf_act_bwd + jaf_channel_sum + jaf_conv2d_pack_input.                                         */
 int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t N, int32_t G, int32_t C,
                        int32_t H, int32_t W, int act, float slope, void* packed, float* dz, float* dbias);
+/* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
+ * [N][G][4C/8][H*W][8] (order i,f,o,g per group) and their per-channel sums ADDED to dbias[G*4C];
+ * `gates` is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0.                                   */
+int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
+                                  const float* dc_next, const float* gates, const float* c_prev,
+                                  const float* c_cur, float* dc_prev, void* packed, float* dbias);
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                           const void* packed_in, const void* packed_w, const float* bias, float* out);

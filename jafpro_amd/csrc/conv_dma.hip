@@ -266,6 +266,121 @@ extern "C" int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// ConvLSTM gate backward straight into the packed image (src/convLSTM.py:48-54 adjoint): reads the
+// saved gates i,f,o,g, c_{t-1}, c_t, dh, dc_{t+1}; writes dc_{t-1} (fp32), the PRE-activation gate
+// gradients as packed bf16 [n][g][4C/8][y][x][8] for the data / weight gradient kernels, and adds their
+// per-channel sums to the bias gradient.  The fp32 gate-gradient tensor (4C channels) is never
+// written, re-read for packing, or re-read for the bias sum.
+// A lane owns 4 consecutive hidden channels x V pixels: its 4 values of one gate are half of a
+// 16-byte packed item (C % 4 == 0 puts every gate's channel block on a 4-channel boundary).
+// grid (pixel blocks, C/4, N*G), block 256.
+// ---------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, int HW, const float* dh, const float* dc_next,
+                                                                   const float* gates, const float* c_prev, const float* c_cur,
+                                                                   float* dc_prev, unsigned char* packed, float* dbias, int iters) {
+    typedef float fv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
+    const int cb = blockIdx.y * 4;                 // first hidden channel of this lane's block
+    const long ng = blockIdx.z;
+    const int g = (int)(ng % G);
+    const int ng8 = (4 * C + 7) >> 3;
+    const long cs = (long)C * HW;
+    float sums[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sums[k] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+        const int pix = ((blockIdx.x * iters + it) * blockDim.x + threadIdx.x) * V;
+        if (pix >= HW) break;
+        float o[4][4][V];                          // [gate][channel][pixel]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cb + j;
+            const long e = (ng * C + c) * (long)HW + pix;
+            const float* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
+            float gi[V], gf[V], go[V], gg[V], cc[V], dhv[V], dcn[V], cp[V];
+            if (V == 2) {
+                *(fv*)gi = *(const fv*)gp; *(fv*)gf = *(const fv*)(gp + cs);
+                *(fv*)go = *(const fv*)(gp + 2 * cs); *(fv*)gg = *(const fv*)(gp + 3 * cs);
+                *(fv*)cc = *(const fv*)(c_cur + e); *(fv*)dhv = *(const fv*)(dh + e);
+                if (dc_next) *(fv*)dcn = *(const fv*)(dc_next + e);
+                if (c_prev) *(fv*)cp = *(const fv*)(c_prev + e);
+            } else {
+                gi[0] = gp[0]; gf[0] = gp[cs]; go[0] = gp[2 * cs]; gg[0] = gp[3 * cs];
+                cc[0] = c_cur[e]; dhv[0] = dh[e];
+                if (dc_next) dcn[0] = dc_next[e];
+                if (c_prev) cp[0] = c_prev[e];
+            }
+            float dcp[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float tc = jaf_tanh(cc[k]);
+                float dc = dhv[k] * go[k] * (1.f - tc * tc);
+                if (dc_next) dc += dcn[k];
+                const float cpv = c_prev ? cp[k] : 0.f;
+                o[0][j][k] = dc * gg[k] * gi[k] * (1.f - gi[k]);
+                o[1][j][k] = dc * cpv * gf[k] * (1.f - gf[k]);
+                o[2][j][k] = dhv[k] * tc * go[k] * (1.f - go[k]);
+                o[3][j][k] = dc * gi[k] * (1.f - gg[k] * gg[k]);
+                dcp[k] = dc * gf[k];
+            }
+            if (V == 2) *(fv*)(dc_prev + e) = *(fv*)dcp;
+            else dc_prev[e] = dcp[0];
+        }
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            const int ch = gate * C + cb;              // first of this lane's 4 gate channels (multiple of 4)
+            unsigned char* op = packed + ((ng * ng8 + (ch >> 3)) * (long)HW + pix) * 16 + ((ch >> 2) & 1) * 8;
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                unsigned int w0 = cd_pack2(o[gate][0][k], o[gate][1][k]);
+                unsigned int w1 = cd_pack2(o[gate][2][k], o[gate][3][k]);
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 w = {w0, w1};
+                *(u32x2*)(op + k * 16) = w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sums[gate * 4 + j] += o[gate][j][k];
+            }
+        }
+    }
+    // bias gradient: 16 gate channels per workgroup
+    __shared__ float red[4][16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sums[k] = jaf_wave_sum(sums[k]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) red[threadIdx.x >> 6][k] = sums[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        const int gate = threadIdx.x >> 2, j = threadIdx.x & 3;
+        atomicAdd(&dbias[g * 4 * C + gate * C + cb + j],
+                  (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    }
+}
+
+extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
+                                             const float* dc_next, const float* gates, const float* c_prev,
+                                             const float* c_cur, float* dc_prev, void* packed, float* dbias) {
+    JAF_REQUIRE(dh && gates && c_cur && dc_prev && packed && dbias && N >= 1 && G >= 1 && C >= 4 && HW >= 1);
+    if (C % 4) return JAF_EUNSUPPORTED;
+    JAF_REQUIRE(C / 4 <= 65535 && (long)N * G <= 65535);
+    const bool v2 = (HW % 2 == 0) && ((((uintptr_t)dh) | ((uintptr_t)gates) | ((uintptr_t)c_cur) | ((uintptr_t)dc_prev) |
+                                       ((uintptr_t)dc_next) | ((uintptr_t)c_prev)) & 7) == 0;
+    const int V = v2 ? 2 : 1;
+    const int per_block = 256 * V;
+    int iters = 8;
+    while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
+    const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 4, N * G);
+    if (v2)
+        hipLaunchKernelGGL(lstm_gates_bwd_pack_kernel<2>, grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, gates, c_prev,
+                           c_cur, dc_prev, (unsigned char*)packed, dbias, iters);
+    else
+        hipLaunchKernelGGL(lstm_gates_bwd_pack_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, gates, c_prev,
+                           c_cur, dc_prev, (unsigned char*)packed, dbias, iters);
+    return jaf_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
 // the convolution kernel
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, bool LSTM>

@@ -462,9 +462,17 @@ class _ConvLSTMFn(Function):
         bias = ctx.bias_ref
         w_inplace, b_inplace = _grad_inplace(weight), _grad_inplace(bias)
         dw = weight.grad if w_inplace else torch.empty_like(weight)
-        db = bias.grad if b_inplace else torch.empty(4 * GC, device=x.device, dtype=torch.float32)
+        # fused path: gate backward writes the packed bf16 gate gradients + the bias sums directly
+        fused = ctx.xps is not None and _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
+        if b_inplace:
+            db = bias.grad
+        elif fused:
+            db = torch.zeros(4 * GC, device=x.device, dtype=torch.float32)
+        else:
+            db = torch.empty(4 * GC, device=x.device, dtype=torch.float32)
         dc = None
         dh = None
+        ng8 = (4 * C + 7) // 8
         for t in range(T - 1, -1, -1):
             first = t == 0
             if ctx.need_all:
@@ -473,32 +481,43 @@ class _ConvLSTMFn(Function):
                 dht = dh_out if t == T - 1 else dh
             dht = _c(dht)
             dc_prev = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
-            gt = gates[t]      # overwritten with the pre-activation gate gradients
-            check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                           None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev)),
-                  "jaf_convlstm_gates_bwd")
-            # weight / bias gradients (accumulated over t)
+            gt = gates[t]
             specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
             Cin = C if first else 2 * C
             d = _make_desc(N, G, Cin, 4 * C, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, 2 * C, 0, 4 * GC, 0, ACT_NONE, 0.0)
             acc = 0 if t == T - 1 else 1
             gspec = [(4 * C, 4 * GC, 0, 4 * C)]
             gtp = None       # packed gate gradients: shared by the weight gradient and the two data gradients
-            ev = _PROF.begin() if _PROF is not None else None
-            if ctx.xps is not None and _packed_path(d):
-                gd = _make_desc(N, G, 4 * C, 1, H, W, H, W, 1, 1, 1, 0, 0, 1, gspec, 1, 0, G, 0, ACT_NONE, 0.0)
-                gtp = pack_input([gt], gd)
+            if fused:
+                gtp = torch.empty(N * G * ng8 * H * W * 16, device=x.device, dtype=torch.uint8)
+                check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
+                                                      None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
+                                                      _p(db)), "jaf_convlstm_gates_bwd_packed")
+                ev = _PROF.begin() if _PROF is not None else None
                 check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
                                                 1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
-                wname = "conv_wgrad_dma_kernel"
+                if ev is not None:
+                    _PROF.end("conv_wgrad_dma_kernel", 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
             else:
-                check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None, _p(gt),
-                                         _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
-                wname = _wgrad_name(3, 3)
-            if ev is not None:
-                _PROF.end(wname, 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
-            check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
-                  "jaf_channel_sum")
+                # gt is overwritten with the pre-activation gate gradients
+                check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
+                                               None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev)),
+                      "jaf_convlstm_gates_bwd")
+                ev = _PROF.begin() if _PROF is not None else None
+                if ctx.xps is not None and _packed_path(d):
+                    gd = _make_desc(N, G, 4 * C, 1, H, W, H, W, 1, 1, 1, 0, 0, 1, gspec, 1, 0, G, 0, ACT_NONE, 0.0)
+                    gtp = pack_input([gt], gd)
+                    check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
+                                                    1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
+                    wname = "conv_wgrad_dma_kernel"
+                else:
+                    check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None,
+                                             _p(gt), _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
+                    wname = _wgrad_name(3, 3)
+                if ev is not None:
+                    _PROF.end(wname, 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
+                      "jaf_channel_sum")
             if dx is not None:
                 _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                    1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True)
