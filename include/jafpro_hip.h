@@ -133,16 +133,17 @@ int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t 
                        int32_t H, int32_t W, int act, float slope, void* packed, float* dz, float* dbias);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
  * [N][G][4C/8][H*W][8] (order i,f,o,g per group) and their per-channel sums ADDED to dbias[G*4C];
- * `gates` is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0.                                   */
+ * `gates` (fp32 or bf16, as the forward cell wrote them) is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0.                                   */
 int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
-                                  const float* dc_next, const float* gates, const float* c_prev,
+                                  const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                   const float* c_cur, float* dc_prev, void* packed, float* dbias);
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                           const void* packed_in, const void* packed_w, const float* bias, float* out);
 int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                                  const void* packed_in, const void* packed_w, const float* bias,
-                                 const float* c_prev, float* h_out, float* c_out, float* gates_out);
+                                 const float* c_prev, float* h_out, float* c_out, void* gates_out,
+                                 int gates_bf16 /* gates_out is bf16 [N, G*4C, H, W] instead of fp32 */);
 
 /* 3x3 weight gradient from the packed input of the forward conv and the packed dz of the data
  * gradient (csrc/wgrad_dma.hip).  Returns JAF_EUNSUPPORTED for shapes it does not cover (stride-2

@@ -40,6 +40,7 @@ struct ConvDArgs {
     int off_w, off_tab;
     int ntiles, ngroups8;
     float inv_pw, inv_twin;
+    int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
 };
 
 __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
@@ -275,9 +276,9 @@ extern "C" int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* 
 // 16-byte packed item (C % 4 == 0 puts every gate's channel block on a 4-channel boundary).
 // grid (pixel blocks, C/4, N*G), block 256.
 // ---------------------------------------------------------------------------------------------
-template <int V>
+template <int V, typename GT>
 __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, int HW, const float* dh, const float* dc_next,
-                                                                   const float* gates, const float* c_prev, const float* c_cur,
+                                                                   const GT* gates, const float* c_prev, const float* c_cur,
                                                                    float* dc_prev, unsigned char* packed, float* dbias, int iters) {
     typedef float fv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
     const int cb = blockIdx.y * 4;                 // first hidden channel of this lane's block
@@ -296,16 +297,18 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
         for (int j = 0; j < 4; ++j) {
             const int c = cb + j;
             const long e = (ng * C + c) * (long)HW + pix;
-            const float* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
+            const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
             float gi[V], gf[V], go[V], gg[V], cc[V], dhv[V], dcn[V], cp[V];
             if (V == 2) {
-                *(fv*)gi = *(const fv*)gp; *(fv*)gf = *(const fv*)(gp + cs);
-                *(fv*)go = *(const fv*)(gp + 2 * cs); *(fv*)gg = *(const fv*)(gp + 3 * cs);
+                typedef GT gv __attribute__((ext_vector_type(2)));
+                const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
+                gi[0] = (float)ti[0]; gi[1] = (float)ti[1]; gf[0] = (float)tf[0]; gf[1] = (float)tf[1];
+                go[0] = (float)to[0]; go[1] = (float)to[1]; gg[0] = (float)tg[0]; gg[1] = (float)tg[1];
                 *(fv*)cc = *(const fv*)(c_cur + e); *(fv*)dhv = *(const fv*)(dh + e);
                 if (dc_next) *(fv*)dcn = *(const fv*)(dc_next + e);
                 if (c_prev) *(fv*)cp = *(const fv*)(c_prev + e);
             } else {
-                gi[0] = gp[0]; gf[0] = gp[cs]; go[0] = gp[2 * cs]; gg[0] = gp[3 * cs];
+                gi[0] = (float)gp[0]; gf[0] = (float)gp[cs]; go[0] = (float)gp[2 * cs]; gg[0] = (float)gp[3 * cs];
                 cc[0] = c_cur[e]; dhv[0] = dh[e];
                 if (dc_next) dcn[0] = dc_next[e];
                 if (c_prev) cp[0] = c_prev[e];
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
 }
 
 extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
-                                             const float* dc_next, const float* gates, const float* c_prev,
+                                             const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                              const float* c_cur, float* dc_prev, void* packed, float* dbias) {
     JAF_REQUIRE(dh && gates && c_cur && dc_prev && packed && dbias && N >= 1 && G >= 1 && C >= 4 && HW >= 1);
     if (C % 4) return JAF_EUNSUPPORTED;
@@ -371,12 +374,12 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
     int iters = 8;
     while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
     const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 4, N * G);
-    if (v2)
-        hipLaunchKernelGGL(lstm_gates_bwd_pack_kernel<2>, grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, gates, c_prev,
-                           c_cur, dc_prev, (unsigned char*)packed, dbias, iters);
-    else
-        hipLaunchKernelGGL(lstm_gates_bwd_pack_kernel<1>, grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, gates, c_prev,
-                           c_cur, dc_prev, (unsigned char*)packed, dbias, iters);
+#define JAF_LGB(V_, T_)                                                                                         \
+    hipLaunchKernelGGL((lstm_gates_bwd_pack_kernel<V_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
+                       (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters)
+    if (gates_bf16) { if (v2) JAF_LGB(2, __bf16); else JAF_LGB(1, __bf16); }
+    else { if (v2) JAF_LGB(2, float); else JAF_LGB(1, float); }
+#undef JAF_LGB
     return jaf_launch_status();
 }
 
@@ -577,11 +580,19 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
                 a.c_out[hc * OHW + opix[nt]] = cc;
                 a.h_out[hc * OHW + opix[nt]] = go * jaf_tanh(cc);
                 if (a.gates_out) {
-                    float* gp = a.gates_out + gc * OHW + opix[nt];
-                    gp[(long)(ch)*OHW] = gi;
-                    gp[(long)(C + ch) * OHW] = gf;
-                    gp[(long)(2 * C + ch) * OHW] = go;
-                    gp[(long)(3 * C + ch) * OHW] = gg;
+                    if (a.gates_bf16) {
+                        __bf16* gp = (__bf16*)a.gates_out + gc * OHW + opix[nt];
+                        gp[(long)(ch)*OHW] = (__bf16)gi;
+                        gp[(long)(C + ch) * OHW] = (__bf16)gf;
+                        gp[(long)(2 * C + ch) * OHW] = (__bf16)go;
+                        gp[(long)(3 * C + ch) * OHW] = (__bf16)gg;
+                    } else {
+                        float* gp = a.gates_out + gc * OHW + opix[nt];
+                        gp[(long)(ch)*OHW] = gi;
+                        gp[(long)(C + ch) * OHW] = gf;
+                        gp[(long)(2 * C + ch) * OHW] = go;
+                        gp[(long)(3 * C + ch) * OHW] = gg;
+                    }
                 }
             }
         }
@@ -793,6 +804,7 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.c_out = nullptr;
     a.h_out = nullptr;
     a.gates_out = nullptr;
+    a.gates_bf16 = 0;
 }
 
 extern "C" int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
@@ -809,7 +821,8 @@ extern "C" int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, con
 
 extern "C" int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                                             const void* packed_in, const void* packed_w, const float* bias,
-                                            const float* c_prev, float* h_out, float* c_out, float* gates_out) {
+                                            const float* c_prev, float* h_out, float* c_out, void* gates_out,
+                                            int gates_bf16) {
     JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && bias && h_out && c_out);
     JAF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->Cout & 3) == 0);
     JAF_REQUIRE(d->Cout % (16 * plan->MT) == 0 && d->H == d->OH && d->W == d->OW);
@@ -822,6 +835,7 @@ extern "C" int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc*
     a.c_prev = c_prev;
     a.c_out = c_out;
     a.h_out = h_out;
-    a.gates_out = gates_out;
+    a.gates_out = (float*)gates_out;
+    a.gates_bf16 = gates_bf16 ? 1 : 0;
     return cd_launch_mt<true>(a, (hipStream_t)s);
 }

@@ -411,7 +411,10 @@ class _ConvLSTMFn(Function):
         keep = any(ctx.needs_input_grad[:3])
         hs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
         cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
-        gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.float32) if keep else None
+        # on the packed bf16 path the saved gates are bf16 (they are the dominant traffic of the cell epilogue
+        # and of the gate backward, which reads them exactly once)
+        g16 = _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
+        gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.bfloat16 if g16 else torch.float32) if keep else None
         xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
         for t in range(T):
             first = t == 0
@@ -428,7 +431,8 @@ class _ConvLSTMFn(Function):
                     xps.append(xp)
                 check(L.jaf_convlstm_cell_fwd_packed(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
                                                      None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
-                                                     _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd_packed")
+                                                     _p(gates[t]) if keep else None, 1 if g16 else 0),
+                      "jaf_convlstm_cell_fwd_packed")
                 if ev is not None:
                     _PROF.end("conv_dma_kernel<%d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
@@ -464,6 +468,8 @@ class _ConvLSTMFn(Function):
         dw = weight.grad if w_inplace else torch.empty_like(weight)
         # fused path: gate backward writes the packed bf16 gate gradients + the bias sums directly
         fused = ctx.xps is not None and _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
+        if gates.dtype == torch.bfloat16 and not fused:
+            raise RuntimeError("convlstm: precision changed between forward and backward")
         if b_inplace:
             db = bias.grad
         elif fused:
@@ -491,7 +497,7 @@ class _ConvLSTMFn(Function):
             if fused:
                 gtp = torch.empty(N * G * ng8 * H * W * 16, device=x.device, dtype=torch.uint8)
                 check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                                      None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
+                                                      1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
                                                       _p(db)), "jaf_convlstm_gates_bwd_packed")
                 ev = _PROF.begin() if _PROF is not None else None
                 check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
