@@ -39,7 +39,8 @@ struct ConvDArgs {
     jaf_conv_plan p;
     int off_w, off_tab;
     int ntiles, ngroups8;
-    float inv_pw, inv_twin;
+    float inv_pwp, inv_pwq, inv_twin;
+    int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
 };
 
@@ -398,7 +399,15 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     const int q = lane >> 4;
     constexpr int MR = 16 * MT;
     const int NG = P.NG;
-    const int npos = P.npos, plane = P.plane, PW = P.PW;
+    const int npos = P.npos, plane = P.plane, PW = P.PW, PWp = P.PWp;
+    // Pixel interleave: lane li of tile nt owns pixel NT*li + nt of the wave's 16*NT pixels, so a lane's NT
+    // accumulators of one output channel are NT consecutive pixels (one vector store).  The patch rows are
+    // de-interleaved into NT column classes (slot = row*PWp + (x % NT)*PWq + x / NT) so that the 16 lanes
+    // of a tile still read 16 consecutive 16-byte slots; with DMA staging that is only a different
+    // slot -> source mapping.
+    const int lg = a.ilv ? (NT == 4 ? 2 : (NT == 2 ? 1 : 0)) : 0;
+    const int cmask = (1 << lg) - 1;
+    const int PWq = PWp >> lg;
 
     unsigned char* s_patch = smem;
     unsigned char* s_w = smem + a.off_w;
@@ -427,19 +436,22 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     const int OHW = d.OH * d.OW;
     const int HW = d.H * d.W;
 
-    // ---- one-time table: slot -> patch byte offset (full chunk, last chunk) ----
+    // ---- one-time table: (slot, tile nt) -> patch byte offset; [0]: full chunk, [1]: last chunk ----
     {
         const int taps = d.KH * d.KW;
         const float inv_kw = 1.0f / (float)d.KW;
-        for (int e = tid; e < 2 * 4 * P.nsteps; e += 256) {
-            const int which = e >= 4 * P.nsteps;
-            const int s = e - which * 4 * P.nsteps;
+        for (int e = tid; e < 2 * 16 * P.nsteps; e += 256) {
+            const int nt = e & 3;
+            int s = e >> 2;
+            const int which = s >= 4 * P.nsteps;
+            s -= which * 4 * P.nsteps;
             const int ngc = which ? P.ng_last : NG;
             int v = 0;
             if (s < taps * ngc) {
                 const int tap = (int)(((float)s + 0.5f) / (float)ngc), grp = s - tap * ngc;
                 const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - ky * d.KW;
-                v = grp * plane + (ky * PW + kx) * 16;
+                const int xk = (a.ilv ? d.stride * nt : 0) + kx;
+                v = grp * plane + (ky * PWp + (xk & cmask) * PWq + (xk >> lg)) * 16;
             }
             s_tab[e] = v;
         }
@@ -450,11 +462,12 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     int opix[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int p = pbase + (wave * NT + nt) * 16 + li;
+        const int p = a.ilv ? (pbase + wave * 16 * NT + li * NT + nt) : (pbase + (wave * NT + nt) * 16 + li);
         const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
-        const int ox = x0 + (p - oy * P.TWIN);
+        const int oxr = p - oy * P.TWIN;
+        const int ox = x0 + oxr;
         const bool valid = (oy < d.OH) && (ox < d.OW);
-        boff[nt] = valid ? (((oy - oy0) * d.stride * PW + (ox - x0) * d.stride) * 16) : 0;
+        boff[nt] = valid ? (((oy - oy0) * d.stride * PWp + (oxr >> lg) * d.stride) * 16) : 0;
         opix[nt] = valid ? (oy * d.OW + ox) : -1;
     }
 
@@ -467,11 +480,13 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
         const int Wd = (d.W - 1) * dil + 1;
 #pragma unroll
         for (int j = 0; j < CD_RPW; ++j) {
-            const int pos = lane + 64 * (wave + 4 * j);
-            const int r = (int)(((float)pos + 0.5f) * a.inv_pw);
-            const int x = pos - r * PW;
+            const int slot = lane + 64 * (wave + 4 * j);
+            const int r = (int)(((float)slot + 0.5f) * a.inv_pwp);
+            const int rem = slot - r * PWp;
+            const int cls = (int)(((float)rem + 0.5f) * a.inv_pwq);
+            const int x = ((rem - cls * PWq) << lg) + cls;               // patch column held by this slot
             const int iyd = iy0 + r, ixd = ix0 + x;
-            bool ok = (pos < npos) && (iyd >= 0) && (ixd >= 0) && (iyd < Hd) && (ixd < Wd);
+            bool ok = (slot < npos) && (x < PW) && (iyd >= 0) && (ixd >= 0) && (iyd < Hd) && (ixd < Wd);
             int iy = iyd, ix = ixd;
             if (dil == 2) {
                 ok = ok && !((iyd | ixd) & 1);
@@ -525,12 +540,13 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
         __syncthreads();
 
         // ---- MFMA over the chunk's steps ----
-        const int* tab = s_tab + (last ? 4 * P.nsteps : 0);
+        const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
         for (int st = 0; st < nst; ++st) {
-            const int off = tab[4 * st + q];
+            const u32x4 t4 = *(const u32x4*)(tab + 16 * st);
+            const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
             bf16x8 bh[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off + boff[nt]);
+            for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const bf16x8 ah = *(const bf16x8*)(s_w + (st * MT + mt) * 1024 + lane * 16);
@@ -541,23 +557,41 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
         }
     }
 
-    // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel) ----
+    // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel).
+    // With the pixel interleave a lane's NT tiles are NT consecutive pixels: one vector access. ----
+    typedef float fvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
+    typedef __bf16 hvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
+    const bool vec = a.vec && (NT > 1);
     if (!LSTM) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = mb * MR + mt * 16 + q * 4 + j;
-                if (co >= d.Cout) continue;
-                const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;
-                float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (opix[nt] < 0) continue;
-                    op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, d.act, d.slope);
-                }
-            }
+#define CD_EPILOGUE(ACT_)                                                                             \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+                const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
+                if (co < d.Cout) {                                                                    \
+                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
+                    float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;  \
+                    if (vec) {                                                                        \
+                        if (opix[0] >= 0) {                                                           \
+                            fvec o;                                                                   \
+                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                                o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
+                            *(fvec*)(op + opix[0]) = o;                                               \
+                        }                                                                             \
+                    } else {                                                                          \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
+                            if (opix[nt] >= 0) op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope); \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
         }
+        switch (d.act) {     // hoisted: one tight copy of the store loop per activation
+            case JAF_ACT_LRELU: CD_EPILOGUE(JAF_ACT_LRELU) break;
+            case JAF_ACT_RELU: CD_EPILOGUE(JAF_ACT_RELU) break;
+            case JAF_ACT_SIGMOID: CD_EPILOGUE(JAF_ACT_SIGMOID) break;
+            case JAF_ACT_TANH: CD_EPILOGUE(JAF_ACT_TANH) break;
+            default: CD_EPILOGUE(JAF_ACT_NONE) break;
+        }
+#undef CD_EPILOGUE
     } else {
         const int C = d.Cout >> 2;   // hidden channels per group (rows are gate-interleaved: 4c+gate)
 #pragma unroll
@@ -566,32 +600,65 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
             if (ch >= C) continue;
             const float* bp = a.bias + g * d.Cout;
             const float bi = bp[ch], bf = bp[C + ch], bo = bp[2 * C + ch], bg = bp[3 * C + ch];
-            const long hc = ((long)n * d.G + g) * C + ch;
-            const long gc = ((long)n * d.G + g) * d.Cout;
+            const long hc = (((long)n * d.G + g) * C + ch) * OHW;
+            const long gc = ((long)n * d.G + g) * d.Cout * (long)OHW;
+            if (vec) {
+                if (opix[0] < 0) continue;
+                fvec cp, vi, vf, vo, vg, vc, vh;
+                if (a.c_prev) cp = *(const fvec*)(a.c_prev + hc + opix[0]);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (opix[nt] < 0) continue;
-                const float gi = jaf_sigmoid(acc[mt][nt][0] + bi);
-                const float gf = jaf_sigmoid(acc[mt][nt][1] + bf);
-                const float go = jaf_sigmoid(acc[mt][nt][2] + bo);
-                const float gg = jaf_tanh(acc[mt][nt][3] + bg);
-                const float cp = a.c_prev ? a.c_prev[hc * OHW + opix[nt]] : 0.f;
-                const float cc = gf * cp + gi * gg;
-                a.c_out[hc * OHW + opix[nt]] = cc;
-                a.h_out[hc * OHW + opix[nt]] = go * jaf_tanh(cc);
+                for (int nt = 0; nt < NT; ++nt) {
+                    vi[nt] = jaf_sigmoid(acc[mt][nt][0] + bi);
+                    vf[nt] = jaf_sigmoid(acc[mt][nt][1] + bf);
+                    vo[nt] = jaf_sigmoid(acc[mt][nt][2] + bo);
+                    vg[nt] = jaf_tanh(acc[mt][nt][3] + bg);
+                    const float c_old = a.c_prev ? cp[nt] : 0.f;
+                    vc[nt] = vf[nt] * c_old + vi[nt] * vg[nt];
+                    vh[nt] = vo[nt] * jaf_tanh(vc[nt]);
+                }
+                *(fvec*)(a.c_out + hc + opix[0]) = vc;
+                *(fvec*)(a.h_out + hc + opix[0]) = vh;
                 if (a.gates_out) {
                     if (a.gates_bf16) {
-                        __bf16* gp = (__bf16*)a.gates_out + gc * OHW + opix[nt];
-                        gp[(long)(ch)*OHW] = (__bf16)gi;
-                        gp[(long)(C + ch) * OHW] = (__bf16)gf;
-                        gp[(long)(2 * C + ch) * OHW] = (__bf16)go;
-                        gp[(long)(3 * C + ch) * OHW] = (__bf16)gg;
+                        __bf16* gp = (__bf16*)a.gates_out + gc + opix[0];
+                        *(hvec*)(gp + (long)(ch)*OHW) = __builtin_convertvector(vi, hvec);
+                        *(hvec*)(gp + (long)(C + ch) * OHW) = __builtin_convertvector(vf, hvec);
+                        *(hvec*)(gp + (long)(2 * C + ch) * OHW) = __builtin_convertvector(vo, hvec);
+                        *(hvec*)(gp + (long)(3 * C + ch) * OHW) = __builtin_convertvector(vg, hvec);
                     } else {
-                        float* gp = a.gates_out + gc * OHW + opix[nt];
-                        gp[(long)(ch)*OHW] = gi;
-                        gp[(long)(C + ch) * OHW] = gf;
-                        gp[(long)(2 * C + ch) * OHW] = go;
-                        gp[(long)(3 * C + ch) * OHW] = gg;
+                        float* gp = a.gates_out + gc + opix[0];
+                        *(fvec*)(gp + (long)(ch)*OHW) = vi;
+                        *(fvec*)(gp + (long)(C + ch) * OHW) = vf;
+                        *(fvec*)(gp + (long)(2 * C + ch) * OHW) = vo;
+                        *(fvec*)(gp + (long)(3 * C + ch) * OHW) = vg;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (opix[nt] < 0) continue;
+                    const float gi = jaf_sigmoid(acc[mt][nt][0] + bi);
+                    const float gf = jaf_sigmoid(acc[mt][nt][1] + bf);
+                    const float go = jaf_sigmoid(acc[mt][nt][2] + bo);
+                    const float gg = jaf_tanh(acc[mt][nt][3] + bg);
+                    const float cp = a.c_prev ? a.c_prev[hc + opix[nt]] : 0.f;
+                    const float cc = gf * cp + gi * gg;
+                    a.c_out[hc + opix[nt]] = cc;
+                    a.h_out[hc + opix[nt]] = go * jaf_tanh(cc);
+                    if (a.gates_out) {
+                        if (a.gates_bf16) {
+                            __bf16* gp = (__bf16*)a.gates_out + gc + opix[nt];
+                            gp[(long)(ch)*OHW] = (__bf16)gi;
+                            gp[(long)(C + ch) * OHW] = (__bf16)gf;
+                            gp[(long)(2 * C + ch) * OHW] = (__bf16)go;
+                            gp[(long)(3 * C + ch) * OHW] = (__bf16)gg;
+                        } else {
+                            float* gp = a.gates_out + gc + opix[nt];
+                            gp[(long)(ch)*OHW] = gi;
+                            gp[(long)(C + ch) * OHW] = gf;
+                            gp[(long)(2 * C + ch) * OHW] = go;
+                            gp[(long)(3 * C + ch) * OHW] = gg;
+                        }
                     }
                 }
             }
@@ -661,7 +728,9 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
             }
             const int PH = (rows_span - 1) * d->stride + d->KH;
             const int PW = (TW - 1) * d->stride + d->KW;
-            const int npos = PH * PW;
+            const int ilv = (ci < 3 && NT > 1) ? 1 : 0;
+            const int PWp = ilv ? rup_d(PW, NT) : PW;
+            const int npos = PH * PWp;
             if (npos > 64 * 4 * CD_RPW) continue;
             const int plane = rup_d(npos * 16, 1024);
             for (int NG = (groups < ngcap ? groups : ngcap); NG >= 1; --NG) {
@@ -669,7 +738,7 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
                 const int ng_last = groups - (nchunks - 1) * NG;
                 const int nsteps = jaf_cdiv(taps * NG, 4);
                 const int nsteps_last = jaf_cdiv(taps * ng_last, 4);
-                const long lds = (long)NG * plane + (long)nsteps * MT * 1024 + 2L * 4 * nsteps * 4 + 64;
+                const long lds = (long)NG * plane + (long)nsteps * MT * 1024 + 2L * 16 * nsteps * 4 + 64;
                 if (lds > 150 * 1024) continue;
                 const double total_steps = (double)(nchunks - 1) * nsteps + nsteps_last;
                 const double mfma = (double)MT * NT * 16.0;
@@ -708,8 +777,10 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->TWIN = bTW;
     plan->PH = (rows_span - 1) * d->stride + d->KH;
     plan->PW = (bTW - 1) * d->stride + d->KW;
-    plan->PWp = plan->PW;
-    plan->npos = plan->PH * plan->PW;
+    plan->ilv = (!linear && bNT > 1) ? 1 : 0;
+    plan->pf = 0;
+    plan->PWp = plan->ilv ? rup_d(plan->PW, bNT) : plan->PW;
+    plan->npos = plan->PH * plan->PWp;
     plan->plane = rup_d(plan->npos * 16, 1024);
     plan->PS = plan->plane;
     plan->MRp = 16 * MT;
@@ -718,7 +789,7 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->nsteps = jaf_cdiv(taps * bNG, 4);
     plan->nsteps_last = jaf_cdiv(taps * plan->ng_last, 4);
     plan->mblocks = jaf_cdiv(M, 16 * MT);
-    plan->lds_bytes = (int)((long)bNG * plan->plane + (long)plan->nsteps * MT * 1024 + 2L * 4 * plan->nsteps * 4 + 64);
+    plan->lds_bytes = (int)((long)bNG * plan->plane + (long)plan->nsteps * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
     plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * plan->nsteps * MT * 1024) / 4;
     return JAF_OK;
 }
@@ -734,7 +805,10 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     const int taps = d->KH * d->KW;
     if (p->nsteps != jaf_cdiv(taps * p->NG, 4) || p->nsteps_last != jaf_cdiv(taps * p->ng_last, 4)) return false;
     if (p->mblocks != jaf_cdiv(d->Cout, 16 * p->MT)) return false;
-    if (p->npos != p->PH * p->PW || p->npos > 64 * 4 * CD_RPW) return false;
+    if (p->ilv != 0 && p->ilv != 1) return false;
+    if (p->ilv && (p->NT < 2 || (p->TWIN == d->OW && p->tiles_x == 1) || p->PWp % p->NT)) return false;
+    if (p->PWp < p->PW || (!p->ilv && p->PWp != p->PW)) return false;
+    if (p->npos != p->PH * p->PWp || p->npos > 64 * 4 * CD_RPW) return false;
     if (p->plane < ((p->npos + 63) / 64) * 1024 || (p->plane & 1023)) return false;
     if (p->TWIN < 1 || p->tiles_x < 1 || p->tiles_p < 1) return false;
     const int Pn = 64 * p->NT;
@@ -748,7 +822,7 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     }
     if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
     if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
-    if (p->lds_bytes < p->NG * p->plane + p->nsteps * p->MT * 1024 + 2 * 4 * p->nsteps * 4) return false;
+    if (p->lds_bytes < p->NG * p->plane + p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
     if (p->lds_bytes > 160 * 1024) return false;
     if ((long)d->H * d->W * 16 >= CD_OOB) return false;
     return true;
@@ -798,8 +872,11 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.off_tab = a.off_w + plan->nsteps * plan->MT * 1024;
     a.ntiles = plan->tiles_x * plan->tiles_p;
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
-    a.inv_pw = 1.0f / (float)plan->PW;
+    a.inv_pwp = 1.0f / (float)plan->PWp;
+    a.inv_pwq = 1.0f / (float)(plan->ilv ? plan->PWp / plan->NT : plan->PWp);
     a.inv_twin = 1.0f / (float)plan->TWIN;
+    a.ilv = plan->ilv;
+    a.vec = (plan->ilv && d->OW % plan->NT == 0) ? 1 : 0;
     a.c_prev = nullptr;
     a.c_out = nullptr;
     a.h_out = nullptr;
