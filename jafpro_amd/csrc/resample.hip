@@ -6,8 +6,8 @@
 // grid (x blocks, output rows, planes): no lane divides.
 __global__ void avgpool_fwd_kernel(const float* x, float* y, int H, int W, int OH, int OW, int k, int stride, int pad) {
     const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ox >= OW) return;
-    const int oy = blockIdx.y;
+    const int oy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ox >= OW || oy >= OH) return;
     const long nc = blockIdx.z;
     const float inv = 1.0f / (float)(k * k);
     const float* p = x + nc * H * W;
@@ -24,22 +24,27 @@ __global__ void avgpool_fwd_kernel(const float* x, float* y, int H, int W, int O
     y[(nc * OH + oy) * OW + ox] = acc * inv;
 }
 
-static inline int row_threads(int w) { return w >= 192 ? 256 : (w >= 96 ? 128 : 64); }
+// (tx, ty) with tx a power of two >= 8 covering short rows and tx*ty = 256
+static inline dim3 block2d(int w) {
+    int tx = 256;
+    while (tx > 8 && (tx >> 1) >= w) tx >>= 1;
+    return dim3(tx, 256 / tx);
+}
 
 extern "C" int jaf_avgpool_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W,
                                int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad) {
     JAF_REQUIRE(x && y && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
     JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
     JAF_REQUIRE(OH <= 65535 && NC <= 65535);
-    const int t = row_threads(OW);
-    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(jaf_cdiv(OW, t), OH, NC), dim3(t), 0, (hipStream_t)s, x, y, H, W, OH, OW, k, stride, pad);
+    const dim3 b = block2d(OW);
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3(jaf_cdiv(OW, b.x), jaf_cdiv(OH, b.y), NC), b, 0, (hipStream_t)s, x, y, H, W, OH, OW, k, stride, pad);
     return jaf_launch_status();
 }
 
 __global__ void avgpool_bwd_kernel(const float* dy, float* dx, int H, int W, int OH, int OW, int k, int stride, int pad) {
     const int ix = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ix >= W) return;
-    const int iy = blockIdx.y;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix >= W || iy >= H) return;
     const long nc = blockIdx.z;
     const float inv = 1.0f / (float)(k * k);
     const float* p = dy + nc * OH * OW;
@@ -63,8 +68,8 @@ extern "C" int jaf_avgpool_bwd(jaf_stream_t s, const float* dy, float* dx, int32
     JAF_REQUIRE(dy && dx && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
     JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
     JAF_REQUIRE(H <= 65535 && NC <= 65535);
-    const int t = row_threads(W);
-    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(jaf_cdiv(W, t), H, NC), dim3(t), 0, (hipStream_t)s, dy, dx, H, W, OH, OW, k, stride, pad);
+    const dim3 b = block2d(W);
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), NC), b, 0, (hipStream_t)s, dy, dx, H, W, OH, OW, k, stride, pad);
     return jaf_launch_status();
 }
 
@@ -72,6 +77,8 @@ extern "C" int jaf_avgpool_bwd(jaf_stream_t s, const float* dy, float* dx, int32
 // Source-index rules of ATen upsample_bilinear2d / upsample_nearest2d (torch 2.x):
 //   align_corners: src = dst * (in-1)/(out-1);   else: src = max((dst+0.5)*in/out - 0.5, 0)
 //   nearest: src = min(floor(dst * in/out), in-1)
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+
 struct ResizeArgs {
     int N, C, H, W, y0, x0, ch, cw, OH, OW;
     float sy, sx;
@@ -86,27 +93,39 @@ __device__ __forceinline__ void resize_src(int o, float scale, int in, int align
     l = src - (float)i0;
 }
 
-// grid (x blocks, output rows, planes)
+// grid (x blocks, output rows, planes); V consecutive output columns per lane (V = 4: one 16-byte store)
+template <int V>
 __global__ void resize_fwd_kernel(const float* x, float* y, ResizeArgs a) {
-    const int ox = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ox >= a.OW) return;
-    const int oy = blockIdx.y;
+    const int ox = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int oy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ox >= a.OW || oy >= a.OH) return;
     const long nc = blockIdx.z;
     const float* p = x + nc * a.H * a.W;
     float* q = y + (nc * a.OH + oy) * a.OW + ox;
+    float o[V];
     if (a.nearest) {
         int iy = (int)floorf((float)oy * a.sy); if (iy > a.ch - 1) iy = a.ch - 1;
-        int ix = (int)floorf((float)ox * a.sx); if (ix > a.cw - 1) ix = a.cw - 1;
-        *q = p[(a.y0 + iy) * a.W + a.x0 + ix];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            int ix = (int)floorf((float)(ox + k) * a.sx); if (ix > a.cw - 1) ix = a.cw - 1;
+            o[k] = p[(a.y0 + iy) * a.W + a.x0 + ix];
+        }
     } else {
-        int y0, y1, x0, x1; float ly, lx;
+        int y0, y1; float ly;
         resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
-        resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
-        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float hy = 1.f - ly;
         const float* r0 = p + (a.y0 + y0) * a.W + a.x0;
         const float* r1 = p + (a.y0 + y1) * a.W + a.x0;
-        *q = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            int x0, x1; float lx;
+            resize_src(ox + k, a.sx, a.cw, a.align, x0, x1, lx);
+            const float hx = 1.f - lx;
+            o[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+        }
     }
+    if (V == 4) *(f32x4r*)q = *(f32x4r*)o;
+    else q[0] = o[0];
 }
 
 static void resize_scales(ResizeArgs& a) {
@@ -130,8 +149,14 @@ extern "C" int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t 
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, nearest};
     resize_scales(a);
     JAF_REQUIRE(OH <= 65535 && (long)N * C <= 65535);
-    const int t = row_threads(OW);
-    hipLaunchKernelGGL(resize_fwd_kernel, dim3(jaf_cdiv(OW, t), OH, N * C), dim3(t), 0, (hipStream_t)s, x, y, a);
+    // 256-thread workgroups: (columns, rows) -- one-wave workgroups are dispatch-rate bound
+    if (OW % 4 == 0 && (((uintptr_t)y) & 15) == 0) {
+        const dim3 b = block2d(OW / 4);
+        hipLaunchKernelGGL(resize_fwd_kernel<4>, dim3(jaf_cdiv(OW / 4, b.x), jaf_cdiv(OH, b.y), N * C), b, 0, (hipStream_t)s, x, y, a);
+    } else {
+        const dim3 b = block2d(OW);
+        hipLaunchKernelGGL(resize_fwd_kernel<1>, dim3(jaf_cdiv(OW, b.x), jaf_cdiv(OH, b.y), N * C), b, 0, (hipStream_t)s, x, y, a);
+    }
     return jaf_launch_status();
 }
 
@@ -144,19 +169,32 @@ __device__ __forceinline__ void resize_cand(int i, float scale, int out, int ali
     float a, b;
     if (align) { a = ((float)i - 1.f) * inv; b = ((float)i + 1.f) * inv; }
     else { a = ((float)i - 0.5f) * inv - 0.5f; b = ((float)i + 1.5f) * inv - 0.5f; }
-    lo = (int)floorf(a) - 1;
-    hi = (int)ceilf(b) + 1;
+    lo = (int)floorf(a - 0.01f);  // outputs with |src - i| < 1 lie in (a, b); the margin absorbs the rounding of 1/scale
+    hi = (int)ceilf(b + 0.01f);
     if (lo < 0) lo = 0;
     if (hi > out - 1) hi = out - 1;
 }
 
-// grid (x blocks, input rows, planes).  The x candidates and their weights depend only on the
-// lane's column: they are resolved once (at most RB_MAXC non-zero taps) and reused for every row.
+// Adjoint as a gather.  The weight of input i in output o of a bilinear resize is the tent function
+// max(0, 1 - |src(o) - i|) of the (clamped) source coordinate -- plus, without align_corners, the mass
+// that the right/bottom clamp i1 = min(i0 + 1, in - 1) folds onto the last index.  Candidates are the
+// outputs with |src - i| < 1; x weights are resolved once per lane and reused for every row.
+__device__ __forceinline__ float resize_w(int o, int i, float scale, int in, int align) {
+    const float src = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+    // forward rule: i0 = min((int)src, in-1), i1 = min(i0+1, in-1), l = src - i0 (resize_src)
+    int i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    const int i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    const float l = src - (float)i0;
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+}
+
 #define RB_MAXC 8
+// grid (x blocks, input rows, planes)
 __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
     const int gx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gx >= a.W) return;
-    const int gy = blockIdx.y;
+    const int gy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (gx >= a.W || gy >= a.H) return;
     const long nc = blockIdx.z;
     const int ix = gx - a.x0, iy = gy - a.y0;
     float acc = 0.f;
@@ -168,40 +206,27 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
         if (xhi - xlo + 1 <= RB_MAXC) {
             float wx[RB_MAXC];
 #pragma unroll
-            for (int j = 0; j < RB_MAXC; ++j) {
-                const int ox = xlo + j;
-                float w = 0.f;
-                if (ox <= xhi) {
-                    int x0, x1; float lx;
-                    resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
-                    w = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-                }
-                wx[j] = w;
-            }
+            for (int j = 0; j < RB_MAXC; ++j) wx[j] = (xlo + j <= xhi) ? resize_w(xlo + j, ix, a.sx, a.cw, a.align) : 0.f;
             for (int oy = ylo; oy <= yhi; ++oy) {
-                int y0, y1; float ly;
-                resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
-                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                const float wy = resize_w(oy, iy, a.sy, a.ch, a.align);      // row-uniform: scalar work
                 if (wy == 0.f) continue;
                 const float* r = p + oy * a.OW + xlo;
                 float row = 0.f;
 #pragma unroll
-                for (int j = 0; j < RB_MAXC; ++j)
-                    if (wx[j] != 0.f) row += wx[j] * r[j];
+                for (int j = 0; j < RB_MAXC; ++j) {
+                    const int oxc = (xlo + j <= xhi) ? j : 0;              // clamped: the load is always in range,
+                    row += wx[j] * r[oxc];                                 // padding taps carry weight 0
+                }
                 acc += wy * row;
             }
         } else {
             for (int oy = ylo; oy <= yhi; ++oy) {
-                int y0, y1; float ly;
-                resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
-                const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                const float wy = resize_w(oy, iy, a.sy, a.ch, a.align);
                 if (wy == 0.f) continue;
                 float row = 0.f;
                 for (int ox = xlo; ox <= xhi; ++ox) {
-                    int x0, x1; float lx;
-                    resize_src(ox, a.sx, a.cw, a.align, x0, x1, lx);
-                    const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-                    if (wx != 0.f) row += wx * p[oy * a.OW + ox];
+                    const float wxv = resize_w(ox, ix, a.sx, a.cw, a.align);
+                    if (wxv != 0.f) row += wxv * p[oy * a.OW + ox];
                 }
                 acc += wy * row;
             }
@@ -218,8 +243,8 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, 0};
     resize_scales(a);
     JAF_REQUIRE(H <= 65535 && (long)N * C <= 65535);
-    const int t = row_threads(W);
-    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_cdiv(W, t), H, N * C), dim3(t), 0, (hipStream_t)s, dy, dx, a);
+    const dim3 b = block2d(W);
+    hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C), b, 0, (hipStream_t)s, dy, dx, a);
     return jaf_launch_status();
 }
 
