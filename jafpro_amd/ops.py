@@ -55,6 +55,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 _PLAN_CACHE = {}
 _PACK_CACHE = {}
+_PACK_KEYS_BY_ID = {}
 _PROF = None
 _PRECISION = PREC_F32
 # JAF_PREC_BF16 runs on the packed-input (DMA-staged) kernels of csrc/conv_dma.hip; JAF_NO_PACKED=1 keeps
@@ -181,10 +182,12 @@ def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mo
         return hit[1]
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
+        _PACK_KEYS_BY_ID.clear()
     buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
     check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
           "jaf_conv2d_pack")
     _PACK_CACHE[ck] = (weakref.ref(weight), buf)
+    _PACK_KEYS_BY_ID.setdefault(id(weight), []).append(ck)
     return buf
 
 
@@ -950,19 +953,27 @@ def linear(x, w, b, act=ACT_NONE, slope=0.0):
     return _LinearFn.apply(_chk(x, "linear x"), _chk(w, "linear w"), _chk(b, "linear b"), act, float(slope))
 
 
-def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8):
-    """In-place torch.optim.Adam update of a flat parameter buffer."""
+def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, params=None):
+    """In-place torch.optim.Adam update of a flat parameter buffer.  `params`: the parameter tensors that
+    view into it (their packed-weight images are dropped; None drops every cached image)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, "adam " + n)
     check(lib().jaf_adam_step(_s(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step),
           "jaf_adam_step")
-    invalidate_packed_weights()
+    invalidate_packed_weights(params)
 
 
-def invalidate_packed_weights():
+def invalidate_packed_weights(params=None):
     """Weights written behind torch's back (the Adam kernel, RCCL broadcasts) do not bump
-    tensor._version, so the packed-weight cache is dropped explicitly."""
-    _PACK_CACHE.clear()
+    tensor._version, so their packed images are dropped explicitly -- only those of `params` when given
+    (frozen networks such as the background CRN and VGG keep theirs across steps)."""
+    if params is None:
+        _PACK_CACHE.clear()
+        _PACK_KEYS_BY_ID.clear()
+        return
+    for t in params:
+        for ck in _PACK_KEYS_BY_ID.pop(id(t), ()):
+            _PACK_CACHE.pop(ck, None)
 
 
 def axpby(a: float, x, b: float, y):

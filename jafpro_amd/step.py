@@ -55,7 +55,7 @@ class FlatParams:
 
     def adam(self, lr: float):
         self.step_count += 1
-        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count)
+        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params)
 
 
 class Stage4Models(nn.Module):
