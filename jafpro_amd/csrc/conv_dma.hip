@@ -300,11 +300,13 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
             const long e = (ng * C + c) * (long)HW + pix;
             const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
             float gi[V], gf[V], go[V], gg[V], cc[V], dhv[V], dcn[V], cp[V];
-            if (V == 2) {
-                typedef GT gv __attribute__((ext_vector_type(2)));
+            if (V > 1) {
+                typedef GT gv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
                 const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
-                gi[0] = (float)ti[0]; gi[1] = (float)ti[1]; gf[0] = (float)tf[0]; gf[1] = (float)tf[1];
-                go[0] = (float)to[0]; go[1] = (float)to[1]; gg[0] = (float)tg[0]; gg[1] = (float)tg[1];
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    gi[k] = (float)ti[k]; gf[k] = (float)tf[k]; go[k] = (float)to[k]; gg[k] = (float)tg[k];
+                }
                 *(fv*)cc = *(const fv*)(c_cur + e); *(fv*)dhv = *(const fv*)(dh + e);
                 if (dc_next) *(fv*)dcn = *(const fv*)(dc_next + e);
                 if (c_prev) *(fv*)cp = *(const fv*)(c_prev + e);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
                 o[3][j][k] = dc * gi[k] * (1.f - gg[k] * gg[k]);
                 dcp[k] = dc * gf[k];
             }
-            if (V == 2) *(fv*)(dc_prev + e) = *(fv*)dcp;
+            if (V > 1) *(fv*)(dc_prev + e) = *(fv*)dcp;
             else dc_prev[e] = dcp[0];
         }
 #pragma unroll
@@ -368,9 +370,11 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
     JAF_REQUIRE(dh && gates && c_cur && dc_prev && packed && dbias && N >= 1 && G >= 1 && C >= 4 && HW >= 1);
     if (C % 4) return JAF_EUNSUPPORTED;
     JAF_REQUIRE(C / 4 <= 65535 && (long)N * G <= 65535);
-    const bool v2 = (HW % 2 == 0) && ((((uintptr_t)dh) | ((uintptr_t)gates) | ((uintptr_t)c_cur) | ((uintptr_t)dc_prev) |
-                                       ((uintptr_t)dc_next) | ((uintptr_t)c_prev)) & 7) == 0;
-    const int V = v2 ? 2 : 1;
+    const uintptr_t al = ((uintptr_t)dh) | ((uintptr_t)gates) | ((uintptr_t)c_cur) | ((uintptr_t)dc_prev) |
+                         ((uintptr_t)dc_next) | ((uintptr_t)c_prev);
+    const bool v4 = (HW % 4 == 0) && (al & 15) == 0;
+    const bool v2 = (HW % 2 == 0) && (al & 7) == 0;
+    const int V = v4 ? 4 : (v2 ? 2 : 1);
     const int per_block = 256 * V;
     int iters = 8;
     while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
@@ -378,8 +382,8 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 #define JAF_LGB(V_, T_)                                                                                         \
     hipLaunchKernelGGL((lstm_gates_bwd_pack_kernel<V_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
                        (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters)
-    if (gates_bf16) { if (v2) JAF_LGB(2, __bf16); else JAF_LGB(1, __bf16); }
-    else { if (v2) JAF_LGB(2, float); else JAF_LGB(1, float); }
+    if (gates_bf16) { if (v4) JAF_LGB(4, __bf16); else if (v2) JAF_LGB(2, __bf16); else JAF_LGB(1, __bf16); }
+    else { if (v4) JAF_LGB(4, float); else if (v2) JAF_LGB(2, float); else JAF_LGB(1, float); }
 #undef JAF_LGB
     return jaf_launch_status();
 }
@@ -541,8 +545,10 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
 
         // ---- MFMA over the chunk's steps ----
         const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
+        u32x4 tnext = *(const u32x4*)tab;                 // slot-table entry fetched one step ahead
         for (int st = 0; st < nst; ++st) {
-            const u32x4 t4 = *(const u32x4*)(tab + 16 * st);
+            const u32x4 t4 = tnext;
+            tnext = *(const u32x4*)(tab + 16 * (st + 1 < nst ? st + 1 : st));
             const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
             bf16x8 bh[NT];
 #pragma unroll
