@@ -336,7 +336,7 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    long nsplit = (1536 + outblocks - 1) / outblocks;
+    long nsplit = (768 + outblocks - 1) / outblocks;     // each split costs an atomic pass over dW + an epilogue
     if (nsplit > items) nsplit = items;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = (int)nsplit;

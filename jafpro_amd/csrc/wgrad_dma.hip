@@ -14,6 +14,7 @@
 //   unswizzled (position, half) -> global offset (cdna_hip_programming.md rule 21);
 // * out-of-image positions / pixels get an out-of-range buffer offset and arrive as zeros.
 #include "conv_internal.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -303,7 +304,15 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    long nsplit = (1536 + outblocks - 1) / outblocks;
+    static int target = 0;
+    if (!target) { const char* e = getenv("JAF_WD_TARGET"); target = e ? atoi(e) : 768; if (target < 64) target = 768; }
+    // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of
+    // atomic traffic per launch at 1536 workgroups): large gradients get just enough splits to fill the chip
+    const long dwf = (long)d->Cout * d->Cin * KS * KS;
+    static int tbig = 0;
+    if (!tbig) { const char* e = getenv("JAF_WD_TBIG"); tbig = e ? atoi(e) : 768; if (tbig < 64) tbig = 768; }
+    const long tgt = dwf >= 32768 ? tbig : target;
+    long nsplit = (tgt + outblocks - 1) / outblocks;
     if (nsplit > items) nsplit = items;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = (int)nsplit;
