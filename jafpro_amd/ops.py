@@ -81,6 +81,17 @@ def get_precision() -> str:
     return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
 
 
+def _wgrad_dma_name(Cout: int, KS: int) -> str:
+    """Template instantiation jaf_conv2d_wgrad_packed launches (same rule as csrc/wgrad_dma.hip), so that the
+    bench's per-kernel rows carry the names rocprofv3 reports."""
+    mt_best, pad_best = 1, None
+    for mt in ((1,) if KS == 5 else (4, 3, 2, 1)):
+        pad = -(-Cout // (16 * mt)) * 16 * mt
+        if pad_best is None or pad < pad_best:
+            mt_best, pad_best = mt, pad
+    return "conv_wgrad_dma_kernel<%d, %d>" % (mt_best, KS)
+
+
 def _wgrad_name(KH, KW) -> str:
     return "conv_wgrad_bf16_kernel" if (_PRECISION == PREC_BF16 and KH == 3 and KW == 3) else "conv_wgrad_kernel"
 
@@ -321,7 +332,7 @@ class _ConvFn(Function):
                     dzp = pack_input([dz], dzd)
                 check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xp), _p(dzp), _p(dw), 1 if inplace else 0),
                       "jaf_conv2d_wgrad_packed")
-                wname = "conv_wgrad_dma_kernel"
+                wname = _wgrad_dma_name(m.Cout, m.KH)
             else:
                 check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
                       "jaf_conv2d_wgrad")
@@ -506,7 +517,7 @@ class _ConvLSTMFn(Function):
                 check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
                                                 1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
                 if ev is not None:
-                    _PROF.end("conv_wgrad_dma_kernel", 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                    _PROF.end(_wgrad_dma_name(4 * C, 3), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
             else:
                 # gt is overwritten with the pre-activation gate gradients
                 check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
@@ -518,7 +529,7 @@ class _ConvLSTMFn(Function):
                     gtp = pack_input([gt], gd)
                     check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
                                                     1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
-                    wname = "conv_wgrad_dma_kernel"
+                    wname = _wgrad_dma_name(4 * C, 3)
                 else:
                     check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None,
                                              _p(gt), _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
