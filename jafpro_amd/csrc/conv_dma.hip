@@ -702,23 +702,28 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
         long pad = (long)jaf_cdiv(M, 16 * mt) * 16 * mt;
         if (pad < bestPad) { bestPad = pad; bestMT = mt; }
     }
-    int MT = bestMT;
+    int mt_lo = 1, mt_hi = 4;
     if (lstm) {
-        MT = (M % 48 == 0) ? 3 : ((M % 64 == 0) ? 4 : ((M % 32 == 0) ? 2 : 1));
-        JAF_REQUIRE(M % (16 * MT) == 0);
+        mt_lo = mt_hi = (M % 48 == 0) ? 3 : ((M % 64 == 0) ? 4 : ((M % 32 == 0) ? 2 : 1));
+        JAF_REQUIRE(M % (16 * mt_lo) == 0);
     }
+    static int mtfree = -1;
+    if (mtfree < 0) { const char* e = getenv("JAF_CD_MTFREE"); mtfree = e ? atoi(e) : 1; }
+    if (!mtfree && !lstm) mt_lo = mt_hi = bestMT;
     const int groups = jaf_cdiv(d->Cin, 8);
     const long OHW = (long)d->OH * d->OW;
 
     double bestCost = 1e300;
-    int bTW = 0, bNT = 0, bNG = 0;
+    int bTW = 0, bNT = 0, bNG = 0, bMT = 0;
     static int ngcap = 0;
     if (!ngcap) { const char* e = getenv("JAF_CD_NGCAP"); ngcap = e ? atoi(e) : 4; if (ngcap < 1 || ngcap > 4) ngcap = 4; }
     const int cand_tw[4] = {16, 32, 64, d->OW};
+    for (int cMT = mt_hi; cMT >= mt_lo; --cMT)
     for (int ci = 0; ci < 4; ++ci) {
         const int TW = cand_tw[ci];
         if (ci < 3 && TW >= d->OW) continue;
         for (int NT = 4; NT >= 1; NT >>= 1) {
+            const int MT = cMT;
             const int Pn = 64 * NT;
             int rows_span, tiles_x, tiles_p;
             if (ci < 3) {
@@ -756,12 +761,22 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
                 const double overlap = 1.0 / (double)(bl < 1 ? 1 : bl);   // resident workgroups hide each other's staging
                 const double occ_pen = bl >= 3 ? 1.0 : (bl == 2 ? 1.1 : 1.4);
                 const double fixed = 2500.0 + 60.0 * MT * NT;
-                const double cost = (double)tiles_x * tiles_p * (total_steps * t_step * occ_pen + nchunks * (stage * overlap + 250.0) + fixed);
-                if (cost < bestCost) { bestCost = cost; bTW = TW; bNT = NT; bNG = NG; }
+                // whole-launch cost: workgroups / 256 CUs, but never less than one workgroup's own
+                // latency (deep 4x4 .. 16x16 layers launch fewer workgroups than there are CUs, and
+                // then smaller tiles that spread over more CUs win)
+                const double nblocks = (double)tiles_x * tiles_p * jaf_cdiv(M, 16 * MT) * d->N * d->G;
+                const double per_cu = nblocks / 256.0;
+                const int conc = per_cu >= bl ? bl : (per_cu <= 1.0 ? 1 : (int)per_cu);
+                const double ovl = mtfree ? 1.0 / (double)(conc < 1 ? 1 : conc) : overlap;
+                const double per_block = total_steps * t_step * occ_pen + nchunks * (stage * ovl + 250.0) + fixed;
+                const double cost = mtfree ? (per_cu > 1.0 ? per_cu : 1.0) * per_block
+                                           : (double)tiles_x * tiles_p * per_block;
+                if (cost < bestCost) { bestCost = cost; bTW = TW; bNT = NT; bNG = NG; bMT = MT; }
             }
         }
     }
     JAF_REQUIRE(bTW > 0);
+    const int MT = bMT;
     const int Pn = 64 * bNT;
     const bool linear = (bTW == d->OW);
     int rows_span;
