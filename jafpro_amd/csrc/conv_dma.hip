@@ -39,6 +39,7 @@ struct ConvDArgs {
     jaf_conv_plan p;
     int off_w, off_tab;
     int ntiles, ngroups8;
+    int tpb, ntg;      // tiles one workgroup walks (weights of all chunks resident in LDS when > 1); tile groups
     float inv_pwp, inv_pwq, inv_twin;
     int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
@@ -364,6 +365,119 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
     }
 }
 
+// Whole-item variant: a lane owns CB hidden channels x V pixels so that every 16-byte packed item it
+// touches is complete in its own registers (the 4-channel variant above writes 8-byte halves of items
+// whose other half belongs to a different workgroup: partial-line writes, 3.6 TB/s measured).
+//   CB == 8  : C % 8 == 0, channels cb .. cb+7 -> one full item per gate;
+//   CB == 12 : C == 12 (the 200x200 level, the most expensive launch), all 48 gate channels = 6 items.
+// Same arithmetic in the same order as the kernel above: packed image and dc_prev are bit-identical.
+// grid (pixel blocks, C/CB, N*G), block 256.
+template <int V, int CB, typename GT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void lstm_gates_bwd_pack_full_kernel(
+        int G, int C, int HW, const float* __restrict__ dh, const float* __restrict__ dc_next, const GT* __restrict__ gates,
+        const float* __restrict__ c_prev, const float* __restrict__ c_cur, float* __restrict__ dc_prev,
+        unsigned char* __restrict__ packed, float* __restrict__ dbias, int iters) {
+    typedef float fv __attribute__((ext_vector_type(V)));
+    typedef GT gv __attribute__((ext_vector_type(V)));
+    const int cb = blockIdx.y * CB;
+    const long ng = blockIdx.z;
+    const int g = (int)(ng % G);
+    const int ng8 = (4 * C) >> 3;
+    const long cs = (long)C * HW;
+    // bias gradient: every channel pair's 8 per-lane sums are wave-reduced at once and added to LDS by
+    // lane 0 (4*CB running sums per lane would cost 48 registers and the occupancy with them)
+    __shared__ float red[4 * CB];
+    if (threadIdx.x < 4 * CB) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+        const int pix0 = (blockIdx.x * iters + it) * blockDim.x * V;      // workgroup-uniform
+        if (pix0 >= HW) break;
+        const int pix = pix0 + threadIdx.x * V;
+        const bool live = pix < HW;
+        unsigned int wp[4][CB / 2][V];             // [gate][channel pair][pixel] bf16x2
+#pragma unroll
+        for (int j2 = 0; j2 < CB / 2; ++j2) {
+            float o[4][2][V];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int k = 0; k < V; ++k) o[a][h][k] = 0.f;
+                if (live) {
+                    const int c = cb + 2 * j2 + h;
+                    const long e = (ng * C + c) * (long)HW + pix;
+                    const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
+                    const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
+                    const fv cc = *(const fv*)(c_cur + e), dhv = *(const fv*)(dh + e);
+                    fv dcn, cp;
+                    if (dc_next) dcn = *(const fv*)(dc_next + e);
+                    if (c_prev) cp = *(const fv*)(c_prev + e);
+                    fv dcp;
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        const float gi = (float)ti[k], gf = (float)tf[k], go = (float)to[k], gg = (float)tg[k];
+                        const float tc = jaf_tanh(cc[k]);
+                        float dc = dhv[k] * go * (1.f - tc * tc);
+                        if (dc_next) dc += dcn[k];
+                        const float cpv = c_prev ? cp[k] : 0.f;
+                        o[0][h][k] = dc * gg * gi * (1.f - gi);
+                        o[1][h][k] = dc * cpv * gf * (1.f - gf);
+                        o[2][h][k] = dhv[k] * tc * go * (1.f - go);
+                        o[3][h][k] = dc * gi * (1.f - gg * gg);
+                        dcp[k] = dc * gf;
+                    }
+                    *(fv*)(dc_prev + e) = dcp;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    wp[a][j2][k] = cd_pack2(o[a][0][k], o[a][1][k]);
+                    s0 += o[a][0][k];
+                    s1 += o[a][1][k];
+                }
+                s0 = jaf_wave_sum(s0);
+                s1 = jaf_wave_sum(s1);
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(&red[a * CB + 2 * j2], s0);
+                    atomicAdd(&red[a * CB + 2 * j2 + 1], s1);
+                }
+            }
+        }
+        // items: packed channel pc = gate*C + cb + j; the lane's channels of all gates, in ascending pc,
+        // form whole 8-channel items (CB == 8: one per gate; CB == 12 == C: the 48 channels back to back)
+        if (live) {
+            constexpr int NITEM = 4 * CB / 8;
+#pragma unroll
+            for (int i = 0; i < NITEM; ++i) {
+                unsigned char* op;
+                if (CB == 8) op = packed + ((ng * ng8 + ((i * C + cb) >> 3)) * (long)HW + pix) * 16;
+                else op = packed + ((ng * ng8 + i) * (long)HW + pix) * 16;
+#pragma unroll
+                for (int k = 0; k < V; ++k) {
+                    u32x4 w;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int qn = i * 4 + u;      // pair number in ascending pc order
+                        const int gate = (CB == 8) ? i : qn / (CB / 2);
+                        const int pr = (CB == 8) ? u : qn % (CB / 2);
+                        w[u] = wp[gate][pr][k];
+                    }
+                    *(u32x4*)(op + k * 16) = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * CB) {
+        const int gate = threadIdx.x / CB, j = threadIdx.x % CB;
+        atomicAdd(&dbias[g * 4 * C + gate * C + cb + j], red[threadIdx.x]);
+    }
+}
+
 extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
                                              const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                              const float* c_cur, float* dc_prev, void* packed, float* dbias) {
@@ -375,6 +489,23 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
     const bool v4 = (HW % 4 == 0) && (al & 15) == 0;
     const bool v2 = (HW % 2 == 0) && (al & 7) == 0;
     const int V = v4 ? 4 : (v2 ? 2 : 1);
+    static int full = -1;
+    if (full < 0) { const char* e = getenv("JAF_LGB_FULL"); full = e ? atoi(e) : 1; }
+    const int CBF = (C == 12) ? 12 : ((C % 8 == 0) ? 8 : 0);
+    if (CBF && full && v2) {
+        // whole-item kernel, 2 pixels per lane (4 per lane does not fit 128 registers)
+        const int per_block = 256 * 2;
+        int iters = 8;
+        while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
+        const dim3 grid(jaf_cdiv(HW, per_block * iters), C / CBF, N * G);
+#define JAF_LGF(CB_, T_)                                                                                        \
+    hipLaunchKernelGGL((lstm_gates_bwd_pack_full_kernel<2, CB_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
+                       (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters)
+        if (gates_bf16) { if (CBF == 12) JAF_LGF(12, __bf16); else JAF_LGF(8, __bf16); }
+        else { if (CBF == 12) JAF_LGF(12, float); else JAF_LGF(8, float); }
+#undef JAF_LGF
+        return jaf_launch_status();
+    }
     const int per_block = 256 * V;
     int iters = 8;
     while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
@@ -799,7 +930,7 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->PH = (rows_span - 1) * d->stride + d->KH;
     plan->PW = (bTW - 1) * d->stride + d->KW;
     plan->ilv = (!linear && bNT > 1) ? 1 : 0;
-    plan->pf = 0;
+    plan->tpb = 1;
     plan->PWp = plan->ilv ? rup_d(plan->PW, bNT) : plan->PW;
     plan->npos = plan->PH * plan->PWp;
     plan->plane = rup_d(plan->npos * 16, 1024);
@@ -811,6 +942,31 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->nsteps_last = jaf_cdiv(taps * plan->ng_last, 4);
     plan->mblocks = jaf_cdiv(M, 16 * MT);
     plan->lds_bytes = (int)((long)bNG * plan->plane + (long)plan->nsteps * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
+    {
+        // tile walk (conv_dma_kernel): layers whose whole weight image is small keep it resident and let a
+        // workgroup walk several tiles, as long as >= 8 workgroups per CU remain to fill the chip
+        static int tpbcap = -1;
+        if (tpbcap < 0) { const char* e = getenv("JAF_CD_TPB"); tpbcap = e ? atoi(e) : 0; }
+        const long wall = (long)plan->nchunks * plan->nsteps * MT * 1024;
+        const long lds_res = (long)bNG * plan->plane + wall + 2L * 16 * plan->nsteps * 4 + 64;
+        const long ntiles = (long)plan->tiles_x * plan->tiles_p;
+        const long nblocks = ntiles * plan->mblocks * d->N * d->G;
+        long tpb = nblocks / 2048;
+        if (tpb > tpbcap) tpb = tpbcap;
+        if (tpb > ntiles) tpb = ntiles;
+        static long ldscap = -1;
+        if (ldscap < 0) { const char* e = getenv("JAF_CD_TPB_LDS"); ldscap = e ? atol(e) * 1024 : 52 * 1024; }
+        if (tpb >= 2 && lds_res <= ldscap) {
+            // even split: among tpb/2 .. tpb take the walk length that wastes the fewest tile slots
+            long best = tpb, bestw = jaf_cdiv(ntiles, tpb) * tpb - ntiles;
+            for (long t = tpb - 1; t >= 2 && t >= tpb / 2; --t) {
+                const long w = jaf_cdiv(ntiles, t) * t - ntiles;
+                if (w < bestw) { bestw = w; best = t; }
+            }
+            plan->tpb = (int)best;
+            plan->lds_bytes = (int)lds_res;
+        }
+    }
     plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * plan->nsteps * MT * 1024) / 4;
     return JAF_OK;
 }
@@ -843,7 +999,8 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     }
     if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
     if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
-    if (p->lds_bytes < p->NG * p->plane + p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
+    if (p->tpb < 0 || p->tpb > 64) return false;
+    if (p->lds_bytes < p->NG * p->plane + (p->tpb > 1 ? p->nchunks : 1) * p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
     if (p->lds_bytes > 160 * 1024) return false;
     if ((long)d->H * d->W * 16 >= CD_OOB) return false;
     return true;
@@ -890,8 +1047,10 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.d = *d;
     a.p = *plan;
     a.off_w = plan->NG * plan->plane;
-    a.off_tab = a.off_w + plan->nsteps * plan->MT * 1024;
+    a.tpb = plan->tpb > 1 ? plan->tpb : 1;
+    a.off_tab = a.off_w + (a.tpb > 1 ? plan->nchunks : 1) * plan->nsteps * plan->MT * 1024;
     a.ntiles = plan->tiles_x * plan->tiles_p;
+    a.ntg = jaf_cdiv(a.ntiles, a.tpb);
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     a.inv_pwp = 1.0f / (float)plan->PWp;
     a.inv_pwq = 1.0f / (float)(plan->ilv ? plan->PWp / plan->NT : plan->PWp);

@@ -116,25 +116,44 @@ class KernelProfiler:
         ev.record(torch.cuda.current_stream())
         return ev
 
-    def end(self, name, flops, ev0):
+    def end(self, name, flops, ev0, nbytes=0.0):
         ev1 = torch.cuda.Event(enable_timing=True)
         ev1.record(torch.cuda.current_stream())
-        self.records.append((name, float(flops), ev0, ev1))
+        self.records.append((name, float(flops), ev0, ev1, float(nbytes)))
 
     def summary(self):
+        """{kernel: {launches, ms, flops, bytes}}: MFMA kernels carry algorithmic FLOPs, the
+        HBM-bound gather / blend / pack kernels carry algorithmic bytes."""
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1 in self.records:
-            r = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for name, flops, e0, e1, nbytes in self.records:
+            r = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             r["launches"] += 1
             r["ms"] += e0.elapsed_time(e1)
             r["flops"] += flops
+            r["bytes"] += nbytes
         return out
 
 
 def set_profiler(p):
     global _PROF
     _PROF = p
+
+
+class _hbm:
+    """with _hbm(kernel name, algorithmic bytes): <one launch>  -- timed only while a profiler is set."""
+    __slots__ = ("name", "nbytes", "ev")
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        self.ev = _PROF.begin() if _PROF is not None else None
+
+    def __exit__(self, *exc):
+        if self.ev is not None and exc[0] is None:
+            _PROF.end(self.name, 0.0, self.ev, self.nbytes)
+        return False
 
 
 def _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, specs, w_cin_tot,
@@ -180,7 +199,8 @@ def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc) -> torch.Tensor:
         raise RuntimeError("jaf_conv2d_packed_input_bytes: invalid descriptor")
     xp = torch.empty(nbytes, device=srcs[0].device, dtype=torch.uint8)
     ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
-    check(lib().jaf_conv2d_pack_input(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(xp)), "jaf_conv2d_pack_input")
+    with _hbm("conv_pack_input_kernel", 4.0 * d.N * d.G * d.Cin * d.H * d.W + nbytes):
+        check(lib().jaf_conv2d_pack_input(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(xp)), "jaf_conv2d_pack_input")
     return xp
 
 
@@ -291,8 +311,9 @@ class _ConvFn(Function):
                 db_done = True
             ng8 = (m.Cout + 7) // 8
             dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16, device=dy.device, dtype=torch.uint8)
-            check(L.jaf_conv2d_pack_dz(_s(), _p(dy), _p(y) if m.act != ACT_NONE else None, m.N, m.G, m.Cout, m.OH, m.OW,
-                                       m.act, m.slope, _p(dzp), _p(dz), _p(dbt)), "jaf_conv2d_pack_dz")
+            with _hbm("conv_pack_dz_kernel", dy.numel() * (4.0 + (4.0 if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
+                check(L.jaf_conv2d_pack_dz(_s(), _p(dy), _p(y) if m.act != ACT_NONE else None, m.N, m.G, m.Cout, m.OH, m.OW,
+                                           m.act, m.slope, _p(dzp), _p(dz), _p(dbt)), "jaf_conv2d_pack_dz")
         elif m.act != ACT_NONE:
             dz = torch.empty_like(dy)
             check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
@@ -510,9 +531,10 @@ class _ConvLSTMFn(Function):
             gtp = None       # packed gate gradients: shared by the weight gradient and the two data gradients
             if fused:
                 gtp = torch.empty(N * G * ng8 * H * W * 16, device=x.device, dtype=torch.uint8)
-                check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                                      1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
-                                                      _p(db)), "jaf_convlstm_gates_bwd_packed")
+                with _hbm("lstm_gates_bwd_pack_kernel", N * G * C * H * W * (4.0 * (4 if first else 5) + 4.0 * gt.element_size()) + gtp.numel()):
+                    check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
+                                                          1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
+                                                          _p(db)), "jaf_convlstm_gates_bwd_packed")
                 ev = _PROF.begin() if _PROF is not None else None
                 check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
                                                 1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
@@ -726,8 +748,9 @@ class _TextureWarpFn(Function):
         B, C, TH, TW = tex.shape
         S = iuv.shape[1]
         out = torch.empty((B, 3, S, S), device=tex.device, dtype=torch.float32)
-        check(lib().jaf_texture_warp_fwd(_s(), _p(tex), _p(iuv), _p(out), B, S, TH, TW, 1 if align else 0),
-              "jaf_texture_warp_fwd")
+        with _hbm("texture_warp_fwd_kernel", B * S * S * (3.0 + 12.0 + 12.0)):    # IUV bytes + output + >= one texel/px
+            check(lib().jaf_texture_warp_fwd(_s(), _p(tex), _p(iuv), _p(out), B, S, TH, TW, 1 if align else 0),
+                  "jaf_texture_warp_fwd")
         ctx.cfg = (B, S, TH, TW, align)
         ctx.save_for_backward(iuv)
         return out
@@ -738,8 +761,9 @@ class _TextureWarpFn(Function):
         B, S, TH, TW, align = ctx.cfg
         dout = _c(dout)
         dtex = torch.zeros((B, 72, TH, TW), device=dout.device, dtype=torch.float32)
-        check(lib().jaf_texture_warp_bwd(_s(), _p(dout), _p(iuv), _p(dtex), B, S, TH, TW, 1 if align else 0),
-              "jaf_texture_warp_bwd")
+        with _hbm("texture_warp_bwd_kernel", B * S * S * (3.0 + 12.0 + 12.0)):
+            check(lib().jaf_texture_warp_bwd(_s(), _p(dout), _p(iuv), _p(dtex), B, S, TH, TW, 1 if align else 0),
+                  "jaf_texture_warp_bwd")
         return dtex, None, None
 
 
@@ -758,8 +782,9 @@ def grid_sample(src, grid, padding_border: bool, align_corners: bool = False):
     B, C, H, W = src.shape
     OH, OW = grid.shape[1], grid.shape[2]
     out = torch.empty((B, C, OH, OW), device=src.device, dtype=torch.float32)
-    check(lib().jaf_grid_sample_fwd(_s(), _p(src), _p(grid), _p(out), B, C, H, W, OH, OW, 1 if padding_border else 0,
-                                    1 if align_corners else 0), "jaf_grid_sample_fwd")
+    with _hbm("grid_sample_fwd_kernel", 4.0 * B * (C * H * W + 2 * OH * OW + C * OH * OW)):
+        check(lib().jaf_grid_sample_fwd(_s(), _p(src), _p(grid), _p(out), B, C, H, W, OH, OW, 1 if padding_border else 0,
+                                        1 if align_corners else 0), "jaf_grid_sample_fwd")
     return out
 
 
@@ -768,7 +793,8 @@ class _BlendFn(Function):
     def forward(ctx, a, b, m):
         N, C, H, W = a.shape
         out = torch.empty_like(a)
-        check(lib().jaf_blend_fwd(_s(), _p(a), _p(b), _p(m), _p(out), N, C, H * W), "jaf_blend_fwd")
+        with _hbm("blend_fwd_kernel", 4.0 * N * H * W * (3 * C + 1)):
+            check(lib().jaf_blend_fwd(_s(), _p(a), _p(b), _p(m), _p(out), N, C, H * W), "jaf_blend_fwd")
         ctx.save_for_backward(a, b, m)
         return out
 
@@ -780,8 +806,10 @@ class _BlendFn(Function):
         da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
         db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
         dm = torch.empty_like(m) if ctx.needs_input_grad[2] else None
-        check(lib().jaf_blend_bwd(_s(), _p(dout), _p(a), _p(b), _p(m), _p(da), _p(db), _p(dm), N, C, H * W),
-              "jaf_blend_bwd")
+        nout = (C if da is not None else 0) + (C if db is not None else 0) + (1 if dm is not None else 0)
+        with _hbm("blend_bwd_kernel", 4.0 * N * H * W * (3 * C + 1 + nout)):
+            check(lib().jaf_blend_bwd(_s(), _p(dout), _p(a), _p(b), _p(m), _p(da), _p(db), _p(dm), N, C, H * W),
+                  "jaf_blend_bwd")
         return da, db, dm
 
 

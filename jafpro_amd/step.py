@@ -118,8 +118,36 @@ def _used_flags(T_all: int, used, device) -> torch.Tensor:
     return t
 
 
+class PreparedClip:
+    """Everything of a stage-4 batch that depends on the batch alone (no trainable parameter):
+    the frozen background CRN's output and the SMPL projection -> rasterise -> barycentric flow ->
+    flow-warp chain (train/4...py:230-231,319-320,325).  Produced on the side HIP stream by
+    `prepare_clip`, either inside the same step (beside the texture pipeline) or one step ahead
+    (beside the previous clip's loss backward, `Stage4Trainer.train_step(next_batch=...)`)."""
+    __slots__ = ("batch", "prosrc", "src0", "bg_output", "tsf", "event")
+
+
+def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int) -> PreparedClip:
+    main = torch.cuda.current_stream()
+    side = _side_stream(main.device)
+    side.wait_stream(main)          # the batch tensors were produced on the main stream
+    p = PreparedClip()
+    p.batch, p.prosrc = b, prosrc
+    with torch.cuda.stream(side), torch.no_grad():
+        p.src0 = b["src_img"][:, 0].contiguous()
+        bg_mask = 1.0 - b["src_mask_in_image0"]                                 # :230-231 (input prep)
+        bg_incomplete = (bg_mask * p.src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
+        p.bg_output = M.bg_model(bg_incomplete, M.image_size)                   # :319-320
+        prev_img = b["src_img"][:, prosrc].contiguous()
+        p.tsf = M.flow_calculator(prev_img, [b["src_cam"], None, b["src_verts"], None],
+                                  [b["tgt_cam"], None, b["tgt_verts"], None])    # :325
+        p.event = torch.cuda.Event()
+        p.event.record(side)
+    return p
+
+
 def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequence[int], prosrc: int,
-                      align_corners: bool = False) -> Dict[str, torch.Tensor]:
+                      align_corners: bool = False, prepared: Optional[PreparedClip] = None) -> Dict[str, torch.Tensor]:
     """train/4...py:269-331 (== test/conv_pro_test.py:219-279 for one target frame)."""
     B, T_all = b["src_img"].shape[0], b["src_img"].shape[1]
     S = M.image_size
@@ -128,17 +156,9 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     # they run on a side HIP stream beside the texture pipeline (whose deep 13x13 / 25x25 levels
     # launch grids far smaller than the chip) and are joined before the fusion blend.
     main = torch.cuda.current_stream()
-    side = _side_stream(main.device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        src0 = b["src_img"][:, 0].contiguous()
-        bg_mask = 1.0 - b["src_mask_in_image0"]                                 # :230-231 (input prep)
-        bg_incomplete = (bg_mask * src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
-        with torch.no_grad():
-            bg_output = M.bg_model(bg_incomplete, S)                            # :319-320
-        prev_img = b["src_img"][:, prosrc].contiguous()
-        tsf = M.flow_calculator(prev_img, [b["src_cam"], None, b["src_verts"], None],
-                                [b["tgt_cam"], None, b["tgt_verts"], None])      # :325
+    if prepared is None or prepared.batch is not b or prepared.prosrc != prosrc:
+        prepared = prepare_clip(M, b, prosrc)
+    bg_output, tsf = prepared.bg_output, prepared.tsf
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
     x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
     accu = M.Accu_model.forward_grouped(x, len(used))                           # :278
@@ -146,8 +166,8 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     inpaint = M.inpaint_model.forward_grouped(masked)                           # :300
     inpaint_warp = ops.texture_warp(inpaint, b["tgt_IUV255"], align_corners)    # :309-312
     refine_output, fg_mask = M.refine_model(inpaint_warp, S)                    # :318
-    main.wait_stream(side)
-    for t in (bg_output, tsf, src0):
+    main.wait_event(prepared.event)
+    for t in (bg_output, tsf, prepared.src0):
         t.record_stream(main)
     fusion = ops.blend(refine_output, bg_output, fg_mask)                       # :321
     pro = M.propagater({"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
@@ -185,17 +205,23 @@ class Stage4Trainer:
             "D": FlatParams(models.discriminator), "face": FlatParams(models.F_Discriminator),
         }
         self.reducer = reducer          # jafpro_amd.dist.GradReducer or None (single GPU)
+        self._prepared: Optional[PreparedClip] = None
 
     def _reduce(self, names: Sequence[str]):
         if self.reducer is not None:
             self.reducer.all_reduce_mean([self.flat[n].grad for n in names])
 
     def train_step(self, batch: Dict[str, torch.Tensor], used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0,
-                   align_corners: bool = False) -> Dict[str, torch.Tensor]:
+                   align_corners: bool = False, next_batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """One stage-4 iteration.  `next_batch` (already on the device) is the clip of the NEXT call:
+        its parameter-independent preparation (SMPL projection/rasterisation/flow warp, frozen
+        background CRN) is issued on the side HIP stream right before this clip's generator loss
+        backward and is picked up by that next call."""
         M, b = self.M, batch
         for f in self.flat.values():                                             # :206-212
             f.zero_grad()
-        g = generator_forward(M, b, used, prosrc, align_corners)
+        prepared, self._prepared = self._prepared, None
+        g = generator_forward(M, b, used, prosrc, align_corners, prepared)
         final = g["final_output"]
         target = b["tgt_img"].contiguous()
         loss = M.loss_criterion(final, target)                                   # :332
@@ -222,6 +248,8 @@ class Stage4Trainer:
         errG = ops.bce_loss(M.discriminator([final, src0]), 1.0)
         F_errG = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0)
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
+        if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
+            self._prepared = prepare_clip(M, next_batch, prosrc)
         total.backward()
         self._reduce(["flow", "refine", "inpaint", "accu"])                      # reverse graph order
         for n in ("accu", "inpaint", "refine", "flow"):

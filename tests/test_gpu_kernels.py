@@ -488,3 +488,44 @@ def test_rasterizer_small_cases():
         assert (fg.cpu().numpy() == fr).all()
         assert np.abs(wg.cpu().numpy() - wr).max() == 0.0
         assert (fr[0] == -1).all() and (fr[2] == -1).all() and (fr[1] == 2).any() and not (fr[1] == 3).any()
+
+
+@pytest.mark.parametrize("C,H,W,g16,first", [(12, 20, 20, True, False), (12, 10, 14, True, True), (24, 10, 10, True, False),
+                                             (24, 6, 6, False, False), (48, 5, 5, True, False), (12, 5, 5, True, False),
+                                             (4, 6, 6, True, False), (12, 20, 20, False, False)])
+def test_lstm_gates_bwd_packed_direct(C, H, W, g16, first):
+    """jaf_convlstm_gates_bwd_packed (src/convLSTM.py:48-54 adjoint) against the closed form: dc_prev,
+    the packed bf16 pre-activation gate gradients [n][g][4C/8][px][8] and the bias gradient.  Covers the
+    whole-item kernels (C == 12, C % 8 == 0 at even H*W) and the 4-channel fallback (odd H*W, C == 4)."""
+    import ctypes
+    ops = _ops()
+    from jafpro_amd._lib import lib
+    N, G = 2, 3
+    HW = H * W
+    gates = torch.cat([torch.sigmoid(R(1, N, G, 3, C, H, W, lo=-2, hi=2)), torch.tanh(R(2, N, G, 1, C, H, W, lo=-2, hi=2))], 2)
+    if g16:
+        gates = gates.to(torch.bfloat16)
+    gf = gates.float()
+    dh, dcn, cp, cc = (R(s, N, G, C, H, W, lo=-1, hi=1) for s in (3, 4, 5, 6))
+    i, f, o, gg = gf[:, :, 0], gf[:, :, 1], gf[:, :, 2], gf[:, :, 3]
+    tc = torch.tanh(cc)
+    dc = dh * o * (1 - tc * tc) + dcn
+    cpv = torch.zeros_like(cp) if first else cp
+    dgates = torch.stack([dc * gg * i * (1 - i), dc * cpv * f * (1 - f), dh * tc * o * (1 - o), dc * i * (1 - gg * gg)], 2)
+    dcp_ref = dc * f
+    db_ref = dgates.sum((0, 4, 5)).reshape(-1)
+    d = {k: dev(v.contiguous()) for k, v in dict(dh=dh, dcn=dcn, cp=cp, cc=cc).items()}
+    gd = gates.reshape(N, G * 4 * C, H, W).contiguous().cuda()
+    dcp = torch.empty(N, G * C, H, W, device="cuda")
+    ng8 = 4 * C // 8
+    packed = torch.zeros(N * G * ng8 * HW * 8, device="cuda", dtype=torch.bfloat16)
+    db = torch.zeros(G * 4 * C, device="cuda")
+    rc = lib().jaf_convlstm_gates_bwd_packed(ops._s(), N, G, C, HW, ops._p(d["dh"]), ops._p(d["dcn"]), ops._p(gd), 1 if g16 else 0,
+                                            None if first else ops._p(d["cp"]), ops._p(d["cc"]), ops._p(dcp), ops._p(packed), ops._p(db))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert maxerr(dcp.reshape(N, G, C, H, W), dcp_ref) <= 2e-6
+    got = packed.float().cpu().reshape(N, G, ng8, HW, 8).permute(0, 1, 2, 4, 3).reshape(N, G, 4, C, H, W)
+    # bf16 rounding of values up to ~1: half an ulp is 2^-9 relative
+    assert (got - dgates).abs().max().item() <= 2.0 ** -8 * max(1.0, dgates.abs().max().item())
+    assert maxerr(db, db_ref) <= 1e-4 * max(1.0, db_ref.abs().max().item())

@@ -120,3 +120,22 @@ def test_train_step_parity():
     # parameters moved by Adam: every trainable buffer changed, frozen ones did not
     for name in ("accu", "inpaint", "refine", "flow", "D", "face"):
         assert tr.flat[name].step_count == (3 if name == "D" else 1)
+
+
+def test_next_clip_preparation_is_bit_identical():
+    """train_step(next_batch=...) moves the clip's parameter-independent preparation (flow chain + frozen
+    background CRN) one step ahead onto the side stream; the generated frame must not change by a bit."""
+    M, tr, orc, batch, dbatch, mods = build(1)
+    from jafpro_amd.step import generator_forward, prepare_clip
+    with torch.no_grad():
+        a = generator_forward(M, dbatch, (0, 1, 2, 3), 0)
+        p = prepare_clip(M, dbatch, 0)
+        torch.cuda.synchronize()
+        b = generator_forward(M, dbatch, (0, 1, 2, 3), 0, prepared=p)
+    for k in ("bg_output", "tsf_image", "final_output"):
+        assert torch.equal(a[k], b[k]), k
+    out1 = tr.train_step(dbatch, next_batch=dbatch)
+    assert tr._prepared is not None and tr._prepared.batch is dbatch
+    out2 = tr.train_step(dbatch)
+    assert tr._prepared is None
+    assert torch.isfinite(out2["final_output"]).all()
