@@ -10,32 +10,39 @@ per-module messages issued in reverse graph order, discriminator 3.94 MB x 3, fa
 """
 from __future__ import annotations
 
-from typing import Sequence
+from typing import List, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, group=None, bucket_bytes: int = 64 << 20, skip_single: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised")
         self.group = group
         self.world = dist.get_world_size(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
+        self.active = not (skip_single and self.world == 1)   # a 1-rank group still exercises the path in tests
 
-    def all_reduce_mean(self, buffers: Sequence[torch.Tensor]):
-        """In-place mean over ranks of every flat buffer.  Buffers are cut into <= bucket_bytes
-        messages, all issued asynchronously before the first wait so that successive messages
-        pipeline on the xGMI links."""
-        if self.world == 1:
-            return
+    def begin(self, buffers: Sequence[torch.Tensor]) -> List[Tuple[object, torch.Tensor]]:
+        """Issues the sum over ranks of every flat buffer as <= bucket_bytes asynchronous messages
+        (they pipeline on the xGMI links) and returns the handles for `finish`.  On RCCL the messages
+        wait for the work already enqueued on the current stream and then run beside whatever is
+        enqueued next -- e.g. the rest of the backward pass (`BackwardOverlap`)."""
+        if not self.active:
+            return []
         works = []
         for buf in buffers:
             flat = buf.view(-1)
             for off in range(0, flat.numel(), self.bucket_elems):
                 chunk = flat[off:off + self.bucket_elems]
                 works.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
+        return works
+
+    def finish(self, works) -> None:
+        """Waits for the messages of `begin` (the current stream waits, not the host) and turns the
+        sums into means."""
         inv = 1.0 / self.world
         for w, chunk in works:
             w.wait()
@@ -45,12 +52,58 @@ class GradReducer:
             else:
                 chunk.mul_(inv)
 
+    def all_reduce_mean(self, buffers: Sequence[torch.Tensor]):
+        """In-place mean over ranks of every flat buffer, all messages issued before the first wait."""
+        self.finish(self.begin(buffers))
+
     def broadcast(self, buffers: Sequence[torch.Tensor], src: int = 0):
         for buf in buffers:
             dist.broadcast(buf, src=src, group=self.group)
         if any(b.is_cuda for b in buffers):
             from . import ops
             ops.invalidate_packed_weights()
+
+
+class BackwardOverlap:
+    """Starts a module's gradient all-reduce from INSIDE the backward pass.
+
+    `watch(x, name, buffers)`: x is the activation a module received as its input.  The hook on x fires
+    when the gradient w.r.t. x has been produced, i.e. after every backward node between the loss and x
+    has run; every parameter of the stage-4 modules sits on such a path (each convolution consumes an
+    activation derived from the module input, and its weight gradient is written by the same backward
+    node as its data gradient), so the module's flat gradient buffer is final and its messages can
+    travel while the modules further upstream are still being differentiated.  `finish` starts whatever
+    has not fired (modules whose input carries no gradient), waits for everything and takes the means.
+    Message order is the reverse graph order on every rank, so ranks issue identical collective sequences."""
+
+    def __init__(self, reducer: GradReducer):
+        self.red = reducer
+        self.works = []
+        self.fired: List[str] = []
+        self._hooks = []
+
+    def watch(self, x: torch.Tensor, name: str, buffers: Sequence[torch.Tensor]) -> None:
+        if x is None or not x.requires_grad:
+            return
+
+        def hook(_grad, name=name, buffers=buffers):
+            if name not in self.fired:
+                self.fired.append(name)
+                self.works += self.red.begin(buffers)
+            return None
+
+        self._hooks.append(x.register_hook(hook))
+
+    def finish(self, rest: Sequence[Tuple[str, Sequence[torch.Tensor]]]) -> None:
+        for name, buffers in rest:
+            if name not in self.fired:
+                self.fired.append(name)
+                self.works += self.red.begin(buffers)
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.red.finish(self.works)
+        self.works = []
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

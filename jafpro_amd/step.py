@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .dist import BackwardOverlap
 from .cal_flow import float_estimate
 from .crn_model import CRN_smaller
 from .flow_net import Propagation3DFlowNet
@@ -174,7 +175,7 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
                         "tgt_smpl_mask": b["smpl_real_mask"], "tgt_IUV": b["tgt_IUV"], "use_IUV": True})
     return {"final_output": pro["pred_target"], "final_mask": pro["weight"], "fusion_output": fusion,
             "refine_output": refine_output, "fg_mask": fg_mask, "bg_output": bg_output, "tsf_image": tsf,
-            "inpaint_warp": inpaint_warp, "inpaint": inpaint, "accu": accu}
+            "inpaint_warp": inpaint_warp, "inpaint": inpaint, "accu": accu, "masked": masked}
 
 
 def face_crops(final, tgt_img, tgt_IUV, bbox: np.ndarray):
@@ -250,8 +251,18 @@ class Stage4Trainer:
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
         if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
             self._prepared = prepare_clip(M, next_batch, prosrc)
-        total.backward()
-        self._reduce(["flow", "refine", "inpaint", "accu"])                      # reverse graph order
+        if self.reducer is not None and self.reducer.active:
+            # each module's gradient messages leave as soon as the backward pass has passed the module's
+            # input (reverse graph order), beside the differentiation of the modules upstream of it
+            ov = BackwardOverlap(self.reducer)
+            ov.watch(g["fusion_output"], "flow", [self.flat["flow"].grad])
+            ov.watch(g["inpaint_warp"], "refine", [self.flat["refine"].grad])
+            ov.watch(g["masked"], "inpaint", [self.flat["inpaint"].grad])
+            total.backward()
+            ov.finish([(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")])
+            self.overlap_order = list(ov.fired)
+        else:
+            total.backward()
         for n in ("accu", "inpaint", "refine", "flow"):
             self.flat[n].adam(self.lrs[n])
         return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),

@@ -55,3 +55,63 @@ def test_two_rank_gradient_mean():
     for a, b, x, y in zip(k0, k1, r0, r1):
         assert torch.allclose(x, (a + b) / 2, atol=1e-6) and torch.equal(x, y)
     assert torch.equal(p0, torch.zeros(10)) and torch.equal(p1, torch.zeros(10))
+
+
+def _flat_grads(mod):
+    """FlatParams in miniature (jafpro_amd/step.py): every p.grad is a view of one flat buffer."""
+    ps = [p for p in mod.parameters()]
+    flat = torch.zeros(sum(p.numel() for p in ps))
+    off = 0
+    for p in ps:
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        off += p.numel()
+    return flat
+
+
+def _overlap_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from jafpro_amd.dist import BackwardOverlap, GradReducer
+    torch.manual_seed(7)                                  # identical weights on both ranks
+    m1, m2, m3 = (torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3, padding=1), torch.nn.Tanh(), torch.nn.Conv2d(4, 4, 3, padding=1))
+                  for _ in range(3))
+    flats = {n: _flat_grads(m) for n, m in (("m1", m1), ("m2", m2), ("m3", m3))}
+    x = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(50 + rank))      # rank-local shard
+    red = GradReducer(bucket_bytes=256)
+    a = m1(x)                       # the input of m1 carries no gradient: m1 is reduced by finish()
+    b = m2(a)
+    c = m3(b)
+    ov = BackwardOverlap(red)
+    ov.watch(x, "m1", [flats["m1"]])
+    ov.watch(a, "m2", [flats["m2"]])
+    ov.watch(b, "m3", [flats["m3"]])
+    c.square().mean().backward()
+    fired_in_backward = list(ov.fired)
+    local = {n: f.clone() for n, f in flats.items()}      # reads race with in-flight messages only for m2/m3 ...
+    ov.finish([("m3", [flats["m3"]]), ("m2", [flats["m2"]]), ("m1", [flats["m1"]])])
+    # ... so the reference mean is recomputed from scratch without overlap
+    for m in (m1, m2, m3):
+        for p in m.parameters():
+            p.grad = None
+    m3(m2(m1(x))).square().mean().backward()
+    ref = {n: torch.cat([p.grad.reshape(-1) for p in m.parameters()]) for n, m in (("m1", m1), ("m2", m2), ("m3", m3))}
+    for n in ref:
+        red.all_reduce_mean([ref[n]])
+    out[rank] = (fired_in_backward, list(ov.fired), {n: f.clone() for n, f in flats.items()}, ref)
+    dist.destroy_process_group()
+
+
+def test_backward_overlap_matches_sequential_reduce():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        in_bwd, fired, got, ref = out[r]
+        assert in_bwd == ["m3", "m2"]                   # reverse graph order, from inside backward()
+        assert fired == ["m3", "m2", "m1"]
+        for n in ref:
+            assert torch.allclose(got[n], ref[n], atol=1e-6), n
+    for n in out[0][2]:
+        assert torch.equal(out[0][2][n], out[1][2][n])

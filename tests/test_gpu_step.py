@@ -139,3 +139,31 @@ def test_next_clip_preparation_is_bit_identical():
     out2 = tr.train_step(dbatch)
     assert tr._prepared is None
     assert torch.isfinite(out2["final_output"]).all()
+
+
+def test_train_step_with_gradient_overlap_on_one_rank_group():
+    """The N>1 code path (RCCL messages started from inside the backward pass, jafpro_amd/dist.py
+    BackwardOverlap) on a 1-rank RCCL group: same losses and parameters as the plain step, and the
+    four generator modules fire in reverse graph order."""
+    import os, socket
+    import torch.distributed as dist
+    from jafpro_amd.dist import GradReducer
+    from jafpro_amd.step import Stage4Trainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        M, tr, orc, batch, dbatch, mods = build(1)
+        out_a = tr.train_step(dbatch)
+        ga = {n: f.grad.clone() for n, f in tr.flat.items()}
+        M2, _, _, _, _, _ = build(1)
+        tr2 = Stage4Trainer(M2, reducer=GradReducer(bucket_bytes=8 << 20, skip_single=False))
+        out_b = tr2.train_step(dbatch)
+        assert tr2.overlap_order == ["flow", "refine", "inpaint", "accu"]
+        for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
+            a, b = float(out_a[k].reshape(-1)[0]), float(out_b[k].reshape(-1)[0])
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (k, a, b)
+        for n, f in tr2.flat.items():          # gradients left in the flat buffers (wgrad atomics reorder sums)
+            assert rel_l2(f.grad, ga[n]) <= 1e-4, (n, rel_l2(f.grad, ga[n]))
+    finally:
+        dist.destroy_process_group()
