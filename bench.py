@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each clip inside its own step instead of one step ahead")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run the side-stream work on the main stream: per-kernel durations free of stream overlap "
+                         "(the rocprofv3 summaries under profiles/ are taken with this flag; the roofline step always uses it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,9 +103,10 @@ def main():
         from jafpro_amd.dist import GradReducer
         reducer = GradReducer()
 
-    from jafpro_amd import ops, synth
+    from jafpro_amd import ops, synth, step as step_mod
     from jafpro_amd.step import Stage4Trainer, _to_dev
     ops.set_precision(args.precision)
+    step_mod.SERIAL_STREAMS = bool(args.serial_streams)
     _, fidx = synth.body_mesh()
     M, mods = build_models(fidx)
     M = M.cuda()
@@ -150,10 +154,17 @@ def main():
     }
 
     if rank == 0 and not args.no_roofline:
+        # one extra step with every kernel on ONE stream: a kernel that shares the chip with side-stream work
+        # runs longer than it does alone, and the roofline wants the kernel's own duration
+        torch.cuda.synchronize()
+        step_mod.SERIAL_STREAMS = True
+        trainer.train_step(batch, next_batch=nb)          # consumes the clip prepared on the side stream
         prof = ops.KernelProfiler()
         ops.set_profiler(prof)
         trainer.train_step(batch, next_batch=nb)
         ops.set_profiler(None)
+        torch.cuda.synchronize()
+        step_mod.SERIAL_STREAMS = bool(args.serial_streams)
         allk = prof.summary()
         summ = {k: v for k, v in allk.items() if v["flops"] > 0}
         hbm = {k: v for k, v in allk.items() if v["bytes"] > 0}
@@ -164,9 +175,19 @@ def main():
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["flops"] for v in summ.values())
         peak = MFMA_PEAK_TFLOPS[args.precision]
+        # HBM bytes per launch of the dominant kernel: not measurable inside this process (PMC counters need
+        # their own rocprofv3 passes), so it is the committed figure of scratch/pmc_traffic.sh for that kernel
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+                pt = json.load(f)
+            if pt.get("kernel") == name and args.precision == "bf16":
+                traffic, traffic_src = pt["hbm_bytes_per_launch"], pt["source"]
+        except (OSError, ValueError, KeyError):
+            pass
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-            "frac": achieved / peak, "traffic": None,
+            "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
             "kernel": name, "launches_per_step": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
             "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
             "all_mfma_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,

@@ -93,7 +93,7 @@ typedef struct jaf_conv_plan {
     int32_t plane;              /* bytes of one (split, group) patch plane, multiple of 256 */
     int32_t PWp_slots_unused;   /* reserved */
     int32_t ilv;                /* packed path: a lane's NT tiles are NT consecutive pixels (vector epilogue) */
-    int32_t tpb;                /* packed path: output tiles one workgroup walks (weights resident in LDS when > 1) */
+    int32_t pf;                 /* reserved */
 } jaf_conv_plan;
 
 enum { JAF_PACK_FWD = 0, JAF_PACK_DGRAD = 1, JAF_PACK_LSTM = 2 };

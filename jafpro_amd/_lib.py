@@ -69,7 +69,7 @@ class ConvPlan(ctypes.Structure):
         ("lds_bytes", ctypes.c_int32), ("packed_floats", ctypes.c_int64),
         ("precision", ctypes.c_int32), ("NG", ctypes.c_int32), ("ng_last", ctypes.c_int32),
         ("nsteps", ctypes.c_int32), ("nsteps_last", ctypes.c_int32), ("npos", ctypes.c_int32),
-        ("plane", ctypes.c_int32), ("PWp_slots_unused", ctypes.c_int32), ("ilv", ctypes.c_int32), ("tpb", ctypes.c_int32),
+        ("plane", ctypes.c_int32), ("PWp_slots_unused", ctypes.c_int32), ("ilv", ctypes.c_int32), ("pf", ctypes.c_int32),
     ]
 
 

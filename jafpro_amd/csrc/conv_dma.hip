@@ -39,7 +39,6 @@ struct ConvDArgs {
     jaf_conv_plan p;
     int off_w, off_tab;
     int ntiles, ngroups8;
-    int tpb, ntg;      // tiles one workgroup walks (weights of all chunks resident in LDS when > 1); tile groups
     float inv_pwp, inv_pwq, inv_twin;
     int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
@@ -520,38 +519,11 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// epilogue shared by the one-tile and the tile-walk kernels
+// epilogue
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, bool LSTM>
-__device__ __forceinline__ void cd_load_bias(const ConvDArgs& a, int g, int mb, int q, float (&bz)[MT][4]) {
-    const jaf_conv_desc& d = a.d;
-    constexpr int MR = 16 * MT;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        if (!LSTM) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = mb * MR + mt * 16 + q * 4 + j;
-                bz[mt][j] = (a.bias && co < d.Cout) ? a.bias[g * d.Cout + co] : 0.f;
-            }
-        } else {
-            const int C = d.Cout >> 2;
-            const int ch = ((mb * MR + mt * 16) >> 2) + q;
-            const float* bp = a.bias + g * d.Cout;
-            const bool ok = ch < C;
-            bz[mt][0] = ok ? bp[ch] : 0.f;
-            bz[mt][1] = ok ? bp[C + ch] : 0.f;
-            bz[mt][2] = ok ? bp[2 * C + ch] : 0.f;
-            bz[mt][3] = ok ? bp[3 * C + ch] : 0.f;
-        }
-    }
-}
-
-// PRE: the bias values are already in registers (tile-walk kernel: loaded once per workgroup); otherwise they
-// are loaded where they are used, which keeps the one-tile kernels at their register count.
-template <int MT, int NT, bool LSTM, bool PRE>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
-                                            const float (&bz)[MT][4], int n, int g, int mb, int q, int OHW) {
+                                            int n, int g, int mb, int q, int OHW) {
     const jaf_conv_desc& d = a.d;
     constexpr int MR = 16 * MT;
     // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel).
@@ -565,7 +537,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
                 if (co < d.Cout) {                                                                    \
-                    const float b = PRE ? bz[mt][j] : (a.bias ? a.bias[g * d.Cout + co] : 0.f);       \
+                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
                     float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;  \
                     if (vec) {                                                                        \
                         if (opix[0] >= 0) {                                                           \
@@ -596,8 +568,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             const int ch = ((mb * MR + mt * 16) >> 2) + q;
             if (ch >= C) continue;
             const float* bp = a.bias + g * d.Cout;
-            const float bi = PRE ? bz[mt][0] : bp[ch], bf = PRE ? bz[mt][1] : bp[C + ch];
-            const float bo = PRE ? bz[mt][2] : bp[2 * C + ch], bg = PRE ? bz[mt][3] : bp[3 * C + ch];
+            const float bi = bp[ch], bf = bp[C + ch], bo = bp[2 * C + ch], bg = bp[3 * C + ch];
             const long hc = (((long)n * d.G + g) * C + ch) * OHW;
             const long gc = ((long)n * d.G + g) * d.Cout * (long)OHW;
             if (vec) {
@@ -840,210 +811,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     }
 
     // ---- epilogue ----
-    const float bz[MT][4] = {};
-    cd_epilogue<MT, NT, LSTM, false>(a, acc, opix, bz, n, g, mb, q, OHW);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Tile-walk kernel for layers whose whole packed weight image fits LDS beside two patch buffers (the
-// 24-part texture networks: 6..48 output channels, 1..2 chunks).  A one-tile workgroup of such a layer
-// spends most of its life in the prologue, the weight DMA and waiting for its patch (PMC: 38 % issue
-// activity per wave), so here a workgroup keeps the weights resident and walks `tpb` consecutive tiles:
-//   * wave 4 is the PRODUCER: it DMAs the weights once, then the patch of stage s+1 (stage = tile x chunk)
-//     into the other patch buffer while waves 0..3 consume stage s.  It alone waits on vmcnt, so the
-//     consumers' output stores never sit in front of a DMA in the in-order vmcnt queue;
-//   * waves 0..3 are the CONSUMERS: slot table once, bias once, then per stage one barrier, the MFMA
-//     loop, and after the last chunk of a tile the epilogue (stores are fire-and-forget).
-// One s_barrier per stage, executed by all five waves: the producer leaves barrier R(s) and fills
-// buffer (s+1)&1, which the consumers last read in stage s-1, i.e. before they arrived at R(s).
-// ---------------------------------------------------------------------------------------------
-template <int MT, int NT, bool LSTM>
-__global__ __launch_bounds__(320) void conv_walk_kernel(const ConvDArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const jaf_conv_desc& d = a.d;
-    const jaf_conv_plan& P = a.p;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int MR = 16 * MT;
-    const int NG = P.NG;
-    const int npos = P.npos, plane = P.plane, PW = P.PW, PWp = P.PWp;
-    const int lg = a.ilv ? (NT == 4 ? 2 : (NT == 2 ? 1 : 0)) : 0;
-    const int cmask = (1 << lg) - 1;
-    const int PWq = PWp >> lg;
-    const int pbytes = NG * plane;                       // one patch buffer; two of them at smem + 0 / pbytes
-    unsigned char* s_w = smem + a.off_w;
-    int* s_tab = (int*)(smem + a.off_tab);
-
-    int L;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x;
-        const int xcd = bid & 7, j = bid >> 3, qn = nblk >> 3, rn = nblk & 7;
-        L = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
-    }
-    const int mb = L % P.mblocks;
-    L /= P.mblocks;
-    const int tg = L % a.ntg;
-    const int ngi = L / a.ntg;
-    const int n = ngi / d.G;
-    const int g = ngi - n * d.G;
-    const int t_first = tg * a.tpb;
-    const int ntl = (a.ntiles - t_first) < a.tpb ? (a.ntiles - t_first) : a.tpb;     // >= 1 by construction
-    const int nchunks = P.nchunks;
-    const int nstages = ntl * nchunks;
-    const int OHW = d.OH * d.OW;
-    const int HW = d.H * d.W;
-    const int wchunk_bytes = P.nsteps * MT * 1024;
-
-    if (wave == 4) {
-        // ------------------------------- producer -------------------------------
-        const unsigned char* wbase = a.wpk + ((long)(g * P.mblocks + mb) * nchunks) * (long)wchunk_bytes;
-        for (int e = 0; e < nchunks * P.nsteps * MT; ++e)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + e * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
-        const unsigned char* xbase = a.xp + (((long)n * d.G + g) * a.ngroups8) * (long)HW * 16;
-        const int plane_bytes = HW * 16;
-        const int nrounds = (npos + 63) >> 6;
-        const int dil = d.dil_in;
-        const int Hd = (d.H - 1) * dil + 1;
-        const int Wd = (d.W - 1) * dil + 1;
-        // slot -> (patch row, patch column) of this lane's 4*CD_RPW rounds: tile independent
-        int srow[4 * CD_RPW], scol[4 * CD_RPW];
-#pragma unroll
-        for (int r = 0; r < 4 * CD_RPW; ++r) {
-            const int slot = lane + 64 * r;
-            const int rr = (int)(((float)slot + 0.5f) * a.inv_pwp);
-            const int rem = slot - rr * PWp;
-            const int cls = (int)(((float)rem + 0.5f) * a.inv_pwq);
-            const int x = ((rem - cls * PWq) << lg) + cls;
-            const bool ok = (slot < npos) && (x < PW);
-            srow[r] = ok ? rr : (1 << 20);               // far outside any image: fails the range test below
-            scol[r] = x;
-        }
-        int dv[4 * CD_RPW];
-        int tl = 0, chunk = 0;                           // (tile, chunk) of the stage being issued
-        for (int s = -1; s < nstages; ++s) {
-            if (s >= 0) {
-                __builtin_amdgcn_s_waitcnt(0);           // stage s (and, first time, the weights) landed
-                __builtin_amdgcn_s_barrier();            // R(s)
-            }
-            if (s + 1 < nstages) {
-                if (chunk == 0) {
-                    const int tile = t_first + tl;
-                    const int tx = tile % P.tiles_x;
-                    const int tb = tile / P.tiles_x;
-                    const int oy0 = (tb * (64 * NT)) / P.TWIN;
-                    const int iy0 = oy0 * d.stride - d.pad_t;
-                    const int ix0 = tx * P.TWIN * d.stride - d.pad_l;
-#pragma unroll
-                    for (int r = 0; r < 4 * CD_RPW; ++r) {
-                        const int iyd = iy0 + srow[r], ixd = ix0 + scol[r];
-                        bool ok = (iyd >= 0) && (ixd >= 0) && (iyd < Hd) && (ixd < Wd);
-                        int iy = iyd, ix = ixd;
-                        if (dil == 2) {
-                            ok = ok && !((iyd | ixd) & 1);
-                            iy = iyd >> 1;
-                            ix = ixd >> 1;
-                        }
-                        dv[r] = ok ? ((iy * d.W + ix) * 16) : CD_OOB;
-                    }
-                }
-                const bool last = (chunk == nchunks - 1);
-                const int ngc = last ? P.ng_last : NG;
-                unsigned char* dst = smem + ((s + 1) & 1) * pbytes;
-                const unsigned char* cbase = xbase + (long)(chunk * NG) * plane_bytes;
-                for (int grp = 0; grp < ngc; ++grp) {
-                    const __amdgpu_buffer_rsrc_t rs =
-                        __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)grp * plane_bytes), 0, plane_bytes, 0x00020000);
-#pragma unroll
-                    for (int r = 0; r < 4 * CD_RPW; ++r)
-                        if (r < nrounds)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + grp * plane + r * 1024),
-                                                                     16, dv[r], 0, 0, 0);
-                }
-                if (++chunk == nchunks) { chunk = 0; ++tl; }
-            }
-        }
-        return;
-    }
-
-    // --------------------------------- consumers ---------------------------------
-    const int li = lane & 15;
-    const int q = lane >> 4;
-    {
-        const int taps = d.KH * d.KW;
-        const float inv_kw = 1.0f / (float)d.KW;
-        for (int e = tid; e < 2 * 16 * P.nsteps; e += 256) {
-            const int nt = e & 3;
-            int sl = e >> 2;
-            const int which = sl >= 4 * P.nsteps;
-            sl -= which * 4 * P.nsteps;
-            const int ngc = which ? P.ng_last : NG;
-            int v = 0;
-            if (sl < taps * ngc) {
-                const int tap = (int)(((float)sl + 0.5f) / (float)ngc), grp = sl - tap * ngc;
-                const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - ky * d.KW;
-                const int xk = (a.ilv ? d.stride * nt : 0) + kx;
-                v = grp * plane + (ky * PWp + (xk & cmask) * PWq + (xk >> lg)) * 16;
-            }
-            s_tab[e] = v;
-        }
-    }
-    float bz[MT][4];
-    cd_load_bias<MT, NT, LSTM>(a, g, mb, q, bz);
-
-    int s = 0;
-    for (int tl = 0; tl < ntl; ++tl) {
-        const int tile = t_first + tl;
-        const int tx = tile % P.tiles_x;
-        const int tb = tile / P.tiles_x;
-        const int x0 = tx * P.TWIN;
-        const int pbase = tb * (64 * NT);
-        const int oy0 = pbase / P.TWIN;
-        int boff[NT];
-        int opix[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int p = a.ilv ? (pbase + wave * 16 * NT + li * NT + nt) : (pbase + (wave * NT + nt) * 16 + li);
-            const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
-            const int oxr = p - oy * P.TWIN;
-            const int ox = x0 + oxr;
-            const bool valid = (oy < d.OH) && (ox < d.OW);
-            boff[nt] = valid ? (((oy - oy0) * d.stride * PWp + (oxr >> lg) * d.stride) * 16) : 0;
-            opix[nt] = valid ? (oy * d.OW + ox) : -1;
-        }
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        for (int chunk = 0; chunk < nchunks; ++chunk, ++s) {
-            const bool last = (chunk == nchunks - 1);
-            const int nst = last ? P.nsteps_last : P.nsteps;
-            __syncthreads();                             // R(s): lgkmcnt(0) (slot table) + s_barrier
-            const unsigned char* s_patch = smem + (s & 1) * pbytes;
-            const unsigned char* s_wc = s_w + chunk * wchunk_bytes;
-            const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
-            u32x4 tnext = *(const u32x4*)tab;
-            for (int st = 0; st < nst; ++st) {
-                const u32x4 t4 = tnext;
-                tnext = *(const u32x4*)(tab + 16 * (st + 1 < nst ? st + 1 : st));
-                const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
-                bf16x8 bh[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 ah = *(const bf16x8*)(s_wc + (st * MT + mt) * 1024 + lane * 16);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
-                }
-            }
-        }
-        cd_epilogue<MT, NT, LSTM, true>(a, acc, opix, bz, n, g, mb, q, OHW);
-    }
+    cd_epilogue<MT, NT, LSTM>(a, acc, opix, n, g, mb, q, OHW);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1173,7 +941,7 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->PH = (rows_span - 1) * d->stride + d->KH;
     plan->PW = (bTW - 1) * d->stride + d->KW;
     plan->ilv = (!linear && bNT > 1) ? 1 : 0;
-    plan->tpb = 1;
+    plan->pf = 0;
     plan->PWp = plan->ilv ? rup_d(plan->PW, bNT) : plan->PW;
     plan->npos = plan->PH * plan->PWp;
     plan->plane = rup_d(plan->npos * 16, 1024);
@@ -1185,33 +953,6 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->nsteps_last = jaf_cdiv(taps * plan->ng_last, 4);
     plan->mblocks = jaf_cdiv(M, 16 * MT);
     plan->lds_bytes = (int)((long)bNG * plan->plane + (long)plan->nsteps * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
-    {
-        // tile walk (conv_dma_kernel): layers whose whole weight image is small keep it resident and let a
-        // workgroup walk several tiles, as long as >= 8 workgroups per CU remain to fill the chip
-        static int tpbcap = -1;
-        if (tpbcap < 0) { const char* e = getenv("JAF_CD_TPB"); tpbcap = e ? atoi(e) : 0; }
-        const long wall = (long)plan->nchunks * plan->nsteps * MT * 1024;
-        const long lds_walk = 2L * bNG * plan->plane + wall + 2L * 16 * plan->nsteps * 4 + 64;   // two patch buffers
-        const long ntiles = (long)plan->tiles_x * plan->tiles_p;
-        const long nblocks = ntiles * plan->mblocks * d->N * d->G;
-        static long minblk = -1;     // workgroups that must remain after the walk (>= 8 per CU); tests lower it
-        if (minblk < 0) { const char* e = getenv("JAF_CD_TPB_MINBLK"); minblk = e ? atol(e) : 2048; if (minblk < 1) minblk = 1; }
-        long tpb = nblocks / minblk;
-        if (tpb > tpbcap) tpb = tpbcap;
-        if (tpb > ntiles) tpb = ntiles;
-        static long ldscap = -1;
-        if (ldscap < 0) { const char* e = getenv("JAF_CD_TPB_LDS"); ldscap = e ? atol(e) * 1024 : 64 * 1024; }
-        if (tpb >= 2 && bNT == 4 && lds_walk <= ldscap) {
-            // even split: among tpb/2 .. tpb take the walk length that wastes the fewest tile slots
-            long best = tpb, bestw = jaf_cdiv(ntiles, tpb) * tpb - ntiles;
-            for (long t = tpb - 1; t >= 2 && t >= tpb / 2; --t) {
-                const long w = jaf_cdiv(ntiles, t) * t - ntiles;
-                if (w < bestw) { bestw = w; best = t; }
-            }
-            plan->tpb = (int)best;
-            plan->lds_bytes = (int)lds_walk;
-        }
-    }
     plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * plan->nsteps * MT * 1024) / 4;
     return JAF_OK;
 }
@@ -1244,9 +985,7 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     }
     if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
     if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
-    if (p->tpb < 0 || p->tpb > 64) return false;
-    if (p->tpb > 1 && p->NT != 4) return false;
-    if (p->lds_bytes < (p->tpb > 1 ? 2 : 1) * p->NG * p->plane + (p->tpb > 1 ? p->nchunks : 1) * p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
+    if (p->lds_bytes < p->NG * p->plane + p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
     if (p->lds_bytes > 160 * 1024) return false;
     if ((long)d->H * d->W * 16 >= CD_OOB) return false;
     return true;
@@ -1269,24 +1008,7 @@ static int cd_launch_one(const ConvDArgs& a, hipStream_t s) {
 }
 
 template <int MT, bool LSTM>
-static int cd_launch_walk(const ConvDArgs& a, hipStream_t s) {
-    auto k = conv_walk_kernel<MT, 4, LSTM>;
-    static int attr_set = 0;
-    const int lds = a.p.lds_bytes;
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = 1;
-    }
-    const long nblk = (long)a.ntg * a.p.mblocks * a.d.N * a.d.G;
-    if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
-    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(320), (size_t)lds, s, a);
-    return jaf_launch_status();
-}
-
-template <int MT, bool LSTM>
 static int cd_launch_nt(const ConvDArgs& a, hipStream_t s) {
-    if (a.tpb > 1) return cd_launch_walk<MT, LSTM>(a, s);
     switch (a.p.NT) {
         case 1: return cd_launch_one<MT, 1, LSTM>(a, s);
         case 2: return cd_launch_one<MT, 2, LSTM>(a, s);
@@ -1309,11 +1031,9 @@ static int cd_launch_mt(const ConvDArgs& a, hipStream_t s) {
 static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* plan) {
     a.d = *d;
     a.p = *plan;
-    a.off_w = (plan->tpb > 1 ? 2 : 1) * plan->NG * plan->plane;
-    a.tpb = plan->tpb > 1 ? plan->tpb : 1;
-    a.off_tab = a.off_w + (a.tpb > 1 ? plan->nchunks : 1) * plan->nsteps * plan->MT * 1024;
+    a.off_w = plan->NG * plan->plane;
+    a.off_tab = a.off_w + plan->nsteps * plan->MT * 1024;
     a.ntiles = plan->tiles_x * plan->tiles_p;
-    a.ntg = jaf_cdiv(a.ntiles, a.tpb);
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     a.inv_pwp = 1.0f / (float)plan->PWp;
     a.inv_pwq = 1.0f / (float)(plan->ilv ? plan->PWp / plan->NT : plan->PWp);

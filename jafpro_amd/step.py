@@ -98,7 +98,12 @@ _FLAG_CACHE = {}
 _SIDE_STREAMS = {}
 
 
+SERIAL_STREAMS = False      # profiling aid: run the side-stream work on the main stream (clean per-kernel times)
+
+
 def _side_stream(device) -> "torch.cuda.Stream":
+    if SERIAL_STREAMS:
+        return torch.cuda.current_stream()
     k = str(device)
     st = _SIDE_STREAMS.get(k)
     if st is None:
