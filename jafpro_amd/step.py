@@ -81,7 +81,7 @@ class Stage4Models(nn.Module):
             p.requires_grad = False
 
 
-_HOST_KEYS = ("face_bbox",)      # host integers (src/data.py:702-716): reading them must not sync the device
+_HOST_KEYS = ("face_bbox", "chosen_frame")      # host integers (src/data.py:702-716): reading them must not sync the device
 
 
 def _to_dev(batch: Dict[str, np.ndarray], device) -> Dict[str, torch.Tensor]:
@@ -278,11 +278,13 @@ class Stage4Trainer:
 @torch.no_grad()
 def forward_clip(M: Stage4Models, clip: Dict[str, torch.Tensor], used: Sequence[int] = (0, 1, 2, 3),
                  align_corners: bool = False) -> torch.Tensor:
-    """Forward-only clip loop, test/conv_pro_test.py:219-279: accumulate + inpaint + background
-    once per clip, then per target frame warp -> refine -> blend -> flow -> propagate.
-    clip tensors: src_* as in a stage-4 batch with B clips; per-frame tensors carry an extra
-    frame axis: tgt_IUV255 [B,F,S,S,3], tgt_IUV [B,F,3,S,S], smpl_real_mask [B,F,3,S,S],
-    tgt_verts [B,F,NV,3], tgt_cam [B,F,3].  The propagater stays in train mode.
+    """Forward-only clip loop, test/conv_pro_test.py:219-279 (BASELINE config 2): accumulate + inpaint +
+    background once per clip, then per target frame warp -> refine -> blend -> flow -> propagate.
+    clip tensors: src_* as in a stage-4 batch with B clips; per-frame tensors carry a frame axis:
+    tgt_IUV255 [B,F,S,S,3], tgt_IUV [B,F,3,S,S], smpl_real_mask [B,F,3,S,S], tgt_verts [B,F,NV,3],
+    tgt_cam [B,F,3]; `chosen_frame` [T] host integers = clip positions of the reference frames: frame i
+    is propagated from the reference nearest in time, whose SMPL pose is the clip's own pose at that
+    position (:256-262, pro_index clipped as there).  The propagater stays in train mode.
     Returns pred_target [B,F,3,S,S]."""
     S = M.image_size
     B, T_all = clip["src_img"].shape[0], clip["src_img"].shape[1]
@@ -295,13 +297,17 @@ def forward_clip(M: Stage4Models, clip: Dict[str, torch.Tensor], used: Sequence[
     bg_mask = 1.0 - clip["src_mask_in_image0"]
     bg_output = M.bg_model((bg_mask * src0 + (1.0 - bg_mask) * clip["bg_noise"]).contiguous(), S)
     Fn = clip["tgt_IUV255"].shape[1]
+    chosen = np.asarray(clip["chosen_frame"]).reshape(-1).astype(np.int64)
     outs = []
     for f in range(Fn):
+        src_pro = int(np.argmin(np.abs(f - chosen)))                            # :257-258
+        pro_index = int(np.clip(chosen[src_pro], 0, min(30, Fn - 1)))           # :268
+        prev_img = clip["src_img"][:, src_pro].contiguous()
         warp = ops.texture_warp(inpaint, clip["tgt_IUV255"][:, f].contiguous(), align_corners)
         refine_output, fg_mask = M.refine_model(warp, S)
         fusion = ops.blend(refine_output, bg_output, fg_mask)
-        # nearest chosen reference by frame distance is host logic (:256-258); source = ref 0 here
-        tsf = M.flow_calculator(src0, [clip["src_cam"], None, clip["src_verts"], None],
+        tsf = M.flow_calculator(prev_img, [clip["tgt_cam"][:, pro_index].contiguous(), None,
+                                           clip["tgt_verts"][:, pro_index].contiguous(), None],
                                 [clip["tgt_cam"][:, f].contiguous(), None, clip["tgt_verts"][:, f].contiguous(), None])
         pro = M.propagater({"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
                             "tgt_smpl_mask": clip["smpl_real_mask"][:, f].contiguous(),

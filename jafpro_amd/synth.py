@@ -173,3 +173,23 @@ def stage4_batch(seed: int, B: int, T: int = 4, S: int = 256) -> Dict[str, np.nd
     d["src_cam"] = cam.copy()
     d["face_bbox"] = np.tile(np.array([[96, 160, 32, 96]], np.int64), (B, 1))   # x0, x1, y0, y1
     return d
+
+
+def stage4_clip(seed: int, B: int, F: int, T: int = 4, S: int = 256) -> Dict[str, np.ndarray]:
+    """B synthetic clips of F target frames for the forward-only loop (test/conv_pro_test.py:219-279,
+    BASELINE config 2): the reference tensors of `stage4_batch` plus per-frame targets
+    (tgt_IUV255 [B,F,S,S,3], tgt_IUV / smpl_real_mask [B,F,3,S,S], tgt_verts [B,F,NV,3], tgt_cam [B,F,3])
+    and `chosen_frame` [T]: the clip positions of the T reference frames (host integers, :256-262)."""
+    d = stage4_batch(seed, B, T, S)
+    for k in ("tgt_img", "tgt_IUV255", "tgt_IUV", "smpl_real_mask", "tgt_verts", "tgt_cam", "face_bbox"):
+        d.pop(k)
+    iuv = np.stack([iuv255(seed, "clip_iuv_f%d" % f, B, S) for f in range(F)], 1)
+    d["tgt_IUV255"] = iuv
+    d["tgt_IUV"] = ((iuv.astype(np.float32) / 255.0 - 0.5) * 2.0).transpose(0, 1, 4, 2, 3).copy()
+    d["smpl_real_mask"] = np.repeat((iuv[..., 0] > 0).astype(np.float32)[:, :, None], 3, 2)
+    d["tgt_verts"] = np.stack([posed_vertices(seed, "clip_verts_f%d" % f, B) for f in range(F)], 1)
+    cam = np.zeros((B, F, 3), np.float32); cam[..., 0] = 0.9
+    d["tgt_cam"] = cam
+    d["chosen_frame"] = np.array([(t * max(F - 1, 1)) // max(T - 1, 1) for t in range(T)], np.int64)
+    return d
+

@@ -77,6 +77,42 @@ class OracleStage4:
                 "refine_output": refine_output, "fg_mask": fg_mask, "bg_output": bg_output, "tsf_image": tsf,
                 "inpaint_warp": warp, "inpaint": torch.cat(inpaint, 1), "accu": torch.cat(accu, 1)}
 
+    # test/conv_pro_test.py:219-279 (BASELINE config 2): texture pipeline and background once per clip, then per
+    # target frame warp -> refine -> blend -> flow from the reference nearest in time -> propagate (train-mode BN)
+    @torch.no_grad()
+    def forward_clip(self, c: Dict[str, torch.Tensor], used=(0, 1, 2, 3), align_corners=False):
+        B = c["src_img"].shape[0]
+        used = list(used)
+        x_in = []
+        for i in range(4):
+            for j in range(6):
+                x_in.append([c["src_texture_im"][:, t, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200] for t in used])
+        accu = O.accumulate_forward(self.sd["accu"], x_in)
+        masked = O.mask_parts(accu, O.common_area_mask(c["src_mask_im"], used))
+        inpaint = O.inpaint_forward(self.sd["inpaint"], masked)
+        src0 = c["src_img"][:, 0]
+        bg_mask = 1 - c["src_mask_in_image0"]
+        bg_output = O.crn_smaller_forward(self.sd["bg"], bg_mask * src0 + (1 - bg_mask) * c["bg_noise"], 256, False)
+        Fn = c["tgt_IUV255"].shape[1]
+        chosen = np.asarray(c["chosen_frame"]).reshape(-1)
+        outs = []
+        for f in range(Fn):
+            src_pro = int(np.argmin(np.abs(f - chosen)))
+            pro_index = int(np.clip(chosen[src_pro], 0, min(30, Fn - 1)))
+            iuv = c["tgt_IUV255"][:, f].numpy()
+            warp = torch.stack([O.texture_warp([t[i] for t in inpaint], iuv[i], align_corners) for i in range(B)])
+            refine_output, fg_mask = O.crn_smaller_forward(self.sd["refine"], warp, 256, True)
+            fusion = refine_output * fg_mask.repeat(1, 3, 1, 1) + bg_output * (1 - fg_mask.repeat(1, 3, 1, 1))
+            fs = O.project_faces(c["tgt_verts"][:, pro_index], c["tgt_cam"][:, pro_index], self.faces_idx)
+            ft = O.project_faces(c["tgt_verts"][:, f], c["tgt_cam"][:, f], self.faces_idx)
+            fim, wim = raster_oracle.rasterize_fim_wim(ft.numpy(), 256)
+            tsf, _ = O.flow_warp(c["src_img"][:, src_pro], fs, torch.from_numpy(fim), torch.from_numpy(wim), align_corners)
+            pro = O.propagation_forward(self.sd["flow"], {"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
+                                                          "tgt_smpl_mask": c["smpl_real_mask"][:, f], "tgt_IUV": c["tgt_IUV"][:, f],
+                                                          "use_IUV": True}, True)
+            outs.append(pro["pred_target"])
+        return torch.stack(outs, 1)
+
     def train_step(self, b: Dict[str, torch.Tensor], used=(0, 1, 2, 3), prosrc=0, align_corners=False):
         for o in self.opt.values():
             o.zero_grad(set_to_none=False)
