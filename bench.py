@@ -62,6 +62,38 @@ def cpu_baseline(mods, fidx):
                       "brute-force C rasteriser single-threaded, torch ops on %d threads" % (nsteps, dt, torch.get_num_threads())}
 
 
+def measure_ceilings():
+    """Sustained dense bf16 MFMA rate and streaming-copy HBM rate of THIS GPU (include/jafpro_hip.h, ubench)."""
+    import ctypes
+    from jafpro_amd import ops
+    from jafpro_amd._lib import lib
+    L = lib()
+    sink = torch.zeros(4, device="cuda")
+    blocks, iters = 256 * 8, 4096
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ops.check(L.jaf_ubench_mfma_bf16(ops._s(), blocks, 64, ops._p(sink)), "jaf_ubench_mfma_bf16")
+    e0.record()
+    ops.check(L.jaf_ubench_mfma_bf16(ops._s(), blocks, iters, ops._p(sink)), "jaf_ubench_mfma_bf16")
+    e1.record()
+    torch.cuda.synchronize()
+    tf = blocks * 4 * iters * 8 * 16384.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    n16 = (1 << 30) // 16
+    src = torch.empty(1 << 30, device="cuda", dtype=torch.uint8)
+    dst = torch.empty(1 << 30, device="cuda", dtype=torch.uint8)
+    src.zero_()
+    ops.check(L.jaf_ubench_copy(ops._s(), ops._p(src), ops._p(dst), n16), "jaf_ubench_copy")
+    e0.record()
+    for _ in range(5):
+        ops.check(L.jaf_ubench_copy(ops._s(), ops._p(src), ops._p(dst), n16), "jaf_ubench_copy")
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 5 * 2.0 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return {"mfma_bf16_tflops": tf, "hbm_copy_GBps": gbps,
+            "how": "jaf_ubench_mfma_bf16: 2048 workgroups x 4 waves x 32768 register-fed v_mfma_f32_16x16x32_bf16 (the chip "
+                   "lowers its clock under matrix-core load: MI355X_MICROARCH.md, DVFS); "
+                   "jaf_ubench_copy: 1 GiB read + 1 GiB written, 16 B per lane x 4 in flight, 5 passes"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,12 +126,19 @@ def main():
         _M, _mods = build_models(_fidx)
         cpu_result = cpu_baseline(_mods, _fidx)
         del _M, _mods
-    torch.cuda.set_device(local_rank)
+    # JAF_BENCH_BACKEND=gloo with JAF_BENCH_SHARE_GPU=1 lets several ranks share one GPU: the way the N>1 control
+    # flow of this file is exercised on a 1-GPU box (RCCL refuses two ranks on one device); never a measurement.
+    backend = os.environ.get("JAF_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if os.environ.get("JAF_BENCH_SHARE_GPU") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
     import torch.distributed as dist
     reducer = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
         from jafpro_amd.dist import GradReducer
         reducer = GradReducer()
 
@@ -158,6 +197,7 @@ def main():
         # runs longer than it does alone, and the roofline wants the kernel's own duration
         torch.cuda.synchronize()
         step_mod.SERIAL_STREAMS = True
+        trainer.reducer = None      # rank-0-only steps: no collective may be issued here (the other ranks wait below)
         trainer.train_step(batch, next_batch=nb)          # consumes the clip prepared on the side stream
         prof = ops.KernelProfiler()
         ops.set_profiler(prof)
@@ -185,11 +225,15 @@ def main():
                 traffic, traffic_src = pt["hbm_bytes_per_launch"], pt["source"]
         except (OSError, ValueError, KeyError):
             pass
+        ceil = measure_ceilings() if args.precision != "f32" else None
         result["roofline"] = {
             "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
             "frac": achieved / peak, "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
             "kernel": name, "launches_per_step": r["launches"], "avg_launch_ms": r["ms"] / r["launches"],
             "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
+            # this box's own ceilings (register-fed MFMA loop, 16 B/lane copy) next to the nominal peaks
+            "measured_ceilings": ceil,
+            "frac_of_measured_mfma": (achieved / (ceil["mfma_bf16_tflops"] / (3.0 if args.precision == "bf16x3" else 1.0))) if ceil else None,
             "all_mfma_kernels": {"ms_per_step": tot_ms, "tflops": tot_fl / (tot_ms * 1e-3) / 1e12,
                                  "share_of_step": tot_ms / ms_per_step},
             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
@@ -219,6 +263,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        dist.barrier()              # ranks > 0 wait here while rank 0 takes its roofline step
         dist.destroy_process_group()
 
 

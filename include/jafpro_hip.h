@@ -328,6 +328,16 @@ int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m, float* v, 
 /* y = a*x + b*y elementwise (gradient accumulation, scaling). */
 int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float* y, int64_t n);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measured ceilings of the box ("confirm on the box"), used only by bench.py to report
+ * roofline fractions against what this GPU delivers next to the nominal peaks.
+ * ------------------------------------------------------------------------------------------ */
+/* `blocks` workgroups of 4 waves, each wave issues iters*8 independent v_mfma_f32_16x16x32_bf16
+ * (16384 FLOP each) from registers: the sustained dense bf16 matrix-core rate at the sustained clock. */
+int jaf_ubench_mfma_bf16(jaf_stream_t s, int32_t blocks, int32_t iters, float* sink);
+/* dst[i] = src[i], 16 bytes per lane, grid-stride: the streaming-copy HBM rate (n16 = 16-byte items). */
+int jaf_ubench_copy(jaf_stream_t s, const void* src, void* dst, int64_t n16);
+
 #ifdef __cplusplus
 }
 #endif

@@ -191,3 +191,27 @@ def test_forward_clip_parity():
     err = (out.cpu() - ref).abs().max().item()
     print("forward_clip B=2 F=3: max|diff| = %.3e, %.1f ms (fp32, %.1f frames/s)" % (err, dt * 1e3, 6 / dt))
     assert err <= 1e-3
+
+
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """bench.py launched exactly as the driver launches it for N=2 (torch.distributed.run, one process per
+    rank), with both ranks sharing this box's single GPU over gloo (RCCL refuses two ranks on one device):
+    barriers, gradient exchange from inside backward, rank-0-only roofline step and the final barrier must
+    neither hang nor print more than ONE JSON line.  The number it prints is not a measurement."""
+    import json, os, socket, subprocess, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JAF_BENCH_BACKEND="gloo", JAF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "2", "--warmup", "1"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["scaling"] == "weak"
+    assert j["roofline"]["kernel"].startswith("conv_dma_kernel") and "cpu_baseline" not in j
+    assert np.isfinite(j["config"]["loss"])
