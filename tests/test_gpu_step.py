@@ -215,3 +215,31 @@ def test_bench_two_ranks_control_flow_on_one_gpu():
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 16 and j["scaling"] == "weak"
     assert j["roofline"]["kernel"].startswith("conv_dma_kernel") and "cpu_baseline" not in j
     assert np.isfinite(j["config"]["loss"])
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_full_size_batch_independence(mode):
+    """BASELINE configs[2] size (B=8): everything upstream of the train-mode BatchNorm of the propagater is
+    independent across samples, so sample i of the B=8 forward must equal the B=1 forward of sample i
+    (the CPU oracle cannot run B=8 in test time; this property needs no oracle).  f32: equal up to the
+    summation order of the tile plan chosen for the batch size (1e-5).  bf16: a different plan flips bf16
+    roundings of the next layer's operands, so agreement is at the bf16 mode's own noise level (the 1e-1 L-inf / 1.5e-2 rel-L2 bars of the mode)."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.step import generator_forward, _to_dev
+    M, tr, orc, _, _, _ = build(1)
+    full = synth.stage4_batch(310, 8)
+    prev = ops.set_precision(mode)
+    try:
+        with torch.no_grad():
+            g8 = generator_forward(M, _to_dev(full, "cuda"), (0, 1, 2, 3), 0)
+            for i in (0, 5):
+                one = {k: v[i:i + 1] for k, v in full.items()}
+                g1 = generator_forward(M, _to_dev(one, "cuda"), (0, 1, 2, 3), 0)
+                for k in ("accu", "inpaint", "refine_output", "fg_mask", "bg_output", "fusion_output", "tsf_image"):
+                    err = (g8[k][i:i + 1] - g1[k]).abs().max().item()
+                    assert err <= (1e-5 if mode == "f32" else 1e-1), (mode, i, k, err)
+                    if mode == "bf16":
+                        assert rel_l2(g8[k][i:i + 1], g1[k]) <= 1.5e-2, (mode, i, k)
+    finally:
+        ops.set_precision(prev)
+    assert torch.isfinite(g8["final_output"]).all()
