@@ -406,10 +406,12 @@ class VGGLoss_CRN(nn.Module):
         self.vgg = VGG19_CRN()
         self.weights = list(weights)
 
-    def forward(self, x, y):
+    def forward(self, x, y, y_vgg=None):
+        """y_vgg: features of y computed earlier by the same (frozen) network, e.g. on a side stream."""
         x_vgg = self.vgg(x)
-        with torch.no_grad():
-            y_vgg = self.vgg(y)
+        if y_vgg is None:
+            with torch.no_grad():
+                y_vgg = self.vgg(y)
         loss = None
         for i in range(len(x_vgg)):
             term = ops.l1_loss(x_vgg[i], y_vgg[i], self.weights[i])
@@ -422,10 +424,20 @@ class VGG_l1_loss(nn.Module):
         super().__init__()
         self.vgg_loss = VGGLoss_CRN(weights=[1 / 2.6, 1 / 4.8, 1 / 3.7, 1 / 5.6, 10 / 1.5])
 
-    def forward(self, x, y):
-        xp = vgg_preprocess(x.contiguous())
+    @torch.no_grad()
+    def target_features(self, y):
+        """Everything of the loss that depends on the target alone (the network is frozen): the preprocessed
+        target and its five feature maps.  Pass the result as `forward(x, y, target=...)`."""
         yp = vgg_preprocess(y.contiguous())
-        loss = self.vgg_loss(xp, yp) + ops.l1_loss(xp, yp, 1.0)
+        return yp, self.vgg_loss.vgg(yp)
+
+    def forward(self, x, y, target=None):
+        xp = vgg_preprocess(x.contiguous())
+        if target is None:
+            yp, y_vgg = vgg_preprocess(y.contiguous()), None
+        else:
+            yp, y_vgg = target
+        loss = self.vgg_loss(xp, yp, y_vgg) + ops.l1_loss(xp, yp, 1.0)
         return loss.squeeze(0)
 
 

@@ -126,14 +126,15 @@ def _used_flags(T_all: int, used, device) -> torch.Tensor:
 
 class PreparedClip:
     """Everything of a stage-4 batch that depends on the batch alone (no trainable parameter):
-    the frozen background CRN's output and the SMPL projection -> rasterise -> barycentric flow ->
-    flow-warp chain (train/4...py:230-231,319-320,325).  Produced on the side HIP stream by
+    the frozen background CRN's output, the SMPL projection -> rasterise -> barycentric flow ->
+    flow-warp chain (train/4...py:230-231,319-320,325) and, for a train step, the frozen VGG's features
+    of the target frame (src/networks.py:118-125).  Produced on the side HIP stream by
     `prepare_clip`, either inside the same step (beside the texture pipeline) or one step ahead
     (beside the previous clip's loss backward, `Stage4Trainer.train_step(next_batch=...)`)."""
-    __slots__ = ("batch", "prosrc", "src0", "bg_output", "tsf", "event")
+    __slots__ = ("batch", "prosrc", "src0", "bg_output", "tsf", "event", "vgg_target", "vgg_event")
 
 
-def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int) -> PreparedClip:
+def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int, with_loss_target: bool = False) -> PreparedClip:
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     side.wait_stream(main)          # the batch tensors were produced on the main stream
@@ -149,11 +150,17 @@ def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int) -> Pr
                                   [b["tgt_cam"], None, b["tgt_verts"], None])    # :325
         p.event = torch.cuda.Event()
         p.event.record(side)
+        p.vgg_target, p.vgg_event = None, None
+        if with_loss_target and "tgt_img" in b:
+            p.vgg_target = M.loss_criterion.target_features(b["tgt_img"])
+            p.vgg_event = torch.cuda.Event()
+            p.vgg_event.record(side)
     return p
 
 
 def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequence[int], prosrc: int,
-                      align_corners: bool = False, prepared: Optional[PreparedClip] = None) -> Dict[str, torch.Tensor]:
+                      align_corners: bool = False, prepared: Optional[PreparedClip] = None,
+                      with_loss_target: bool = False) -> Dict[str, torch.Tensor]:
     """train/4...py:269-331 (== test/conv_pro_test.py:219-279 for one target frame)."""
     B, T_all = b["src_img"].shape[0], b["src_img"].shape[1]
     S = M.image_size
@@ -163,7 +170,7 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     # launch grids far smaller than the chip) and are joined before the fusion blend.
     main = torch.cuda.current_stream()
     if prepared is None or prepared.batch is not b or prepared.prosrc != prosrc:
-        prepared = prepare_clip(M, b, prosrc)
+        prepared = prepare_clip(M, b, prosrc, with_loss_target)
     bg_output, tsf = prepared.bg_output, prepared.tsf
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
     x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
@@ -180,7 +187,7 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
                         "tgt_smpl_mask": b["smpl_real_mask"], "tgt_IUV": b["tgt_IUV"], "use_IUV": True})
     return {"final_output": pro["pred_target"], "final_mask": pro["weight"], "fusion_output": fusion,
             "refine_output": refine_output, "fg_mask": fg_mask, "bg_output": bg_output, "tsf_image": tsf,
-            "inpaint_warp": inpaint_warp, "inpaint": inpaint, "accu": accu, "masked": masked}
+            "inpaint_warp": inpaint_warp, "inpaint": inpaint, "accu": accu, "masked": masked, "prepared": prepared}
 
 
 def face_crops(final, tgt_img, tgt_IUV, bbox: np.ndarray):
@@ -227,10 +234,17 @@ class Stage4Trainer:
         for f in self.flat.values():                                             # :206-212
             f.zero_grad()
         prepared, self._prepared = self._prepared, None
-        g = generator_forward(M, b, used, prosrc, align_corners, prepared)
+        g = generator_forward(M, b, used, prosrc, align_corners, prepared, with_loss_target=True)
         final = g["final_output"]
         target = b["tgt_img"].contiguous()
-        loss = M.loss_criterion(final, target)                                   # :332
+        vgg_target = None
+        prep = g["prepared"]
+        if prep.vgg_target is not None:         # target features came from the side stream
+            torch.cuda.current_stream().wait_event(prep.vgg_event)
+            vgg_target = prep.vgg_target
+            for t in [vgg_target[0]] + list(vgg_target[1]):
+                t.record_stream(torch.cuda.current_stream())
+        loss = M.loss_criterion(final, target, target=vgg_target)                # :332
         face_pred, face_real, face_IUV = face_crops(final, target, b["tgt_IUV"], b["face_bbox"])
         src0 = b["src_img"][:, 0].contiguous()
         face_pred_d = face_pred.detach()
@@ -255,7 +269,7 @@ class Stage4Trainer:
         F_errG = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0)
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
         if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
-            self._prepared = prepare_clip(M, next_batch, prosrc)
+            self._prepared = prepare_clip(M, next_batch, prosrc, with_loss_target=True)
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
             # input (reverse graph order), beside the differentiation of the modules upstream of it
