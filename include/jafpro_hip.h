@@ -143,6 +143,13 @@ int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t 
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                           const void* packed_in, const void* packed_w, const float* bias, float* out);
+/* Same, and the epilogue ADDS (sum, sum of squares) of every image's outputs to stats[n][slot][2] (fp64,
+ * slot = workgroup % stat_slots, caller zeroes the buffer): the statistics pass of the CRN LayerNorm that
+ * follows (src/crn_model.py:78-87), taken while the values are in registers.  act must be NONE, G == 1.
+ * stats == NULL is jaf_conv2d_fwd_packed.                                                              */
+int jaf_conv2d_fwd_packed_stats(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                const void* packed_in, const void* packed_w, const float* bias, float* out,
+                                double* stats, int32_t stat_slots);
 int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                                  const void* packed_in, const void* packed_w, const float* bias,
                                  const float* c_prev, float* h_out, float* c_out, void* gates_out,
@@ -192,6 +199,9 @@ int jaf_act_bwd(jaf_stream_t s, const float* dy, const float* y, float* dz, int6
  * stats[n] = {mean, 1/(std+eps)} (float2).                                                      */
 int jaf_layernorm_stats(jaf_stream_t s, const float* x, int32_t N, int64_t chw, float eps,
                         double* workspace /* 2*N doubles */, float* stats /* 2*N */);
+/* stats[n] from sums[n][slot][2] = (sum, sum of squares) accumulated by jaf_conv2d_fwd_packed_stats. */
+int jaf_layernorm_finalize(jaf_stream_t s, const double* sums, int32_t N, int32_t slots, int64_t chw, float eps,
+                           float* stats /* 2*N */);
 int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                             const float* beta, float* y, int32_t N, int32_t C, int32_t HW,
                             float slope);

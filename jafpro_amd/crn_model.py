@@ -41,9 +41,10 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.Tensor(num_features).uniform_())
         self.beta = nn.Parameter(torch.zeros(num_features))
 
-    def forward(self, x, slope: float = 1.0):
-        """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01."""
-        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope)
+    def forward(self, x, slope: float = 1.0, pre=None):
+        """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01 and the statistics
+        its convolution's epilogue already accumulated (ops.LNStats)."""
+        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope, pre)
 
 
 class ConvBlock(nn.Module):
@@ -61,8 +62,9 @@ class ConvBlock(nn.Module):
         """x: tensor or list of tensors (read as their channel concatenation)."""
         for r in range(self.n_repeats):
             conv, ln = self.conv_block[3 * r], self.conv_block[3 * r + 1]
-            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE)
-            x = ln(x, 0.01)
+            st = ops.LNStats()
+            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE, ln_stats=st)
+            x = ln(x, 0.01, st)
         return x
 
 

@@ -42,6 +42,8 @@ struct ConvDArgs {
     float inv_pwp, inv_pwq, inv_twin;
     int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
+    double* stats;     // nullable: [N][slots][2] += (sum, sum of squares) of the image's outputs (act NONE, G == 1):
+    int stat_slots;    // the statistics pass of the LayerNorm that follows, taken while the values are in registers
 };
 
 __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
@@ -523,7 +525,7 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, bool LSTM>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
-                                            int n, int g, int mb, int q, int OHW) {
+                                            int n, int g, int mb, int q, int OHW, unsigned char* smem) {
     const jaf_conv_desc& d = a.d;
     constexpr int MR = 16 * MT;
     // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel).
@@ -532,7 +534,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
     typedef __bf16 hvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
     const bool vec = a.vec && (NT > 1);
     if (!LSTM) {
-#define CD_EPILOGUE(ACT_)                                                                             \
+        float st1 = 0.f, st2 = 0.f;     // LayerNorm statistics of this lane's outputs (ACT NONE + a.stats only)
+#define CD_EPILOGUE(ACT_, ST_)                                                                        \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
@@ -545,22 +548,44 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
                                 o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
                             *(fvec*)(op + opix[0]) = o;                                               \
+                            if (ST_) {                                                                \
+                                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { st1 += o[nt]; st2 += o[nt] * o[nt]; } \
+                            }                                                                         \
                         }                                                                             \
                     } else {                                                                          \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
-                            if (opix[nt] >= 0) op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope); \
+                            if (opix[nt] >= 0) {                                                      \
+                                const float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);           \
+                                op[opix[nt]] = v;                                                     \
+                                if (ST_) { st1 += v; st2 += v * v; }                                  \
+                            }                                                                         \
                     }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
         }
         switch (d.act) {     // hoisted: one tight copy of the store loop per activation
-            case JAF_ACT_LRELU: CD_EPILOGUE(JAF_ACT_LRELU) break;
-            case JAF_ACT_RELU: CD_EPILOGUE(JAF_ACT_RELU) break;
-            case JAF_ACT_SIGMOID: CD_EPILOGUE(JAF_ACT_SIGMOID) break;
-            case JAF_ACT_TANH: CD_EPILOGUE(JAF_ACT_TANH) break;
-            default: CD_EPILOGUE(JAF_ACT_NONE) break;
+            case JAF_ACT_LRELU: CD_EPILOGUE(JAF_ACT_LRELU, 0) break;
+            case JAF_ACT_RELU: CD_EPILOGUE(JAF_ACT_RELU, 0) break;
+            case JAF_ACT_SIGMOID: CD_EPILOGUE(JAF_ACT_SIGMOID, 0) break;
+            case JAF_ACT_TANH: CD_EPILOGUE(JAF_ACT_TANH, 0) break;
+            default:
+                if (a.stats) { CD_EPILOGUE(JAF_ACT_NONE, 1) } else { CD_EPILOGUE(JAF_ACT_NONE, 0) }
+                break;
         }
 #undef CD_EPILOGUE
+        if (a.stats) {      // uniform: wave sums -> LDS -> one pair of fp64 atomics per workgroup, spread over slots
+            st1 = jaf_wave_sum(st1);
+            st2 = jaf_wave_sum(st2);
+            __syncthreads();                      // every wave has left the MFMA loop: the patch buffer is free
+            float* red = (float*)smem;
+            if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = st1; red[2 * (threadIdx.x >> 6) + 1] = st2; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double* w = a.stats + ((long)n * a.stat_slots + (blockIdx.x % a.stat_slots)) * 2;
+                atomicAdd(w, (double)((red[0] + red[2]) + (red[4] + red[6])));
+                atomicAdd(w + 1, (double)((red[1] + red[3]) + (red[5] + red[7])));
+            }
+        }
     } else {
         const int C = d.Cout >> 2;   // hidden channels per group (rows are gate-interleaved: 4c+gate)
 #pragma unroll
@@ -811,7 +836,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     }
 
     // ---- epilogue ----
-    cd_epilogue<MT, NT, LSTM>(a, acc, opix, n, g, mb, q, OHW);
+    cd_epilogue<MT, NT, LSTM>(a, acc, opix, n, g, mb, q, OHW, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1045,18 +1070,29 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.h_out = nullptr;
     a.gates_out = nullptr;
     a.gates_bf16 = 0;
+    a.stats = nullptr;
+    a.stat_slots = 1;
 }
 
-extern "C" int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
-                                     const void* packed_in, const void* packed_w, const float* bias, float* out) {
+extern "C" int jaf_conv2d_fwd_packed_stats(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                           const void* packed_in, const void* packed_w, const float* bias, float* out,
+                                           double* stats, int32_t stat_slots) {
     JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && out);
+    JAF_REQUIRE(!stats || (d->act == JAF_ACT_NONE && d->G == 1 && stat_slots >= 1 && stat_slots <= 64));
     ConvDArgs a;
     cd_fill(a, d, plan);
     a.xp = (const unsigned char*)packed_in;
     a.wpk = (const unsigned char*)packed_w;
     a.bias = bias;
     a.out = out;
+    a.stats = stats;
+    a.stat_slots = stats ? stat_slots : 1;
     return cd_launch_mt<false>(a, (hipStream_t)s);
+}
+
+extern "C" int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                     const void* packed_in, const void* packed_w, const float* bias, float* out) {
+    return jaf_conv2d_fwd_packed_stats(s, d, plan, packed_in, packed_w, bias, out, nullptr, 1);
 }
 
 extern "C" int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,

@@ -65,6 +65,30 @@ __global__ void ln_finalize_kernel(const double* ws, int N, long chw, float eps,
     stats[2 * n + 1] = 1.0f / (stdv + eps);
 }
 
+__global__ void ln_finalize_slots_kernel(const double* ws, int N, int slots, long chw, float eps, float* stats) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s = 0.0, ss = 0.0;
+    for (int k = 0; k < slots; ++k) {
+        s += ws[((long)n * slots + k) * 2];
+        ss += ws[((long)n * slots + k) * 2 + 1];
+    }
+    const double cnt = (double)chw;
+    const double mean = s / cnt;
+    double var = (ss - s * mean) / (cnt > 1.0 ? cnt - 1.0 : 1.0);
+    if (var < 0.0) var = 0.0;
+    const float stdv = (float)sqrt(var);
+    stats[2 * n] = (float)mean;
+    stats[2 * n + 1] = 1.0f / (stdv + eps);
+}
+
+extern "C" int jaf_layernorm_finalize(jaf_stream_t s, const double* sums, int32_t N, int32_t slots, int64_t chw, float eps,
+                                      float* stats) {
+    JAF_REQUIRE(sums && stats && N >= 1 && slots >= 1 && chw >= 1);
+    hipLaunchKernelGGL(ln_finalize_slots_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, (hipStream_t)s, sums, N, slots, (long)chw, eps, stats);
+    return jaf_launch_status();
+}
+
 extern "C" int jaf_layernorm_stats(jaf_stream_t s_, const float* x, int32_t N, int64_t chw, float eps,
                                    double* workspace, float* stats) {
     JAF_REQUIRE(x && workspace && stats && N >= 1 && chw >= 1 && N <= 65535);

@@ -226,10 +226,22 @@ def _out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+class LNStats:
+    """Side channel between a convolution and the CRN LayerNorm that follows it (crn_model.ConvBlock): on the
+    packed bf16 path the conv epilogue accumulates each image's (sum, sum of squares) into `sums`
+    ([N][slots][2] fp64) while the outputs are still in registers, and the LayerNorm skips its own
+    statistics pass over the tensor.  `filled` stays False when the convolution took another path."""
+    __slots__ = ("sums", "slots", "filled")
+    SLOTS = 8
+
+    def __init__(self):
+        self.sums, self.slots, self.filled = None, self.SLOTS, False
+
+
 def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_tot: int, mode: int,
               bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
-              xp: Optional[torch.Tensor] = None, want_xp: bool = False):
+              xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None):
     if out is None:
         out_ctot = G * Cout
         out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
@@ -242,9 +254,15 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
     if _packed_path(d):
         if xp is None:
             xp = pack_input(srcs, d)
+        sums = None
+        if ln_stats is not None and act == ACT_NONE and G == 1:
+            sums = torch.zeros(N * ln_stats.slots * 2, device=out.device, dtype=torch.float64)
         ev = _PROF.begin() if _PROF is not None else None
-        check(lib().jaf_conv2d_fwd_packed(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out)),
-              "jaf_conv2d_fwd_packed")
+        check(lib().jaf_conv2d_fwd_packed_stats(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out),
+                                                _p(sums), ln_stats.slots if sums is not None else 1),
+              "jaf_conv2d_fwd_packed_stats")
+        if sums is not None:
+            ln_stats.sums, ln_stats.filled = sums, True
         if ev is not None:
             _PROF.end("conv_dma_kernel<%d, %d, false>" % (pl.MT, pl.NT), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
@@ -268,7 +286,7 @@ def _grad_inplace(p: torch.Tensor) -> bool:
 
 class _ConvMeta:
     __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
-                 "KH", "KW", "cin_tot")
+                 "KH", "KW", "cin_tot", "ln_stats")
 
 
 class _ConvFn(Function):
@@ -276,7 +294,8 @@ class _ConvFn(Function):
     def forward(ctx, weight, bias, meta: _ConvMeta, *srcs):
         m = meta
         y, xp = _conv_raw(srcs, m.specs, weight, m.Cout, PACK_FWD, bias, m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW,
-                          m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True)
+                          m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True,
+                          ln_stats=m.ln_stats)
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
         ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.meta = m
@@ -373,8 +392,10 @@ class _ConvFn(Function):
 
 
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0,
-           act: int = ACT_NONE, slope: float = 0.0, groups: int = 1, shared: Optional[Sequence[bool]] = None):
+           act: int = ACT_NONE, slope: float = 0.0, groups: int = 1, shared: Optional[Sequence[bool]] = None,
+           ln_stats: Optional[LNStats] = None):
     """Grouped convolution over the channel concatenation of `srcs` with fused bias + activation.
+    `ln_stats`: see LNStats (filled only on the packed bf16 path with act NONE and groups 1).
 
     srcs[i]: [N, groups*c_i, H, W] (or [N, c_i, H, W] when shared[i]: every group reads the same
     channels).  weight: [groups*Cout, sum(c_i), KH, KW] or [groups, Cout, sum(c_i), KH, KW].
@@ -410,6 +431,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     m.G, m.stride, m.pad, m.act, m.slope = G, stride, pad, act, float(slope)
     m.specs, m.N, m.Cin, m.Cout, m.H, m.W = specs, int(N), Cin, Cout, int(H), int(W)
     m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
+    m.ln_stats = ln_stats
     return _ConvFn.apply(weight, bias, m, *srcs)
 
 
@@ -582,12 +604,15 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
 # --------------------------------------------------------------------------------------------
 class _LayerNormLReLUFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, slope: float):
+    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats]):
         N, C, H, W = x.shape
         L = lib()
-        ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
-        check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")
+        if pre is not None and pre.filled:       # sums came out of the producing convolution's epilogue
+            check(L.jaf_layernorm_finalize(_s(), _p(pre.sums), N, pre.slots, C * H * W, eps, _p(stats)), "jaf_layernorm_finalize")
+        else:
+            ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
+            check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")
         y = torch.empty_like(x)
         check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
               "jaf_layernorm_lrelu_fwd")
@@ -609,12 +634,12 @@ class _LayerNormLReLUFn(Function):
         check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
                                             _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
               "jaf_layernorm_lrelu_bwd")
-        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None
+        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None
 
 
-def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01):
+def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01, pre: Optional[LNStats] = None):
     _chk(x, "layernorm x"); _chk(gamma, "gamma"); _chk(beta, "beta")
-    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope)
+    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre)
 
 
 class _BatchNormActFn(Function):

@@ -219,6 +219,7 @@ class Stage4Trainer:
         }
         self.reducer = reducer          # jafpro_amd.dist.GradReducer or None (single GPU)
         self._prepared: Optional[PreparedClip] = None
+        self.phase_mark = None          # optional callable(name): phase boundaries of train_step (profiling)
 
     def _reduce(self, names: Sequence[str]):
         if self.reducer is not None:
@@ -244,7 +245,10 @@ class Stage4Trainer:
             vgg_target = prep.vgg_target
             for t in [vgg_target[0]] + list(vgg_target[1]):
                 t.record_stream(torch.cuda.current_stream())
+        mark = self.phase_mark or (lambda name: None)
+        mark("generator forward")
         loss = M.loss_criterion(final, target, target=vgg_target)                # :332
+        mark("VGG+L1 loss forward")
         face_pred, face_real, face_IUV = face_crops(final, target, b["tgt_IUV"], b["face_bbox"])
         src0 = b["src_img"][:, 0].contiguous()
         face_pred_d = face_pred.detach()
@@ -255,6 +259,7 @@ class Stage4Trainer:
         F_errD_fake.backward()
         self._reduce(["face"])
         self.flat["face"].adam(self.lrs["face"])
+        mark("face-D update")
         # ---- image discriminator, three updates on accumulating grads (:380-394, F10)
         final_d = final.detach()
         for _ in range(3):
@@ -264,6 +269,7 @@ class Stage4Trainer:
             errD_fake.backward()
             self._reduce(["D"])
             self.flat["D"].adam(self.lrs["D"])
+        mark("D x3 updates")
         # ---- generator (:398-413)
         errG = ops.bce_loss(M.discriminator([final, src0]), 1.0)
         F_errG = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0)
@@ -282,8 +288,10 @@ class Stage4Trainer:
             self.overlap_order = list(ov.fired)
         else:
             total.backward()
+        mark("generator loss backward")
         for n in ("accu", "inpaint", "refine", "flow"):
             self.flat[n].adam(self.lrs[n])
+        mark("generator Adam x4")
         return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),
                 "errG": errG.detach(), "F_errD": (F_errD_real + F_errD_fake).detach(), "F_errG": F_errG.detach(),
                 "final_output": final_d}

@@ -529,3 +529,30 @@ def test_lstm_gates_bwd_packed_direct(C, H, W, g16, first):
     # bf16 rounding of values up to ~1: half an ulp is 2^-9 relative
     assert (got - dgates).abs().max().item() <= 2.0 ** -8 * max(1.0, dgates.abs().max().item())
     assert maxerr(db, db_ref) <= 1e-4 * max(1.0, db_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 16, 64, 32, 32), (3, 7, 20, 13, 9), (1, 64, 256, 16, 16)])
+def test_layernorm_statistics_from_conv_epilogue(N, Cin, Cout, H, W):
+    """jaf_conv2d_fwd_packed_stats + jaf_layernorm_finalize (bf16 packed path): the LayerNorm fed by the sums the
+    convolution's epilogue accumulated must equal the LayerNorm that makes its own statistics pass over
+    the same convolution output (src/crn_model.py:78-87)."""
+    ops = _ops()
+    x, w, b = dev(R(1, N, Cin, H, W)), dev(R(2, Cout, Cin, 3, 3, lo=-0.2, hi=0.2)), dev(R(3, Cout, lo=-0.5, hi=0.5))
+    g, be = dev(R(4, Cout, lo=0.2, hi=1.0)), dev(R(5, Cout, lo=-0.2, hi=0.2))
+    prev = ops.set_precision("bf16")
+    try:
+        st = ops.LNStats()
+        y = ops.conv2d(x, w, b, stride=1, pad=1, act=0, ln_stats=st)
+        assert st.filled and st.sums.numel() == N * st.slots * 2
+        fused = ops.layernorm_lrelu(y, g, be, 1e-5, 0.01, st)
+        plain = ops.layernorm_lrelu(y, g, be, 1e-5, 0.01)
+    finally:
+        ops.set_precision(prev)
+    sums = st.sums.view(N, st.slots, 2).sum(1).cpu()
+    ref = torch.stack([y.double().sum((1, 2, 3)), (y.double() ** 2).sum((1, 2, 3))], 1).cpu()
+    assert torch.allclose(sums, ref, rtol=2e-6, atol=1e-6)
+    assert maxerr(fused, plain.cpu()) <= 2e-5
+    # other paths leave the side channel untouched
+    st2 = ops.LNStats()
+    ops.conv2d(x, w, b, stride=1, pad=1, act=0, ln_stats=st2)      # f32 mode
+    assert not st2.filled
