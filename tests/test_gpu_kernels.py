@@ -41,6 +41,8 @@ CONV_CASES = [
     (1, 2, [96, 48], 48, 13, 13, 3, 1, 1, 1),
     (1, 1, [6], 32, 256, 256, 3, 2, 1, 1),
     (1, 1, [64], 64, 100, 100, 3, 1, 1, 2),
+    (2, 3, [24], 24, 50, 50, 3, 2, 1, 1),              # stride 2, wide (two ci tiles): part-network enc2/4/6/8
+    (1, 1, [128], 72, 33, 31, 3, 2, 1, 1),             # stride 2, >32 input channels, odd sizes
 ]
 
 
