@@ -76,8 +76,9 @@ class BackwardOverlap:
     has not fired (modules whose input carries no gradient), waits for everything and takes the means.
     Message order is the reverse graph order on every rank, so ranks issue identical collective sequences."""
 
-    def __init__(self, reducer: GradReducer):
+    def __init__(self, reducer: GradReducer, before_begin=None):
         self.red = reducer
+        self.before_begin = before_begin      # e.g. ops.join_wgrad_stream: gradients written on another stream
         self.works = []
         self.fired: List[str] = []
         self._hooks = []
@@ -89,6 +90,8 @@ class BackwardOverlap:
         def hook(_grad, name=name, buffers=buffers):
             if name not in self.fired:
                 self.fired.append(name)
+                if self.before_begin is not None:
+                    self.before_begin()
                 self.works += self.red.begin(buffers)
             return None
 
@@ -98,6 +101,8 @@ class BackwardOverlap:
         for name, buffers in rest:
             if name not in self.fired:
                 self.fired.append(name)
+                if self.before_begin is not None:
+                    self.before_begin()
                 self.works += self.red.begin(buffers)
         for h in self._hooks:
             h.remove()

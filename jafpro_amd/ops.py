@@ -226,6 +226,25 @@ def _out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+_WGRAD_STREAM = None     # see set_wgrad_stream
+
+
+def set_wgrad_stream(stream):
+    """While set, the weight-gradient kernels of convolutions / ConvLSTMs whose parameter owns its .grad buffer
+    (step.FlatParams) are enqueued on `stream` instead of the current one: they depend only on the packed dz
+    and the saved input, nothing downstream in the backward pass waits for them, so they run beside the data
+    gradients of the layers further upstream.  Whoever reads the .grad buffers must call `join_wgrad_stream()`
+    first (the trainer does before every Adam / all-reduce and before it returns).  Returns the previous value."""
+    global _WGRAD_STREAM
+    prev, _WGRAD_STREAM = _WGRAD_STREAM, stream
+    return prev
+
+
+def join_wgrad_stream():
+    if _WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
+
+
 class LNStats:
     """Side channel between a convolution and the CRN LayerNorm that follows it (crn_model.ConvBlock): on the
     packed bf16 path the conv epilogue accumulates each image's (sum, sum of squares) into `sums`
@@ -289,6 +308,33 @@ class _ConvMeta:
                  "KH", "KW", "cin_tot", "ln_stats")
 
 
+def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
+    """Weight gradient of one convolution on the CURRENT stream.  A parameter whose .grad buffer already
+    exists (step.FlatParams) is accumulated in place by the kernel: no temporary, no memset, no separate
+    AccumulateGrad add launch; otherwise the gradient tensor is returned."""
+    L = lib()
+    dw = weight.grad if inplace else torch.empty_like(weight)
+    d = _make_desc(m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW, m.KH, m.KW, m.stride, m.pad, m.pad, 1,
+                   m.specs, m.cin_tot, 0, m.G * m.Cout, 0, ACT_NONE, 0.0)
+    ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+    ev = _PROF.begin() if _PROF is not None else None
+    if ctx.xp is not None and _packed_path(d):
+        if dzp is None:
+            dzd = _make_desc(m.N, m.G, m.Cout, 1, m.OH, m.OW, m.OH, m.OW, 1, 1, 1, 0, 0, 1,
+                             [(m.Cout, m.G * m.Cout, 0, m.Cout)], 1, 0, m.G, 0, ACT_NONE, 0.0)
+            dzp = pack_input([dz], dzd)
+        check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xp), _p(dzp), _p(dw), 1 if inplace else 0),
+              "jaf_conv2d_wgrad_packed")
+        wname = _wgrad_dma_name(m.Cout, m.KH)
+    else:
+        check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
+              "jaf_conv2d_wgrad")
+        wname = _wgrad_name(m.KH, m.KW)
+    if ev is not None:
+        _PROF.end(wname, 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
+    return None if inplace else dw
+
+
 class _ConvFn(Function):
     @staticmethod
     def forward(ctx, weight, bias, meta: _ConvMeta, *srcs):
@@ -338,6 +384,18 @@ class _ConvFn(Function):
             check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
         else:
             dz = dy
+        dw = None
+        wgrad_done = False
+        ws = _WGRAD_STREAM
+        if ws is not None and ctx.needs_input_grad[0] and _grad_inplace(weight):
+            # weight gradient first, on the side stream: it needs only dz (just made) and the saved input
+            ws.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ws):
+                _conv_wgrad(ctx, m, weight, srcs, dz, dzp, True)
+            for t in (ctx.xp, dzp, dz) + tuple(srcs):
+                if t is not None:
+                    t.record_stream(ws)
+            wgrad_done = True
         dsrcs: List[Optional[torch.Tensor]] = []
         pad_d = m.KH - 1 - m.pad
         coff = 0
@@ -355,32 +413,9 @@ class _ConvFn(Function):
             else:
                 dsrcs.append(None)
             coff += c
-        dw = None
-        if ctx.needs_input_grad[0]:
-            # a parameter whose .grad buffer already exists (step.FlatParams) is accumulated in place
-            # by the kernel: no temporary, no memset, no separate AccumulateGrad add launch
+        if ctx.needs_input_grad[0] and not wgrad_done:
             inplace = _grad_inplace(weight)
-            dw = weight.grad if inplace else torch.empty_like(weight)
-            d = _make_desc(m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW, m.KH, m.KW, m.stride, m.pad, m.pad, 1,
-                           m.specs, m.cin_tot, 0, m.G * m.Cout, 0, ACT_NONE, 0.0)
-            ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
-            ev = _PROF.begin() if _PROF is not None else None
-            if ctx.xp is not None and _packed_path(d):
-                if dzp is None:
-                    dzd = _make_desc(m.N, m.G, m.Cout, 1, m.OH, m.OW, m.OH, m.OW, 1, 1, 1, 0, 0, 1,
-                                     [(m.Cout, m.G * m.Cout, 0, m.Cout)], 1, 0, m.G, 0, ACT_NONE, 0.0)
-                    dzp = pack_input([dz], dzd)
-                check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xp), _p(dzp), _p(dw), 1 if inplace else 0),
-                      "jaf_conv2d_wgrad_packed")
-                wname = _wgrad_dma_name(m.Cout, m.KH)
-            else:
-                check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
-                      "jaf_conv2d_wgrad")
-                wname = _wgrad_name(m.KH, m.KW)
-            if ev is not None:
-                _PROF.end(wname, 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
-            if inplace:
-                dw = None
+            dw = _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace)
         if want_db and not db_done:
             inplace = bias is not None and _grad_inplace(bias)
             db = bias.grad if inplace else torch.empty(m.G * m.Cout, device=dy.device, dtype=torch.float32)
@@ -557,11 +592,18 @@ class _ConvLSTMFn(Function):
                     check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
                                                           1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
                                                           _p(db)), "jaf_convlstm_gates_bwd_packed")
-                ev = _PROF.begin() if _PROF is not None else None
-                check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
-                                                1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
-                if ev is not None:
-                    _PROF.end(_wgrad_dma_name(4 * C, 3), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                wst = _WGRAD_STREAM if w_inplace else None      # see set_wgrad_stream
+                if wst is not None:
+                    wst.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(wst if wst is not None else torch.cuda.current_stream()):
+                    ev = _PROF.begin() if _PROF is not None else None
+                    check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
+                                                    1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
+                    if ev is not None:
+                        _PROF.end(_wgrad_dma_name(4 * C, 3), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                if wst is not None:
+                    gtp.record_stream(wst)
+                    ctx.xps[t].record_stream(wst)
             else:
                 # gt is overwritten with the pre-activation gate gradients
                 check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),

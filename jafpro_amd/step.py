@@ -12,6 +12,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -55,6 +57,7 @@ class FlatParams:
         self.grad.zero_()
 
     def adam(self, lr: float):
+        ops.join_wgrad_stream()         # weight gradients may have been written on the side stream
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params)
 
@@ -99,12 +102,13 @@ _SIDE_STREAMS = {}
 
 
 SERIAL_STREAMS = False      # profiling aid: run the side-stream work on the main stream (clean per-kernel times)
+WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradients on a second side stream
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
+def _side_stream(device, which: int = 0) -> "torch.cuda.Stream":
     if SERIAL_STREAMS:
         return torch.cuda.current_stream()
-    k = str(device)
+    k = "%s/%d" % (device, which)
     st = _SIDE_STREAMS.get(k)
     if st is None:
         st = torch.cuda.Stream(device=device)
@@ -223,6 +227,7 @@ class Stage4Trainer:
 
     def _reduce(self, names: Sequence[str]):
         if self.reducer is not None:
+            ops.join_wgrad_stream()
             self.reducer.all_reduce_mean([self.flat[n].grad for n in names])
 
     def train_step(self, batch: Dict[str, torch.Tensor], used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0,
@@ -231,6 +236,16 @@ class Stage4Trainer:
         its parameter-independent preparation (SMPL projection/rasterisation/flow warp, frozen
         background CRN) is issued on the side HIP stream right before this clip's generator loss
         backward and is picked up by that next call."""
+        M, b = self.M, batch
+        # weight-gradient kernels run on their own stream beside the data gradients (ops.set_wgrad_stream)
+        prev_ws = ops.set_wgrad_stream(None if (SERIAL_STREAMS or not WGRAD_STREAM) else _side_stream(torch.cuda.current_stream().device, 1))
+        try:
+            return self._train_step(batch, used, prosrc, align_corners, next_batch)
+        finally:
+            ops.join_wgrad_stream()
+            ops.set_wgrad_stream(prev_ws)
+
+    def _train_step(self, batch, used, prosrc, align_corners, next_batch):
         M, b = self.M, batch
         for f in self.flat.values():                                             # :206-212
             f.zero_grad()
@@ -279,7 +294,7 @@ class Stage4Trainer:
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
             # input (reverse graph order), beside the differentiation of the modules upstream of it
-            ov = BackwardOverlap(self.reducer)
+            ov = BackwardOverlap(self.reducer, before_begin=ops.join_wgrad_stream)
             ov.watch(g["fusion_output"], "flow", [self.flat["flow"].grad])
             ov.watch(g["inpaint_warp"], "refine", [self.flat["refine"].grad])
             ov.watch(g["masked"], "inpaint", [self.flat["inpaint"].grad])
