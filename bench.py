@@ -142,10 +142,10 @@ def main():
         from jafpro_amd.dist import GradReducer
         reducer = GradReducer()
 
-    from jafpro_amd import ops, synth, step as step_mod
+    from jafpro_amd import ops, synth
     from jafpro_amd.step import Stage4Trainer, _to_dev
     ops.set_precision(args.precision)
-    step_mod.SERIAL_STREAMS = bool(args.serial_streams)
+    ops.set_serial_streams(bool(args.serial_streams))
     _, fidx = synth.body_mesh()
     M, mods = build_models(fidx)
     M = M.cuda()
@@ -196,7 +196,7 @@ def main():
         # one extra step with every kernel on ONE stream: a kernel that shares the chip with side-stream work
         # runs longer than it does alone, and the roofline wants the kernel's own duration
         torch.cuda.synchronize()
-        step_mod.SERIAL_STREAMS = True
+        ops.set_serial_streams(True)
         trainer.reducer = None      # rank-0-only steps: no collective may be issued here (the other ranks wait below)
         trainer.train_step(batch, next_batch=nb)          # consumes the clip prepared on the side stream
         prof = ops.KernelProfiler()
@@ -204,7 +204,7 @@ def main():
         trainer.train_step(batch, next_batch=nb)
         ops.set_profiler(None)
         torch.cuda.synchronize()
-        step_mod.SERIAL_STREAMS = bool(args.serial_streams)
+        ops.set_serial_streams(bool(args.serial_streams))
         allk = prof.summary()
         summ = {k: v for k, v in allk.items() if v["flops"] > 0}
         hbm = {k: v for k, v in allk.items() if v["bytes"] > 0}

@@ -226,6 +226,31 @@ def _out_size(n, k, s, p):
     return (n + 2 * p - k) // s + 1
 
 
+_AUX_STREAMS = {}
+_SERIAL_STREAMS = False
+
+
+def set_serial_streams(flag: bool) -> bool:
+    """Profiling aid: every auxiliary stream becomes the current stream (per-kernel times free of overlap)."""
+    global _SERIAL_STREAMS
+    prev, _SERIAL_STREAMS = _SERIAL_STREAMS, bool(flag)
+    return prev
+
+
+def aux_stream(which: int = 0) -> "torch.cuda.Stream":
+    """One of a few long-lived side HIP streams of the current device (0: clip preparation, 1: weight
+    gradients)."""
+    cur = torch.cuda.current_stream()
+    if _SERIAL_STREAMS:
+        return cur
+    k = (cur.device.index, which)
+    st = _AUX_STREAMS.get(k)
+    if st is None:
+        st = torch.cuda.Stream(device=cur.device)
+        _AUX_STREAMS[k] = st
+    return st
+
+
 _WGRAD_STREAM = None     # see set_wgrad_stream
 
 

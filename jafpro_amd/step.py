@@ -98,22 +98,13 @@ def _to_dev(batch: Dict[str, np.ndarray], device) -> Dict[str, torch.Tensor]:
 
 
 _FLAG_CACHE = {}
-_SIDE_STREAMS = {}
 
 
-SERIAL_STREAMS = False      # profiling aid: run the side-stream work on the main stream (clean per-kernel times)
 WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradients on a second side stream
 
 
-def _side_stream(device, which: int = 0) -> "torch.cuda.Stream":
-    if SERIAL_STREAMS:
-        return torch.cuda.current_stream()
-    k = "%s/%d" % (device, which)
-    st = _SIDE_STREAMS.get(k)
-    if st is None:
-        st = torch.cuda.Stream(device=device)
-        _SIDE_STREAMS[k] = st
-    return st
+def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
+    return ops.aux_stream(which)
 
 
 def _used_flags(T_all: int, used, device) -> torch.Tensor:
@@ -238,7 +229,7 @@ class Stage4Trainer:
         backward and is picked up by that next call."""
         M, b = self.M, batch
         # weight-gradient kernels run on their own stream beside the data gradients (ops.set_wgrad_stream)
-        prev_ws = ops.set_wgrad_stream(None if (SERIAL_STREAMS or not WGRAD_STREAM) else _side_stream(torch.cuda.current_stream().device, 1))
+        prev_ws = ops.set_wgrad_stream(None if not WGRAD_STREAM else ops.aux_stream(1))
         try:
             return self._train_step(batch, used, prosrc, align_corners, next_batch)
         finally:
