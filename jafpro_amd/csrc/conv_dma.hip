@@ -490,10 +490,8 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
     const bool v4 = (HW % 4 == 0) && (al & 15) == 0;
     const bool v2 = (HW % 2 == 0) && (al & 7) == 0;
     const int V = v4 ? 4 : (v2 ? 2 : 1);
-    static int full = -1;
-    if (full < 0) { const char* e = getenv("JAF_LGB_FULL"); full = e ? atoi(e) : 1; }
     const int CBF = (C == 12) ? 12 : ((C % 8 == 0) ? 8 : 0);
-    if (CBF && full && v2) {
+    if (CBF && v2) {
         // whole-item kernel, 2 pixels per lane (4 per lane does not fit 128 registers)
         const int per_block = 256 * 2;
         int iters = 8;
@@ -863,27 +861,17 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     if (lstm) JAF_REQUIRE((d->Cout & 3) == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1);
     const int M = d->Cout;
     const int taps = d->KH * d->KW;
-    int bestMT = 1;
-    long bestPad = 1L << 60;
-    for (int mt = 4; mt >= 1; --mt) {
-        long pad = (long)jaf_cdiv(M, 16 * mt) * 16 * mt;
-        if (pad < bestPad) { bestPad = pad; bestMT = mt; }
-    }
     int mt_lo = 1, mt_hi = 4;
     if (lstm) {
         mt_lo = mt_hi = (M % 48 == 0) ? 3 : ((M % 64 == 0) ? 4 : ((M % 32 == 0) ? 2 : 1));
         JAF_REQUIRE(M % (16 * mt_lo) == 0);
     }
-    static int mtfree = -1;
-    if (mtfree < 0) { const char* e = getenv("JAF_CD_MTFREE"); mtfree = e ? atoi(e) : 1; }
-    if (!mtfree && !lstm) mt_lo = mt_hi = bestMT;
     const int groups = jaf_cdiv(d->Cin, 8);
     const long OHW = (long)d->OH * d->OW;
 
     double bestCost = 1e300;
     int bTW = 0, bNT = 0, bNG = 0, bMT = 0;
-    static int ngcap = 0;
-    if (!ngcap) { const char* e = getenv("JAF_CD_NGCAP"); ngcap = e ? atoi(e) : 4; if (ngcap < 1 || ngcap > 4) ngcap = 4; }
+    const int ngcap = 4;          // channel groups of 8 per chunk (slot table and DMA rounds are sized for <= 4)
     const int cand_tw[4] = {16, 32, 64, d->OW};
     for (int cMT = mt_hi; cMT >= mt_lo; --cMT)
     for (int ci = 0; ci < 4; ++ci) {
@@ -925,7 +913,6 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
                 const double stage = 600.0 + ((double)npos * NG * 16.0 + (double)nsteps * MT * 1024.0) / 48.0;
                 const int blocks_cu = (int)(160 * 1024 / lds);
                 const int bl = blocks_cu > 6 ? 6 : blocks_cu;
-                const double overlap = 1.0 / (double)(bl < 1 ? 1 : bl);   // resident workgroups hide each other's staging
                 const double occ_pen = bl >= 3 ? 1.0 : (bl == 2 ? 1.1 : 1.4);
                 const double fixed = 2500.0 + 60.0 * MT * NT;
                 // whole-launch cost: workgroups / 256 CUs, but never less than one workgroup's own
@@ -934,10 +921,9 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
                 const double nblocks = (double)tiles_x * tiles_p * jaf_cdiv(M, 16 * MT) * d->N * d->G;
                 const double per_cu = nblocks / 256.0;
                 const int conc = per_cu >= bl ? bl : (per_cu <= 1.0 ? 1 : (int)per_cu);
-                const double ovl = mtfree ? 1.0 / (double)(conc < 1 ? 1 : conc) : overlap;
+                const double ovl = 1.0 / (double)(conc < 1 ? 1 : conc);   // resident workgroups hide each other's staging
                 const double per_block = total_steps * t_step * occ_pen + nchunks * (stage * ovl + 250.0) + fixed;
-                const double cost = mtfree ? (per_cu > 1.0 ? per_cu : 1.0) * per_block
-                                           : (double)tiles_x * tiles_p * per_block;
+                const double cost = (per_cu > 1.0 ? per_cu : 1.0) * per_block;
                 if (cost < bestCost) { bestCost = cost; bTW = TW; bNT = NT; bNG = NG; bMT = MT; }
             }
         }

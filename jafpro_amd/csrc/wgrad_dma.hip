@@ -304,14 +304,9 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    static int target = 0;
-    if (!target) { const char* e = getenv("JAF_WD_TARGET"); target = e ? atoi(e) : 768; if (target < 64) target = 768; }
+    const long tgt = 768;         // workgroups per launch (3 per CU)
     // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of
     // atomic traffic per launch at 1536 workgroups): large gradients get just enough splits to fill the chip
-    const long dwf = (long)d->Cout * d->Cin * KS * KS;
-    static int tbig = 0;
-    if (!tbig) { const char* e = getenv("JAF_WD_TBIG"); tbig = e ? atoi(e) : 768; if (tbig < 64) tbig = 768; }
-    const long tgt = dwf >= 32768 ? tbig : target;
     long nsplit = (tgt + outblocks - 1) / outblocks;
     if (nsplit > items) nsplit = items;
     if (nsplit < 1) nsplit = 1;
