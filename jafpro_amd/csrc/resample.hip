@@ -129,6 +129,50 @@ __global__ void resize_fwd_kernel(const float* x, float* y, ResizeArgs a) {
     else q[0] = o[0];
 }
 
+// Bilinear forward with the source region of the workgroup's output tile staged in LDS: the direct kernel issues 16
+// overlapping 4-byte global loads per lane (4 outputs x 4 taps) and reaches 1.9 TB/s on a store-bound operation.
+// Block (tx, ty) = tx*4 x ty outputs of one plane; the source rows / columns of a tile are those of its first and
+// last output (the source index is monotonic in the output index).
+__global__ void resize_fwd_lds_kernel(const float* __restrict__ x, float* __restrict__ y, ResizeArgs a) {
+    extern __shared__ float s_src[];
+    const int ox0 = blockIdx.x * blockDim.x * 4, oy0 = blockIdx.y * blockDim.y;
+    const long nc = blockIdx.z;
+    int oxl = ox0 + (int)blockDim.x * 4 - 1, oyl = oy0 + (int)blockDim.y - 1;
+    if (oxl > a.OW - 1) oxl = a.OW - 1;
+    if (oyl > a.OH - 1) oyl = a.OH - 1;
+    int rx0, rx1, ry0, ry1, t0, t1;
+    float l;
+    resize_src(ox0, a.sx, a.cw, a.align, rx0, t1, l);
+    resize_src(oxl, a.sx, a.cw, a.align, t0, rx1, l);
+    resize_src(oy0, a.sy, a.ch, a.align, ry0, t1, l);
+    resize_src(oyl, a.sy, a.ch, a.align, t0, ry1, l);
+    if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;          // never taken: a.rw / a.rh bound the region (host)
+    if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
+    const float* p = x + nc * a.H * a.W + (long)(a.y0 + ry0) * a.W + a.x0 + rx0;
+    for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
+        for (int c = threadIdx.x; c <= rx1 - rx0; c += blockDim.x) s_src[r * a.rw + c] = p[(long)r * a.W + c];
+    __syncthreads();
+    const int ox = ox0 + threadIdx.x * 4;
+    const int oy = oy0 + threadIdx.y;
+    if (ox >= a.OW || oy >= a.OH) return;
+    int y0, y1;
+    float ly;
+    resize_src(oy, a.sy, a.ch, a.align, y0, y1, ly);
+    const float hy = 1.f - ly;
+    const float* r0 = s_src + (y0 - ry0) * a.rw - rx0;
+    const float* r1 = s_src + (y1 - ry0) * a.rw - rx0;
+    f32x4r o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int x0, x1;
+        float lx;
+        resize_src(ox + k, a.sx, a.cw, a.align, x0, x1, lx);
+        const float hx = 1.f - lx;
+        o[k] = hy * (hx * r0[x0] + lx * r0[x1]) + ly * (hx * r1[x0] + lx * r1[x1]);
+    }
+    *(f32x4r*)(y + (nc * a.OH + oy) * a.OW + ox) = o;
+}
+
 static void resize_scales(ResizeArgs& a) {
     if (a.nearest) {
         a.sy = (float)a.ch / (float)a.OH;
@@ -153,6 +197,17 @@ extern "C" int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t 
     // 256-thread workgroups: (columns, rows) -- one-wave workgroups are dispatch-rate bound
     if (OW % 4 == 0 && (((uintptr_t)y) & 15) == 0) {
         const dim3 b = block2d(OW / 4);
+        // source region of one tile of b.x*4 x b.y outputs: outputs*scale + 3 per axis, capped by the crop window
+        long rw = (long)ceilf((float)(b.x * 4) * a.sx) + 3, rh = (long)ceilf((float)b.y * a.sy) + 3;
+        if (rw > cw) rw = cw;
+        if (rh > ch) rh = ch;
+        if (!nearest && a.sx <= 2.5f && a.sy <= 2.5f && rw * rh * 4 <= 48 * 1024) {
+            a.rw = (int)rw;
+            a.rh = (int)rh;
+            hipLaunchKernelGGL(resize_fwd_lds_kernel, dim3(jaf_cdiv(OW / 4, b.x), jaf_cdiv(OH, b.y), N * C), b, (size_t)(rw * rh * 4),
+                               (hipStream_t)s, x, y, a);
+            return jaf_launch_status();
+        }
         hipLaunchKernelGGL(resize_fwd_kernel<4>, dim3(jaf_cdiv(OW / 4, b.x), jaf_cdiv(OH, b.y), N * C), b, 0, (hipStream_t)s, x, y, a);
     } else {
         const dim3 b = block2d(OW);
