@@ -83,7 +83,8 @@ struct ResizeArgs {
     int N, C, H, W, y0, x0, ch, cw, OH, OW;
     float sy, sx;
     int align, nearest;
-    int rw, rh;        // resize_bwd_lds_kernel: pitch and rows of the staged dy region (floats)
+    int rw, rh;        // LDS kernels: pitch and rows of the staged region (floats)
+    float inv_sy, inv_sx;
 };
 
 __device__ __forceinline__ void resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
@@ -298,7 +299,7 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
 // Same adjoint with the candidate region of the workgroup's tile staged in LDS first: the direct kernel issues
 // ~36 overlapping 4-byte global loads per input pixel (each dy element is fetched by 4-9 lanes) and runs at
 // 1.4 TB/s; here every dy element is loaded once per tile, coalesced, and the taps read LDS (with the 4-instruction
-// align_corners weights: 161 -> 136 us per launch on average; the rest is the ~40 taps per input pixel themselves).
+// align_corners weights and the exact 5x5 support of <= 2.2x up-sampling: 161 -> 124 us per launch on average).
 // Block (tx, ty) = one tile of tx x ty input pixels of one plane; the region is the union of the candidates of
 // the tile's first and last pixel (candidate ranges are monotonic in the pixel index).
 __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a) {
@@ -314,9 +315,9 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
     if (ixl > a.cw - 1) ixl = a.cw - 1;
     if (iyl > a.ch - 1) iyl = a.ch - 1;
     const bool any = (ixf <= ixl) && (iyf <= iyl);
-    int rx0 = 0, ry0 = 0;
+    int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
     if (any) {
-        int lo, hi, rx1, ry1;
+        int lo, hi;
         resize_cand(ixf, a.sx, a.OW, a.align, rx0, hi);
         resize_cand(ixl, a.sx, a.OW, a.align, lo, rx1);
         resize_cand(iyf, a.sy, a.OH, a.align, ry0, hi);
@@ -334,6 +335,31 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
     float acc = 0.f;
     if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
         int ylo, yhi, xlo, xhi;
+        if (a.align && a.sx >= 0.45f && a.sy >= 0.45f) {
+            // up-sampling by <= 2.2x with align_corners (every decoder of the path): the tent max(0, 1 - |s*o - i|)
+            // is non-zero on at most 5 consecutive outputs per axis, o > (i-1)/s: 25 taps, no candidate margins.
+            // Taps past the support carry weight 0; their index is clamped into the staged region.
+            int xl = (int)floorf((float)(ix - 1) * a.inv_sx) + 1, yl = (int)floorf((float)(iy - 1) * a.inv_sy) + 1;
+            if (xl < rx0) xl = rx0;
+            if (yl < ry0) yl = ry0;
+            float wx[5];
+            int cx[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int o = xl + j;
+                wx[j] = o <= rx1 ? fmaxf(0.f, 1.f - fabsf(a.sx * (float)o - (float)ix)) : 0.f;
+                cx[j] = (o <= rx1 ? o : rx1) - rx0;
+            }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int o = yl + r;
+                const float wy = o <= ry1 ? fmaxf(0.f, 1.f - fabsf(a.sy * (float)o - (float)iy)) : 0.f;
+                const float* row = s_reg + ((o <= ry1 ? o : ry1) - ry0) * a.rw;
+                acc += wy * ((wx[0] * row[cx[0]] + wx[1] * row[cx[1]]) + (wx[2] * row[cx[2]] + wx[3] * row[cx[3]]) + wx[4] * row[cx[4]]);
+            }
+            dx[(nc * a.H + gy) * a.W + gx] = acc;
+            return;
+        }
         resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
         resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
         if (xhi - xlo + 1 <= RB_MAXC) {
@@ -376,7 +402,7 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, 0};
     resize_scales(a);
     JAF_REQUIRE(H <= 65535 && (long)N * C <= 65535);
-    const dim3 b = block2d(W);      // (squarer 32x8 tiles stage fewer halo rows but measured 8 % slower)
+    const dim3 b = block2d(W);      // (squarer 32x8 / 64x4 tiles stage fewer halo rows but measured 6-8 % slower)
     // candidate region of one (b.x, b.y) tile: (pixels + 1) / scale + 4 per axis (resize_cand), capped by the image
     long rw = a.sx > 0.f ? (long)ceilf(((float)b.x + 1.f) / a.sx) + 4 : OW;
     long rh = a.sy > 0.f ? (long)ceilf(((float)b.y + 1.f) / a.sy) + 4 : OH;
@@ -385,6 +411,8 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     if (rw * rh * 4 <= 48 * 1024) {
         a.rw = (int)rw;
         a.rh = (int)rh;
+        a.inv_sx = a.sx > 0.f ? 1.0f / a.sx : 0.f;
+        a.inv_sy = a.sy > 0.f ? 1.0f / a.sy : 0.f;
         hipLaunchKernelGGL(resize_bwd_lds_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C), b, (size_t)(rw * rh * 4),
                            (hipStream_t)s, dy, dx, a);
     } else {
