@@ -85,6 +85,7 @@ struct ResizeArgs {
     int align, nearest;
     int rw, rh;        // LDS kernels: pitch and rows of the staged region (floats)
     float inv_sy, inv_sx;
+    int vec;           // resize_bwd_lds_kernel: 16-byte staging allowed
 };
 
 __device__ __forceinline__ void resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
@@ -322,12 +323,33 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
         resize_cand(ixl, a.sx, a.OW, a.align, lo, rx1);
         resize_cand(iyf, a.sy, a.OH, a.align, ry0, hi);
         resize_cand(iyl, a.sy, a.OH, a.align, lo, ry1);
-        if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;      // never taken: a.rw / a.rh bound the region (host)
-        if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
         const float* p = dy + nc * a.OH * a.OW;
-        for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
-            for (int c = threadIdx.x; c <= rx1 - rx0; c += blockDim.x)
-                s_reg[r * a.rw + c] = p[(ry0 + r) * a.OW + rx0 + c];
+        if (a.vec) {
+            // 16-byte staging: the region starts on a multiple of 4 columns (OW % 4 == 0, pitch a.rw % 4 == 0);
+            // three rows per pass so that three independent loads are in flight before the first LDS write
+            rx0 &= ~3;
+            if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;  // never taken: a.rw / a.rh bound the region (host)
+            if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
+            const int w4 = (rx1 - rx0 + 4) >> 2, nr = ry1 - ry0 + 1, sy3 = blockDim.y;
+            for (int c4 = threadIdx.x; c4 < w4; c4 += blockDim.x) {
+                for (int r = threadIdx.y; r < nr; r += 3 * sy3) {
+                    const f32x4r z = {0.f, 0.f, 0.f, 0.f};
+                    const float* q = p + (long)(ry0 + r) * a.OW + rx0 + 4 * c4;
+                    const f32x4r v0 = *(const f32x4r*)q;
+                    const f32x4r v1 = (r + sy3 < nr) ? *(const f32x4r*)(q + (long)sy3 * a.OW) : z;
+                    const f32x4r v2 = (r + 2 * sy3 < nr) ? *(const f32x4r*)(q + 2L * sy3 * a.OW) : z;
+                    *(f32x4r*)(s_reg + r * a.rw + 4 * c4) = v0;
+                    if (r + sy3 < nr) *(f32x4r*)(s_reg + (r + sy3) * a.rw + 4 * c4) = v1;
+                    if (r + 2 * sy3 < nr) *(f32x4r*)(s_reg + (r + 2 * sy3) * a.rw + 4 * c4) = v2;
+                }
+            }
+        } else {
+            if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;
+            if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
+            for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
+                for (int c = threadIdx.x; c <= rx1 - rx0; c += blockDim.x)
+                    s_reg[r * a.rw + c] = p[(ry0 + r) * a.OW + rx0 + c];
+        }
     }
     __syncthreads();
     if (gx >= a.W || gy >= a.H) return;
@@ -408,9 +430,12 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     long rh = a.sy > 0.f ? (long)ceilf(((float)b.y + 1.f) / a.sy) + 4 : OH;
     if (rw > OW) rw = OW;
     if (rh > OH) rh = OH;
+    const bool vec = (OW % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
+    if (vec) rw = (rw + 3 + 3) / 4 * 4;        // start rounded down to a multiple of 4, pitch a multiple of 4
     if (rw * rh * 4 <= 48 * 1024) {
         a.rw = (int)rw;
         a.rh = (int)rh;
+        a.vec = vec ? 1 : 0;
         a.inv_sx = a.sx > 0.f ? 1.0f / a.sx : 0.f;
         a.inv_sy = a.sy > 0.f ? 1.0f / a.sy : 0.f;
         hipLaunchKernelGGL(resize_bwd_lds_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C), b, (size_t)(rw * rh * 4),
