@@ -85,7 +85,7 @@ struct ResizeArgs {
     int align, nearest;
     int rw, rh;        // LDS kernels: pitch and rows of the staged region (floats)
     float inv_sy, inv_sx;
-    int vec;           // resize_bwd_lds_kernel: 16-byte staging allowed
+    int vec;           // LDS kernels: 16-byte staging allowed
 };
 
 __device__ __forceinline__ void resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
@@ -148,11 +148,19 @@ __global__ void resize_fwd_lds_kernel(const float* __restrict__ x, float* __rest
     resize_src(oxl, a.sx, a.cw, a.align, t0, rx1, l);
     resize_src(oy0, a.sy, a.ch, a.align, ry0, t1, l);
     resize_src(oyl, a.sy, a.ch, a.align, t0, ry1, l);
+    if (a.vec) rx0 &= ~3;                                    // 16-byte staging (W % 4 == 0, x0 % 4 == 0, pitch % 4 == 0)
     if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;          // never taken: a.rw / a.rh bound the region (host)
     if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
     const float* p = x + nc * a.H * a.W + (long)(a.y0 + ry0) * a.W + a.x0 + rx0;
-    for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
-        for (int c = threadIdx.x; c <= rx1 - rx0; c += blockDim.x) s_src[r * a.rw + c] = p[(long)r * a.W + c];
+    if (a.vec) {
+        const int w4 = (rx1 - rx0 + 4) >> 2;
+        for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
+            for (int c4 = threadIdx.x; c4 < w4; c4 += blockDim.x)
+                *(f32x4r*)(s_src + r * a.rw + 4 * c4) = *(const f32x4r*)(p + (long)r * a.W + 4 * c4);
+    } else {
+        for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
+            for (int c = threadIdx.x; c <= rx1 - rx0; c += blockDim.x) s_src[r * a.rw + c] = p[(long)r * a.W + c];
+    }
     __syncthreads();
     const int ox = ox0 + threadIdx.x * 4;
     const int oy = oy0 + threadIdx.y;
@@ -203,9 +211,13 @@ extern "C" int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t 
         long rw = (long)ceilf((float)(b.x * 4) * a.sx) + 3, rh = (long)ceilf((float)b.y * a.sy) + 3;
         if (rw > cw) rw = cw;
         if (rh > ch) rh = ch;
+        // 16-byte staging needs whole 4-column groups inside the plane: W % 4 == 0 and the crop window starting on one
+        const bool vec = (W % 4 == 0) && (x0 % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+        if (vec) rw = (rw + 3 + 3) / 4 * 4;
         if (!nearest && a.sx <= 2.5f && a.sy <= 2.5f && rw * rh * 4 <= 48 * 1024) {
             a.rw = (int)rw;
             a.rh = (int)rh;
+            a.vec = vec ? 1 : 0;
             hipLaunchKernelGGL(resize_fwd_lds_kernel, dim3(jaf_cdiv(OW / 4, b.x), jaf_cdiv(OH, b.y), N * C), b, (size_t)(rw * rh * 4),
                                (hipStream_t)s, x, y, a);
             return jaf_launch_status();
