@@ -138,14 +138,19 @@ extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, con
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     const long nz = (long)d->N * d->G * a.ngroups8;
     if (nz > 65535 || d->H > 65535) return JAF_EUNSUPPORTED;
-    const bool v4 = (d->W % 4 == 0) && ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
+    const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
+    // packing is elementwise over the plane: when only H*W is a multiple of 4 (50x50 levels) the plane is walked
+    // as one row so that the 16-byte path still applies
+    if (al && d->W % 4 != 0 && ((long)d->H * d->W) % 4 == 0 && (long)d->H * d->W < (1L << 30)) { a.d.W = d->H * d->W; a.d.H = 1; }
+    const int H = a.d.H, W = a.d.W;
+    const bool v4 = (W % 4 == 0) && al;
     // 256-thread workgroups: tx lanes along x (a power of two covering the row when it is short), ty rows
-    const int wx = v4 ? d->W / 4 : d->W;
-    int tx = 64;
+    const int wx = v4 ? W / 4 : W;
+    int tx = H == 1 ? 256 : 64;
     while (tx > 1 && (tx >> 1) >= wx) tx >>= 1;
     if (tx < 8) tx = 8;
     const int ty = 256 / tx;
-    const dim3 grid(jaf_cdiv(wx, tx), jaf_cdiv(d->H, ty), (unsigned)nz);
+    const dim3 grid(jaf_cdiv(wx, tx), jaf_cdiv(H, ty), (unsigned)nz);
     if (v4) hipLaunchKernelGGL(conv_pack_input_kernel<4>, grid, dim3(tx, ty), 0, (hipStream_t)s, a);
     else hipLaunchKernelGGL(conv_pack_input_kernel<1>, grid, dim3(tx, ty), 0, (hipStream_t)s, a);
     return jaf_launch_status();
@@ -254,12 +259,14 @@ extern "C" int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* 
     JAF_REQUIRE(act == JAF_ACT_NONE || y);
     PackDzArgs a;
     a.dy = dy; a.y = y; a.out = (unsigned char*)packed; a.dz = dz; a.dbias = dbias;
+    const bool al = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
+    if (al && W % 4 != 0 && ((long)H * W) % 4 == 0 && (long)H * W < (1L << 30)) { W = H * W; H = 1; }   // as in jaf_conv2d_pack_input
     a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;
     const long nz = (long)N * G * a.ngroups8;
     if (nz > 65535 || H > 65535) return JAF_EUNSUPPORTED;
-    const bool v4 = (W % 4 == 0) && ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
+    const bool v4 = (W % 4 == 0) && al;
     const int wx = v4 ? W / 4 : W;
-    int tx = 64;
+    int tx = H == 1 ? 256 : 64;
     while (tx > 1 && (tx >> 1) >= wx) tx >>= 1;
     if (tx < 8) tx = 8;
     const int ty = 256 / tx;
