@@ -209,17 +209,61 @@ def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mo
     (the entry holds a weak reference: a new tensor that reuses a freed address must not hit)."""
     ck = (id(weight), weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision, pl.nsteps, pl.plane)
     hit = _PACK_CACHE.get(ck)
-    if hit is not None and hit[0]() is weight:
-        return hit[1]
+    if hit is not None and hit.ref() is weight:
+        if hit.event is not None:        # image refreshed on another stream (refresh_packed_weights)
+            sid = torch.cuda.current_stream().cuda_stream
+            if sid not in hit.waited:
+                torch.cuda.current_stream().wait_event(hit.event)
+                hit.waited.add(sid)
+        return hit.buf
     if len(_PACK_CACHE) > 4096:
         _PACK_CACHE.clear()
         _PACK_KEYS_BY_ID.clear()
     buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
     check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
           "jaf_conv2d_pack")
-    _PACK_CACHE[ck] = (weakref.ref(weight), buf)
+    _PACK_CACHE[ck] = _PackEntry(weight, buf, d, pl, mode, w_rows_tot)
     _PACK_KEYS_BY_ID.setdefault(id(weight), []).append(ck)
     return buf
+
+
+class _PackEntry:
+    """One cached packed-weight image and what it takes to make it again in place."""
+    __slots__ = ("ref", "buf", "d", "pl", "mode", "rows", "event", "waited")
+
+    def __init__(self, weight, buf, d, pl, mode, rows):
+        self.ref, self.buf = weakref.ref(weight), buf
+        self.d, self.pl = type(d).from_buffer_copy(d), type(pl).from_buffer_copy(pl)
+        self.mode, self.rows = mode, rows
+        self.event, self.waited = None, set()
+
+
+def refresh_packed_weights(params) -> None:
+    """Re-packs, into the same buffers, every cached image of `params` right after the optimiser wrote them, on
+    a side stream: the ~230 tiny pack launches per step leave the dependent chain (they used to run one by one
+    in front of the first convolution that needs each image) and the next use only waits for an event."""
+    todo = []
+    for t in params:
+        for ck in _PACK_KEYS_BY_ID.get(id(t), ()):
+            e = _PACK_CACHE.get(ck)
+            if e is not None and e.ref() is t:
+                todo.append((t, e))
+    if not todo:
+        return
+    main = torch.cuda.current_stream()
+    st = aux_stream(2)
+    st.wait_stream(main)                      # after the optimiser kernel and every reader of the old images
+    L = lib()
+    with torch.cuda.stream(st):
+        for t, e in todo:
+            check(L.jaf_conv2d_pack(_s(), ctypes.byref(e.d), ctypes.byref(e.pl), e.mode, _p(t), e.rows, _p(e.buf)),
+                  "jaf_conv2d_pack")
+        ev = None
+        if st != main:
+            ev = torch.cuda.Event()
+            ev.record(st)
+    for _, e in todo:
+        e.event, e.waited = ev, set()
 
 
 def _out_size(n, k, s, p):
@@ -239,7 +283,7 @@ def set_serial_streams(flag: bool) -> bool:
 
 def aux_stream(which: int = 0) -> "torch.cuda.Stream":
     """One of a few long-lived side HIP streams of the current device (0: clip preparation, 1: weight
-    gradients)."""
+    gradients, 2: weight re-packing)."""
     cur = torch.cuda.current_stream()
     if _SERIAL_STREAMS:
         return cur
@@ -1084,14 +1128,18 @@ def linear(x, w, b, act=ACT_NONE, slope=0.0):
     return _LinearFn.apply(_chk(x, "linear x"), _chk(w, "linear w"), _chk(b, "linear b"), act, float(slope))
 
 
-def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, params=None):
+def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, params=None, refresh: bool = False):
     """In-place torch.optim.Adam update of a flat parameter buffer.  `params`: the parameter tensors that
-    view into it (their packed-weight images are dropped; None drops every cached image)."""
+    view into it (their packed-weight images are dropped, or with `refresh` re-made on a side stream;
+    None drops every cached image)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, "adam " + n)
     check(lib().jaf_adam_step(_s(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step),
           "jaf_adam_step")
-    invalidate_packed_weights(params)
+    if refresh and params is not None:
+        refresh_packed_weights(params)
+    else:
+        invalidate_packed_weights(params)
 
 
 def invalidate_packed_weights(params=None):

@@ -59,7 +59,7 @@ class FlatParams:
     def adam(self, lr: float):
         ops.join_wgrad_stream()         # weight gradients may have been written on the side stream
         self.step_count += 1
-        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params)
+        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params, refresh=True)
 
 
 class Stage4Models(nn.Module):
