@@ -252,6 +252,7 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
     const long items = (long)d->N * a.tiles_x * a.tiles_p;
     const long byz = (long)a.ncolblocks * a.mblocks * d->G;
     long nsplit = (2048 + byz - 1) / byz;
+    if (nsplit > JAF_WGRAD_MAX_SPLIT) nsplit = JAF_WGRAD_MAX_SPLIT;   // same-address atomic contention (conv_internal.h)
     if (nsplit > items) nsplit = items;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = (int)nsplit;
