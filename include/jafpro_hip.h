@@ -209,7 +209,7 @@ int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, 
  * dgamma/dbeta are accumulated (+=).                                                            */
 int jaf_layernorm_lrelu_bwd(jaf_stream_t s, const float* dy, const float* x, const float* stats,
                             const float* gamma, const float* beta, float* dx, float* dgamma,
-                            float* dbeta, double* workspace /* 2*N doubles */, int32_t N,
+                            float* dbeta, double* workspace /* 32*N doubles */, int32_t N,
                             int32_t C, int32_t HW, float slope, float eps);
 
 /* BatchNorm2d in training mode (src/flow_net.py:13-51, src/networks.py:369-390; eps 1e-5,

@@ -142,7 +142,9 @@ extern "C" int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const flo
 }
 
 // pass A: per (c, n) block: a = sum dz, b = sum dz*xhat ; dbeta[c] += a, dgamma[c] += b,
-// ws[2n] += gamma_c*a (S1), ws[2n+1] += gamma_c*b (S2).
+// ws[n][c % 16][0] += gamma_c*a (S1), ws[n][c % 16][1] += gamma_c*b (S2): the C workgroups of one image spread their
+// fp64 atomics over 16 slots (one address per image cost a ~21 us floor per launch), folded by ln_bwd_fold_kernel.
+#define LN_BWD_SLOTS 16
 template <int V>
 __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const float* stats, const float* gamma,
                                      const float* beta, float* dgamma, float* dbeta, double* ws, int C, int HW,
@@ -189,9 +191,21 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
         const double bb = rb[0] + rb[1] + rb[2] + rb[3];
         atomicAdd(&dbeta[c], (float)a);
         atomicAdd(&dgamma[c], (float)bb);
-        atomicAdd(&ws[2 * n], (double)g * a);
-        atomicAdd(&ws[2 * n + 1], (double)g * bb);
+        double* w = ws + ((long)n * LN_BWD_SLOTS + (c & (LN_BWD_SLOTS - 1))) * 2;
+        atomicAdd(w, (double)g * a);
+        atomicAdd(w + 1, (double)g * bb);
     }
+}
+
+// ws[n][0] = sum over the slots (in place): what ln_bwd_apply_kernel reads
+__global__ void ln_bwd_fold_kernel(double* ws, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double* w = ws + (long)n * LN_BWD_SLOTS * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < LN_BWD_SLOTS; ++k) { s1 += w[2 * k]; s2 += w[2 * k + 1]; }
+    w[0] = s1;
+    w[1] = s2;
 }
 
 // grid (pixel blocks, C, N)
@@ -206,9 +220,10 @@ __global__ void ln_bwd_apply_kernel(const float* dy, const float* x, const float
     const double M = (double)C * (double)HW;
     const float mean = stats[2 * n], r = stats[2 * n + 1];
     const float sigma = 1.0f / r - eps;
-    const float m1 = (float)(ws[2 * n] / M);
+    const double* w = ws + (long)n * LN_BWD_SLOTS * 2;        // folded sums (ln_bwd_fold_kernel)
+    const float m1 = (float)(w[0] / M);
     // S2 / ((M-1) * sigma * r)
-    const float kk = (sigma > 0.f) ? (float)(ws[2 * n + 1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
+    const float kk = (sigma > 0.f) ? (float)(w[1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
     const float g = gamma[c], b = beta[c];
     if (V == 4) {
         const f32x4 xv = *(const f32x4*)(x + e), dv = *(const f32x4*)(dy + e);
@@ -236,16 +251,18 @@ extern "C" int jaf_layernorm_lrelu_bwd(jaf_stream_t s_, const float* dy, const f
     JAF_REQUIRE(dy && x && stats && gamma && beta && dx && dgamma && dbeta && workspace);
     JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535 && C <= 65535);
     hipStream_t s = (hipStream_t)s_;
-    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * N, s);
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * LN_BWD_SLOTS * N, s);
     if (e != hipSuccess) return (int)e;
     if ((HW % 4 == 0) && al16(dy, x, dx)) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel<4>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
                            workspace, C, HW, slope);
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
         hipLaunchKernelGGL(ln_bwd_apply_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
                            beta, workspace, dx, C, HW, slope, eps);
     } else {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel<1>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
                            workspace, C, HW, slope);
+        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
         hipLaunchKernelGGL(ln_bwd_apply_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
                            beta, workspace, dx, C, HW, slope, eps);
     }

@@ -741,7 +741,7 @@ class _LayerNormLReLUFn(Function):
         gi, bi = _grad_inplace(gamma), _grad_inplace(beta)
         dgamma = gamma.grad if gi else torch.zeros_like(gamma)
         dbeta = beta.grad if bi else torch.zeros_like(beta)
-        ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
+        ws = torch.empty(32 * N, device=x.device, dtype=torch.float64)      # [N][16 slots][2], include/jafpro_hip.h
         check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
                                             _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
               "jaf_layernorm_lrelu_bwd")
