@@ -252,7 +252,8 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
     const long items = (long)d->N * a.tiles_x * a.tiles_p;
     const long byz = (long)a.ncolblocks * a.mblocks * d->G;
     long nsplit = (2048 + byz - 1) / byz;
-    if (nsplit > JAF_WGRAD_MAX_SPLIT) nsplit = JAF_WGRAD_MAX_SPLIT;   // same-address atomic contention (conv_internal.h)
+    if (nsplit > 512) nsplit = 512;      // same-address atomic contention; this kernel's tiles are small: 96 / 256 / 512 / 1024
+                                         // splits measured 980 / 705 / 677 / 692 us over the two 7x7 layers of the propagater
     if (nsplit > items) nsplit = items;
     if (nsplit < 1) nsplit = 1;
     a.nsplit = (int)nsplit;
