@@ -8,6 +8,23 @@
 // set); measured on the discriminator's 6->32 layer: 768 splits 197 us, 96 splits ~50 us.
 #define JAF_WGRAD_MAX_SPLIT 96
 
+// Pixel splits of a weight-gradient launch.  items = (image, pixel tile) pairs, outblocks = workgroups per split,
+// dw_floats = size of the whole dW.  A split shortens every workgroup's serial walk over its items but adds one
+// atomic pass over dW (device-wide ~3e11 float atomics/s): deep layers (512 channels at 4x4..32x32: 8-64 items,
+// 2-4 M floats of dW) want 1-2 splits, the 256x256 layers (4096 items) want as many as fill the chip.
+static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, double t_item = 2.5e-6) {
+    const double atomics_per_s = 3e11, slots = 768.0;
+    long best = 1;
+    double best_t = 1e30;
+    const long hi = items < JAF_WGRAD_MAX_SPLIT ? items : JAF_WGRAD_MAX_SPLIT;
+    for (long ns = 1; ns <= hi; ++ns) {
+        const double waves = (double)(outblocks * ns) / slots;
+        const double t = (double)((items + ns - 1) / ns) * t_item * (waves > 1.0 ? waves : 1.0) + (double)ns * (double)dw_floats / atomics_per_s;
+        if (t < best_t * 0.999) { best_t = t; best = ns; }
+    }
+    return best;
+}
+
 int jafb_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
               int32_t w_rows_tot, void* packed);

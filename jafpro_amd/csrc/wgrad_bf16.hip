@@ -336,10 +336,7 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    long nsplit = (768 + outblocks - 1) / outblocks;     // each split costs an atomic pass over dW + an epilogue
-    if (nsplit > JAF_WGRAD_MAX_SPLIT) nsplit = JAF_WGRAD_MAX_SPLIT;   // same-address atomic contention (conv_internal.h)
-    if (nsplit > items) nsplit = items;
-    if (nsplit < 1) nsplit = 1;
+    const long nsplit = jaf_wgrad_nsplit(items, outblocks, (long)d->G * d->Cout * d->Cin * 9, 5e-6);   // fp32-input staging: slower items
     a.nsplit = (int)nsplit;
     const long nblk = outblocks * nsplit;
     JAF_REQUIRE(nblk <= 0x7fffffffL);

@@ -304,15 +304,9 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    const long tgt = 768;         // workgroups per launch (3 per CU)
-    // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of
-    // atomic traffic per launch at 1536 workgroups): large gradients get just enough splits to fill the chip
-    long nsplit = (tgt + outblocks - 1) / outblocks;
-    // ... and every workgroup of one (co, ci) block adds to the SAME dW addresses: beyond ~100-way contention the
-    // atomics serialise and cost more than the pixels they split (6->32 first discriminator layer: 768 splits 197 us)
-    if (nsplit > JAF_WGRAD_MAX_SPLIT) nsplit = JAF_WGRAD_MAX_SPLIT;
-    if (nsplit > items) nsplit = items;
-    if (nsplit < 1) nsplit = 1;
+    // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of atomic
+    // traffic per launch at 1536 workgroups) and contends for the same addresses: see jaf_wgrad_nsplit
+    const long nsplit = jaf_wgrad_nsplit(items, outblocks, (long)d->G * d->Cout * d->Cin * KS * KS);
     a.nsplit = (int)nsplit;
     const long nblk = outblocks * nsplit;
     JAF_REQUIRE(nblk <= 0x7fffffffL);
