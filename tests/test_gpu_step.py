@@ -279,3 +279,32 @@ def test_second_step_uses_updated_weights(mode, tol):
     finally:
         ops.set_precision(prev)
     assert torch.equal(g_cached, g_fresh)
+
+
+def test_config5_forward_at_512():
+    """BASELINE config 5 geometry (512x512 frames; the part textures stay 200x200): the reference cannot run it
+    (SMPLRenderer(image_size=256) and the discriminator's Linear are hard-coded), so there is no
+    oracle -- the forward chain must run at 512 in both arithmetic modes and the modes must agree with each
+    other within the bf16 mode's bars."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.step import Stage4Models, generator_forward, _to_dev
+    _, fidx = synth.body_mesh()
+    M = Stage4Models(fidx, image_size=512)
+    for i, m in enumerate((M.Accu_model, M.inpaint_model, M.bg_model, M.refine_model, M.propagater)):
+        synth.load_synth(m, 201 + i)
+    M = M.cuda()
+    M.set_train_modes()
+    b = _to_dev(synth.stage4_batch(500, 2, S=512), "cuda")
+    outs = {}
+    for mode in ("f32", "bf16"):
+        prev = ops.set_precision(mode)
+        try:
+            with torch.no_grad():
+                outs[mode] = generator_forward(M, b, (0, 1, 2, 3), 0)
+        finally:
+            ops.set_precision(prev)
+    for k in ("tsf_image", "bg_output", "refine_output", "final_output"):
+        assert outs["f32"][k].shape[-2:] == (512, 512) and torch.isfinite(outs["f32"][k]).all(), k
+    assert torch.equal(outs["f32"]["tsf_image"], outs["bf16"]["tsf_image"])      # rasteriser / flow warp: no matrix cores
+    assert (outs["f32"]["final_output"] - outs["bf16"]["final_output"]).abs().max().item() <= 1e-1
+    assert rel_l2(outs["bf16"]["final_output"], outs["f32"]["final_output"]) <= 1.5e-2
