@@ -258,6 +258,15 @@ class Stage4Trainer:
         face_pred, face_real, face_IUV = face_crops(final, target, b["tgt_IUV"], b["face_bbox"])
         src0 = b["src_img"][:, 0].contiguous()
         face_pred_d = face_pred.detach()
+        # The image discriminator's Linear assumes 256x256 inputs (src/networks.py:409).  BASELINE config 5 (512x512, no
+        # reference implementation) feeds it 2x average-pooled images; at 256 `dview` is the identity.
+        if M.image_size == 512:
+            dview = lambda t: ops.avg_pool(t, 2, 2, 0)
+        elif M.image_size == 256:
+            dview = lambda t: t
+        else:
+            raise RuntimeError("train_step supports image_size 256 (reference) and 512 (config 5), got %d" % M.image_size)
+        target_d, src0_d = dview(target), dview(src0)
         # ---- face discriminator, one update (:362-374)
         F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
         F_errD_real.backward()
@@ -268,16 +277,17 @@ class Stage4Trainer:
         mark("face-D update")
         # ---- image discriminator, three updates on accumulating grads (:380-394, F10)
         final_d = final.detach()
+        final_dd = dview(final_d)
         for _ in range(3):
-            errD_real = ops.bce_loss(M.discriminator([target, src0]), 1.0)
+            errD_real = ops.bce_loss(M.discriminator([target_d, src0_d]), 1.0)
             errD_real.backward()
-            errD_fake = ops.bce_loss(M.discriminator([final_d, src0]), 0.0)
+            errD_fake = ops.bce_loss(M.discriminator([final_dd, src0_d]), 0.0)
             errD_fake.backward()
             self._reduce(["D"])
             self.flat["D"].adam(self.lrs["D"])
         mark("D x3 updates")
         # ---- generator (:398-413)
-        errG = ops.bce_loss(M.discriminator([final, src0]), 1.0)
+        errG = ops.bce_loss(M.discriminator([dview(final), src0_d]), 1.0)
         F_errG = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0)
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
         if next_batch is not None:      # overlaps with the VGG + GAN loss backward below

@@ -308,3 +308,28 @@ def test_config5_forward_at_512():
     assert torch.equal(outs["f32"]["tsf_image"], outs["bf16"]["tsf_image"])      # rasteriser / flow warp: no matrix cores
     assert (outs["f32"]["final_output"] - outs["bf16"]["final_output"]).abs().max().item() <= 1e-1
     assert rel_l2(outs["bf16"]["final_output"], outs["f32"]["final_output"]) <= 1.5e-2
+
+
+def test_config5_train_step_at_512():
+    """One full bf16 train step at 512x512 (B=1): every loss finite, every trainable module updated once (D three times)."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.step import Stage4Models, Stage4Trainer, _to_dev
+    _, fidx = synth.body_mesh()
+    M = Stage4Models(fidx, image_size=512)
+    mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
+            "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
+    for k, m in mods.items():
+        synth.load_synth(m, SEEDS[k])
+    M = M.cuda()
+    tr = Stage4Trainer(M)
+    b = _to_dev(synth.stage4_batch(501, 1, S=512), "cuda")
+    prev = ops.set_precision("bf16")
+    try:
+        out = tr.train_step(b)
+    finally:
+        ops.set_precision(prev)
+    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
+        assert torch.isfinite(out[k]).all(), k
+    assert out["final_output"].shape == (1, 3, 512, 512)
+    for name in ("accu", "inpaint", "refine", "flow", "D", "face"):
+        assert tr.flat[name].step_count == (3 if name == "D" else 1)
