@@ -27,10 +27,10 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0}
 SEEDS = {"accu": 1301, "inpaint": 1302, "bg": 1303, "refine": 1304, "flow": 1305, "D": 1306, "face": 1307, "vgg": 1308}
 
 
-def build_models(fidx):
+def build_models(fidx, image_size=256):
     from jafpro_amd import synth
     from jafpro_amd.step import Stage4Models
-    M = Stage4Models(fidx)
+    M = Stage4Models(fidx, image_size=image_size)
     mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
             "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
     for k, m in mods.items():
@@ -104,6 +104,9 @@ def main():
                     help="matrix-core arithmetic of the convolutions (tensors stay fp32 in HBM)")
     ap.add_argument("--parity-mode-steps", type=int, default=3,
                     help="N=1 only: also time this many steps in the bf16x3 parity-grade mode (0 = skip)")
+    ap.add_argument("--size", type=int, default=256, choices=[256, 512],
+                    help="frame size: 256 = the BASELINE metric's configuration (configs[2]); 512 = configs[4] geometry "
+                         "(no reference implementation; throughput only, no cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each clip inside its own step instead of one step ahead")
@@ -120,7 +123,7 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     # CPU baseline first (rank 0, N=1), before this process initialises the GPU
     cpu_result = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.size == 256:
         from jafpro_amd import synth as _synth
         _, _fidx = _synth.body_mesh()
         _M, _mods = build_models(_fidx)
@@ -147,11 +150,14 @@ def main():
     ops.set_precision(args.precision)
     ops.set_serial_streams(bool(args.serial_streams))
     _, fidx = synth.body_mesh()
-    M, mods = build_models(fidx)
+    M, mods = build_models(fidx, args.size)
     M = M.cuda()
     trainer = Stage4Trainer(M, reducer=reducer)
     B = args.batch
-    batch = _to_dev(synth.stage4_batch(1300 + rank, B), "cuda")       # weak scaling: B per GPU fixed
+    batch = _to_dev(synth.stage4_batch(1300 + rank, B, S=args.size), "cuda")       # weak scaling: B per GPU fixed
+    # algorithmic GFLOP per sample; at 512 the CRN / propagater / VGG terms scale by 4, the texture
+    # networks stay at 200x200 and the image discriminator sees 256x256 (pooled)
+    gflop_per_sample = 2278.8 if args.size == 256 else 6390.3
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,16 +185,17 @@ def main():
     frames_per_s = world * B * args.steps / elapsed
 
     result = {
-        "metric": "train-step frames/sec, 256x256 30-frame clips, stage-4",
+        "metric": "train-step frames/sec, %dx%d 30-frame clips, stage-4" % (args.size, args.size),
         "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "stage-4 full train step (G fwd+bwd, VGG+L1, 3x D, face-D, 6x Adam), "
-                               "B=%d/GPU, T=4 refs, 256x256, 1 target frame/sample (BASELINE configs[2]); "
-                               "%s matrix-core arithmetic, fp32 accumulate, fp32 tensors in HBM" % (B, args.precision),
+                               "B=%d/GPU, T=4 refs, %dx%d, 1 target frame/sample (BASELINE configs[%d]); "
+                               "%s matrix-core arithmetic, fp32 accumulate, fp32 tensors in HBM"
+                               % (B, args.size, args.size, 2 if args.size == 256 else 4, args.precision),
                    "global_batch": world * B, "per_gpu_batch": B, "parallelism": "dp%d" % world,
                    "clips_per_s": frames_per_s / 30.0,
-                   "algorithmic_tflop_per_step": 2.2788 * world * B,
+                   "algorithmic_tflop_per_step": gflop_per_sample / 1e3 * world * B,
                    "loss": float(out["total_loss"].reshape(-1)[0])},
     }
 
@@ -221,7 +228,7 @@ def main():
         try:
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
                 pt = json.load(f)
-            if pt.get("kernel") == name and args.precision == "bf16":
+            if pt.get("kernel") == name and args.precision == "bf16" and args.size == 256:
                 traffic, traffic_src = pt["hbm_bytes_per_launch"], pt["source"]
         except (OSError, ValueError, KeyError):
             pass
