@@ -12,11 +12,12 @@
 // dw_floats = size of the whole dW.  A split shortens every workgroup's serial walk over its items but adds one
 // atomic pass over dW (device-wide ~3e11 float atomics/s): deep layers (512 channels at 4x4..32x32: 8-64 items,
 // 2-4 M floats of dW) want 1-2 splits, the 256x256 layers (4096 items) want as many as fill the chip.
-static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, double t_item = 2.5e-6) {
-    const double atomics_per_s = 3e11, slots = 768.0;
+static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, double t_item = 2.5e-6, double slots = 768.0,
+                                    long max_split = JAF_WGRAD_MAX_SPLIT) {
+    const double atomics_per_s = 3e11;
     long best = 1;
     double best_t = 1e30;
-    const long hi = items < JAF_WGRAD_MAX_SPLIT ? items : JAF_WGRAD_MAX_SPLIT;
+    const long hi = items < max_split ? items : max_split;
     for (long ns = 1; ns <= hi; ++ns) {
         const double waves = (double)(outblocks * ns) / slots;
         const double t = (double)((items + ns - 1) / ns) * t_item * (waves > 1.0 ? waves : 1.0) + (double)ns * (double)dw_floats / atomics_per_s;

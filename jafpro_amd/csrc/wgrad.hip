@@ -251,11 +251,10 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_p;
     const long byz = (long)a.ncolblocks * a.mblocks * d->G;
-    long nsplit = (2048 + byz - 1) / byz;
-    if (nsplit > 512) nsplit = 512;      // same-address atomic contention; this kernel's tiles are small: 96 / 256 / 512 / 1024
-                                         // splits measured 980 / 705 / 677 / 692 us over the two 7x7 layers of the propagater
-    if (nsplit > items) nsplit = items;
-    if (nsplit < 1) nsplit = 1;
+    // fp32 tiles are small (one 16-column block per workgroup): more workgroup slots and up to 512 splits (96 / 256 /
+    // 512 / 1024 splits measured 980 / 705 / 677 / 692 us over the two 7x7 layers of the propagater); deep layers
+    // with a huge dW still want few splits (jaf_wgrad_nsplit)
+    const long nsplit = jaf_wgrad_nsplit(items, byz, (long)d->G * d->Cout * d->Cin * KHW, 6e-6, 2048.0, 512);
     a.nsplit = (int)nsplit;
     dim3 grid((unsigned)nsplit, (unsigned)(a.ncolblocks * a.mblocks), (unsigned)d->G);
     JAF_REQUIRE((long)a.ncolblocks * a.mblocks <= 65535 && d->G <= 65535);
