@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ACT_NONE, ACT_SIGMOID
+from .ops import ACT_NONE
 
 
 class _Conv2d(nn.Module):
@@ -108,8 +108,12 @@ class CRN_smaller(nn.Module):
         net_2 = up(self.conv2_decoder([down(sp // 4), pool2, net_3]), sp // 2)
         net_1 = up(self.conv1_decoder([down(sp // 2), pool1, net_2]), sp)
         net = self.decoder([label, net_1])
-        net_final = ops.conv2d(net, self.out_conv.weight, self.out_conv.bias, stride=1, pad=0, act=ACT_NONE)
         if self.fg:
-            fg_mask = ops.conv2d(net, self.fg_conv.weight, self.fg_conv.bias, stride=1, pad=0, act=ACT_SIGMOID)
-            return net_final, fg_mask
-        return net_final
+            # the rgb head (256 -> 3) and the mask head (256 -> 1, sigmoid) read the same 256-channel tensor: one 1x1
+            # convolution with the four output rows stacked packs `net` once and sends ONE gradient back to it
+            # (separately: two packs of a 537 MB tensor, two data gradients and their 537 MB sum, per step at B=8)
+            w = torch.cat([self.out_conv.weight, self.fg_conv.weight], 0)
+            b = torch.cat([self.out_conv.bias, self.fg_conv.bias], 0)
+            y = ops.conv2d(net, w, b, stride=1, pad=0, act=ACT_NONE)
+            return y[:, :3].contiguous(), torch.sigmoid(y[:, 3:4]).contiguous()
+        return ops.conv2d(net, self.out_conv.weight, self.out_conv.bias, stride=1, pad=0, act=ACT_NONE)
