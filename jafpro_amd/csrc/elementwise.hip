@@ -226,27 +226,24 @@ extern "C" int jaf_atlas_to_parts(jaf_stream_t s, const float* atlas, float* par
 }
 
 // out[b, 3p+c, y, x] = tex[...] * (OR_t used[t] && masks[b,t,ay,ax] != 0)
-__global__ void part_mask_mul_kernel(const float* tex, const float* masks, const int* used, float* out,
-                                     int B, int T, int AH, int AW, int P, int PSZ) {
+// grid (x blocks, row blocks, B*P), block (tx, ty): no per-element index decoding
+__global__ void part_mask_mul_kernel(const float* __restrict__ tex, const float* __restrict__ masks, const int* __restrict__ used,
+                                     float* __restrict__ out, int B, int T, int AH, int AW, int P, int PSZ) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= PSZ || y >= PSZ) return;
     const int pcols = AW / PSZ;
-    const long total = (long)B * P * PSZ * PSZ;
-    const long stride = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
-        long t_ = e;
-        const int x = (int)(t_ % PSZ); t_ /= PSZ;
-        const int y = (int)(t_ % PSZ); t_ /= PSZ;
-        const int p = (int)(t_ % P); t_ /= P;
-        const int b = (int)t_;
-        const int ay = (p / pcols) * PSZ + y;
-        const int ax = (p % pcols) * PSZ + x;
-        bool on = false;
-        for (int t = 0; t < T; ++t)
-            on = on || (used[t] && ((unsigned char)masks[(((long)b * T + t) * AH + ay) * AW + ax] != 0));
-        const float mv = on ? 1.f : 0.f;
-        for (int c = 0; c < 3; ++c) {
-            const long i = ((((long)b * P + p) * 3 + c) * PSZ + y) * PSZ + x;
-            out[i] = tex[i] * mv;
-        }
+    const int p = blockIdx.z % P;
+    const int b = blockIdx.z / P;
+    const int ay = (p / pcols) * PSZ + y;
+    const int ax = (p % pcols) * PSZ + x;
+    bool on = false;
+    for (int t = 0; t < T; ++t)
+        on = on || (used[t] && ((unsigned char)masks[(((long)b * T + t) * AH + ay) * AW + ax] != 0));
+    const float mv = on ? 1.f : 0.f;
+    for (int c = 0; c < 3; ++c) {
+        const long i = ((((long)b * P + p) * 3 + c) * PSZ + y) * PSZ + x;
+        out[i] = tex[i] * mv;
     }
 }
 
@@ -254,8 +251,12 @@ extern "C" int jaf_part_mask_mul(jaf_stream_t s, const float* tex, const float* 
                                  float* out, int32_t B, int32_t T, int32_t AH, int32_t AW, int32_t P, int32_t PSZ) {
     JAF_REQUIRE(tex && masks && used && out && B >= 1 && T >= 1 && PSZ >= 1);
     JAF_REQUIRE(AH % PSZ == 0 && AW % PSZ == 0 && (AH / PSZ) * (AW / PSZ) == P);
-    hipLaunchKernelGGL(part_mask_mul_kernel, dim3(jaf_ew_grid((long)B * P * PSZ * PSZ)), dim3(256), 0, (hipStream_t)s,
-                       tex, masks, used, out, B, T, AH, AW, P, PSZ);
+    if ((long)B * P > 65535) return JAF_EUNSUPPORTED;
+    int tx = 64;
+    while (tx > 8 && (tx >> 1) >= PSZ) tx >>= 1;
+    const int ty = 256 / tx;
+    hipLaunchKernelGGL(part_mask_mul_kernel, dim3(jaf_cdiv(PSZ, tx), jaf_cdiv(PSZ, ty), (unsigned)(B * P)), dim3(tx, ty), 0,
+                       (hipStream_t)s, tex, masks, used, out, B, T, AH, AW, P, PSZ);
     return jaf_launch_status();
 }
 
