@@ -199,8 +199,9 @@ int jaf_act_bwd(jaf_stream_t s, const float* dy, const float* y, float* dz, int6
  * stats[n] = {mean, 1/(std+eps)} (float2).                                                      */
 int jaf_layernorm_stats(jaf_stream_t s, const float* x, int32_t N, int64_t chw, float eps,
                         double* workspace /* 2*N doubles */, float* stats /* 2*N */);
-/* stats[n] from sums[n][slot][2] = (sum, sum of squares) accumulated by jaf_conv2d_fwd_packed_stats. */
-int jaf_layernorm_finalize(jaf_stream_t s, const double* sums, int32_t N, int32_t slots, int64_t chw, float eps,
+/* stats[n] from sums[n][slot][2] = (sum, sum of squares) accumulated by jaf_conv2d_fwd_packed_stats; the sums are
+ * set back to zero, so a buffer zeroed once can be handed to the next jaf_conv2d_fwd_packed_stats as it is.       */
+int jaf_layernorm_finalize(jaf_stream_t s, double* sums, int32_t N, int32_t slots, int64_t chw, float eps,
                            float* stats /* 2*N */);
 int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                             const float* beta, float* y, int32_t N, int32_t C, int32_t HW,

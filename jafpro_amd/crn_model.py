@@ -40,6 +40,7 @@ class LayerNorm(nn.Module):
             raise NotImplementedError("the stage-4 CRN always uses the affine LayerNorm")
         self.gamma = nn.Parameter(torch.Tensor(num_features).uniform_())
         self.beta = nn.Parameter(torch.zeros(num_features))
+        self.pre_stats = ops.LNStats()
 
     def forward(self, x, slope: float = 1.0, pre=None):
         """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01 and the statistics
@@ -62,7 +63,7 @@ class ConvBlock(nn.Module):
         """x: tensor or list of tensors (read as their channel concatenation)."""
         for r in range(self.n_repeats):
             conv, ln = self.conv_block[3 * r], self.conv_block[3 * r + 1]
-            st = ops.LNStats()
+            st = ln.pre_stats          # this LayerNorm's own side channel (zeroed once, kept clean by the finalize kernel)
             x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE, ln_stats=st)
             x = ln(x, 0.01, st)
         return x

@@ -65,13 +65,16 @@ __global__ void ln_finalize_kernel(const double* ws, int N, long chw, float eps,
     stats[2 * n + 1] = 1.0f / (stdv + eps);
 }
 
-__global__ void ln_finalize_slots_kernel(const double* ws, int N, int slots, long chw, float eps, float* stats) {
+__global__ void ln_finalize_slots_kernel(double* ws, int N, int slots, long chw, float eps, float* stats) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     double s = 0.0, ss = 0.0;
     for (int k = 0; k < slots; ++k) {
-        s += ws[((long)n * slots + k) * 2];
-        ss += ws[((long)n * slots + k) * 2 + 1];
+        double* w = ws + ((long)n * slots + k) * 2;
+        s += w[0];
+        ss += w[1];
+        w[0] = 0.0;          // left clean for the next accumulation: the caller never has to zero the buffer again
+        w[1] = 0.0;
     }
     const double cnt = (double)chw;
     const double mean = s / cnt;
@@ -82,7 +85,7 @@ __global__ void ln_finalize_slots_kernel(const double* ws, int N, int slots, lon
     stats[2 * n + 1] = 1.0f / (stdv + eps);
 }
 
-extern "C" int jaf_layernorm_finalize(jaf_stream_t s, const double* sums, int32_t N, int32_t slots, int64_t chw, float eps,
+extern "C" int jaf_layernorm_finalize(jaf_stream_t s, double* sums, int32_t N, int32_t slots, int64_t chw, float eps,
                                       float* stats) {
     JAF_REQUIRE(sums && stats && N >= 1 && slots >= 1 && chw >= 1);
     hipLaunchKernelGGL(ln_finalize_slots_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, (hipStream_t)s, sums, N, slots, (long)chw, eps, stats);

@@ -318,12 +318,23 @@ class LNStats:
     """Side channel between a convolution and the CRN LayerNorm that follows it (crn_model.ConvBlock): on the
     packed bf16 path the conv epilogue accumulates each image's (sum, sum of squares) into `sums`
     ([N][slots][2] fp64) while the outputs are still in registers, and the LayerNorm skips its own
-    statistics pass over the tensor.  `filled` stays False when the convolution took another path."""
-    __slots__ = ("sums", "slots", "filled")
+    statistics pass over the tensor.  `filled` stays False when the convolution took another path.
+    One object per LayerNorm module: the buffer is zeroed once, `jaf_layernorm_finalize` leaves it clean
+    (`dirty` re-zeroes it if an accumulation was never finalised)."""
+    __slots__ = ("sums", "slots", "filled", "dirty")
     SLOTS = 8
 
     def __init__(self):
-        self.sums, self.slots, self.filled = None, self.SLOTS, False
+        self.sums, self.slots, self.filled, self.dirty = None, self.SLOTS, False, False
+
+    def buffer(self, N: int, device) -> torch.Tensor:
+        n = N * self.slots * 2
+        if self.sums is None or self.sums.numel() != n or self.sums.device != device:
+            self.sums = torch.zeros(n, device=device, dtype=torch.float64)
+        elif self.dirty:
+            self.sums.zero_()
+        self.dirty = True
+        return self.sums
 
 
 def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_tot: int, mode: int,
@@ -343,14 +354,16 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if xp is None:
             xp = pack_input(srcs, d)
         sums = None
-        if ln_stats is not None and act == ACT_NONE and G == 1:
-            sums = torch.zeros(N * ln_stats.slots * 2, device=out.device, dtype=torch.float64)
+        if ln_stats is not None:
+            ln_stats.filled = False
+            if act == ACT_NONE and G == 1:
+                sums = ln_stats.buffer(N, out.device)
         ev = _PROF.begin() if _PROF is not None else None
         check(lib().jaf_conv2d_fwd_packed_stats(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out),
                                                 _p(sums), ln_stats.slots if sums is not None else 1),
               "jaf_conv2d_fwd_packed_stats")
         if sums is not None:
-            ln_stats.sums, ln_stats.filled = sums, True
+            ln_stats.filled = True
         if ev is not None:
             _PROF.end("conv_dma_kernel<%d, %d, false>" % (pl.MT, pl.NT), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
@@ -721,6 +734,7 @@ class _LayerNormLReLUFn(Function):
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
         if pre is not None and pre.filled:       # sums came out of the producing convolution's epilogue
             check(L.jaf_layernorm_finalize(_s(), _p(pre.sums), N, pre.slots, C * H * W, eps, _p(stats)), "jaf_layernorm_finalize")
+            pre.filled, pre.dirty = False, False     # consumed, and the kernel left the sums at zero
         else:
             ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
             check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")

@@ -546,11 +546,17 @@ def test_layernorm_statistics_from_conv_epilogue(N, Cin, Cout, H, W):
         st = ops.LNStats()
         y = ops.conv2d(x, w, b, stride=1, pad=1, act=0, ln_stats=st)
         assert st.filled and st.sums.numel() == N * st.slots * 2
+        sums = st.sums.view(N, st.slots, 2).sum(1).cpu()
         fused = ops.layernorm_lrelu(y, g, be, 1e-5, 0.01, st)
+        assert not st.filled and float(st.sums.abs().max()) == 0.0      # consumed, and left clean for the next use
         plain = ops.layernorm_lrelu(y, g, be, 1e-5, 0.01)
+        # second round through the same side channel: no re-zeroing by the caller
+        y2 = ops.conv2d(x * 0.5, w, b, stride=1, pad=1, act=0, ln_stats=st)
+        fused2 = ops.layernorm_lrelu(y2, g, be, 1e-5, 0.01, st)
+        plain2 = ops.layernorm_lrelu(y2, g, be, 1e-5, 0.01)
+        assert maxerr(fused2, plain2.cpu()) <= 2e-5
     finally:
         ops.set_precision(prev)
-    sums = st.sums.view(N, st.slots, 2).sum(1).cpu()
     ref = torch.stack([y.double().sum((1, 2, 3)), (y.double() ** 2).sum((1, 2, 3))], 1).cpu()
     assert torch.allclose(sums, ref, rtol=2e-6, atol=1e-6)
     assert maxerr(fused, plain.cpu()) <= 2e-5
