@@ -381,6 +381,8 @@ def _wgrad_packed_ok(m) -> bool:
 
 
 def _grad_inplace(p: torch.Tensor) -> bool:
+    if not p.is_leaf:        # e.g. the concatenated CRN head weights: their gradient goes back through autograd
+        return False
     g = p.grad
     return g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape
 
