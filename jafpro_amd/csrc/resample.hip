@@ -465,50 +465,49 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i;
 }
 
-__global__ void reflect_pad_fwd_kernel(const float* x, float* y, int NC, int H, int W, int p) {
+// grid (x blocks, row blocks, planes), block (tx, ty): no per-element index decoding
+__global__ void reflect_pad_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int p) {
     const int PH = H + 2 * p, PW = W + 2 * p;
-    const long total = (long)NC * PH * PW;
-    const long gs = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int px = (int)(e % PW);
-        const int py = (int)((e / PW) % PH);
-        const long nc = e / ((long)PW * PH);
-        y[e] = x[(nc * H + reflect_idx(py - p, H)) * W + reflect_idx(px - p, W)];
-    }
+    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int py = blockIdx.y * blockDim.y + threadIdx.y;
+    if (px >= PW || py >= PH) return;
+    const long nc = blockIdx.z;
+    y[(nc * PH + py) * PW + px] = x[(nc * H + reflect_idx(py - p, H)) * W + reflect_idx(px - p, W)];
 }
 
 extern "C" int jaf_reflect_pad_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W, int32_t p) {
     JAF_REQUIRE(x && y && NC >= 1 && p >= 0 && p < H && p < W);
-    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(jaf_ew_grid((long)NC * (H + 2 * p) * (W + 2 * p))), dim3(256), 0, (hipStream_t)s, x, y, NC, H, W, p);
+    JAF_REQUIRE(NC <= 65535 && H + 2 * p <= 65535);
+    const dim3 b = block2d(W + 2 * p);
+    hipLaunchKernelGGL(reflect_pad_fwd_kernel, dim3(jaf_cdiv(W + 2 * p, b.x), jaf_cdiv(H + 2 * p, b.y), NC), b, 0, (hipStream_t)s, x, y, H, W, p);
     return jaf_launch_status();
 }
 
 // gather form of the adjoint: each input pixel sums the padded positions that mirror onto it.
-__global__ void reflect_pad_bwd_kernel(const float* dy, float* dx, int NC, int H, int W, int p) {
+__global__ void reflect_pad_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int p) {
     const int PH = H + 2 * p, PW = W + 2 * p;
-    const long total = (long)NC * H * W;
-    const long gs = (long)gridDim.x * blockDim.x;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
-        const int x = (int)(e % W);
-        const int y = (int)((e / W) % H);
-        const long nc = e / ((long)W * H);
-        int ys[3], xs[3], ny = 0, nx = 0;
-        ys[ny++] = y + p;
-        if (y >= 1 && y <= p) ys[ny++] = p - y;
-        if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = p + 2 * (H - 1) - y;
-        xs[nx++] = x + p;
-        if (x >= 1 && x <= p) xs[nx++] = p - x;
-        if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = p + 2 * (W - 1) - x;
-        const float* q = dy + nc * PH * PW;
-        float acc = 0.f;
-        for (int i = 0; i < ny; ++i)
-            for (int j = 0; j < nx; ++j) acc += q[ys[i] * PW + xs[j]];
-        dx[e] = acc;
-    }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= W || y >= H) return;
+    const long nc = blockIdx.z;
+    int ys[3], xs[3], ny = 0, nx = 0;
+    ys[ny++] = y + p;
+    if (y >= 1 && y <= p) ys[ny++] = p - y;
+    if (y <= H - 2 && y >= H - 1 - p) ys[ny++] = p + 2 * (H - 1) - y;
+    xs[nx++] = x + p;
+    if (x >= 1 && x <= p) xs[nx++] = p - x;
+    if (x <= W - 2 && x >= W - 1 - p) xs[nx++] = p + 2 * (W - 1) - x;
+    const float* q = dy + nc * PH * PW;
+    float acc = 0.f;
+    for (int i = 0; i < ny; ++i)
+        for (int j = 0; j < nx; ++j) acc += q[ys[i] * PW + xs[j]];
+    dx[(nc * H + y) * W + x] = acc;
 }
 
 extern "C" int jaf_reflect_pad_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W, int32_t p) {
     JAF_REQUIRE(dy && dx && NC >= 1 && p >= 0 && p < H && p < W);
-    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(jaf_ew_grid((long)NC * H * W)), dim3(256), 0, (hipStream_t)s, dy, dx, NC, H, W, p);
+    JAF_REQUIRE(NC <= 65535 && H <= 65535);
+    const dim3 b = block2d(W);
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), NC), b, 0, (hipStream_t)s, dy, dx, H, W, p);
     return jaf_launch_status();
 }
