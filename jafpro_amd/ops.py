@@ -210,10 +210,12 @@ def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mo
     ck = (id(weight), weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision, pl.nsteps, pl.plane)
     hit = _PACK_CACHE.get(ck)
     if hit is not None and hit.ref() is weight:
-        if hit.event is not None:        # image refreshed on another stream (refresh_packed_weights)
-            sid = torch.cuda.current_stream().cuda_stream
+        if hit.event is not None:        # image made or refreshed on another stream: order this stream behind it
+            cur = torch.cuda.current_stream()
+            sid = cur.cuda_stream
             if sid not in hit.waited:
-                torch.cuda.current_stream().wait_event(hit.event)
+                cur.wait_event(hit.event)
+                hit.buf.record_stream(cur)          # ... and keep the block from being reused under this stream's reads
                 hit.waited.add(sid)
         return hit.buf
     if len(_PACK_CACHE) > 4096:
@@ -222,7 +224,12 @@ def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mo
     buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
     check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
           "jaf_conv2d_pack")
-    _PACK_CACHE[ck] = _PackEntry(weight, buf, d, pl, mode, w_rows_tot)
+    ent = _PackEntry(weight, buf, d, pl, mode, w_rows_tot)
+    cur = torch.cuda.current_stream()
+    ent.event = torch.cuda.Event()          # a frozen network's image may be made on the preparation stream and read
+    ent.event.record(cur)                   # on the main one (VGG: target features there, generated frame here)
+    ent.waited = {cur.cuda_stream}
+    _PACK_CACHE[ck] = ent
     _PACK_KEYS_BY_ID.setdefault(id(weight), []).append(ck)
     return buf
 
@@ -258,12 +265,17 @@ def refresh_packed_weights(params) -> None:
         for t, e in todo:
             check(L.jaf_conv2d_pack(_s(), ctypes.byref(e.d), ctypes.byref(e.pl), e.mode, _p(t), e.rows, _p(e.buf)),
                   "jaf_conv2d_pack")
+            if st != main:
+                # both blocks were allocated on another stream: the allocator must not hand them out again (cache
+                # dropped, model freed) while this stream still reads the weights / writes the image
+                e.buf.record_stream(st)
+                t.record_stream(st)
         ev = None
         if st != main:
             ev = torch.cuda.Event()
             ev.record(st)
     for _, e in todo:
-        e.event, e.waited = ev, set()
+        e.event, e.waited = ev, (set() if ev is not None else {main.cuda_stream})
 
 
 def _out_size(n, k, s, p):
