@@ -333,3 +333,34 @@ def test_config5_train_step_at_512():
     assert out["final_output"].shape == (1, 3, 512, 512)
     for name in ("accu", "inpaint", "refine", "flow", "D", "face"):
         assert tr.flat[name].step_count == (3 if name == "D" else 1)
+
+
+def test_no_late_writes_after_dropping_a_trainer():
+    """Side-stream work that outlives a train step (weight re-packing on stream 2, the next clip's preparation on
+    stream 0) must not write into memory the caching allocator has already handed out again: drop the trainer,
+    its models and the packed-image cache right after a step, grab memory of every size on the main stream, fill it
+    with a pattern and check the pattern after everything has drained."""
+    import gc
+    from jafpro_amd import ops
+    M, tr, orc, batch, dbatch, mods = build(1)
+    prev = ops.set_precision("bf16")
+    try:
+        tr.train_step(dbatch, next_batch=dbatch)
+        # park the side streams for ~a second: the second step's re-pack / preparation launches are then still queued when
+        # everything below is freed and reallocated (without record_stream on that stream they scribble over `bufs`)
+        for which in (0, 2):                      # 0: the next clip's preparation, 2: weight re-packing
+            with torch.cuda.stream(ops.aux_stream(which)):
+                torch.cuda._sleep(int(2.0e9))
+        tr.train_step(dbatch, next_batch=dbatch)
+    finally:
+        ops.set_precision(prev)
+    del tr, M, orc, mods
+    ops.invalidate_packed_weights()
+    gc.collect()
+    bufs = []
+    for shift in range(10, 27):                       # 1 KiB .. 64 MiB of floats, several of each
+        for _ in range(24 if shift < 20 else 4):
+            bufs.append(torch.full((1 << (shift - 2),), 3.25, device="cuda"))
+    torch.cuda.synchronize()
+    bad = [b.numel() for b in bufs if not bool((b == 3.25).all())]
+    assert not bad, "buffers overwritten after allocation: sizes %s" % bad[:8]
