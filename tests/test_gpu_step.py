@@ -364,3 +364,29 @@ def test_no_late_writes_after_dropping_a_trainer():
     torch.cuda.synchronize()
     bad = [b.numel() for b in bufs if not bool((b == 3.25).all())]
     assert not bad, "buffers overwritten after allocation: sizes %s" % bad[:8]
+
+
+def test_results_do_not_depend_on_side_stream_timing():
+    """Every cross-stream dependency of the train step (clip preparation on stream 0, weight gradients on stream 1,
+    weight re-packing on stream 2) must be expressed by an event or a join, not by luck: with each side stream
+    parked for ~0.3 s in front of every step, two steps must give the same losses and frame as undisturbed.
+    f32 mode: run-to-run noise (atomic summation order) is ~1e-6 there; in bf16 the GAN terms of the second step
+    already move by 3-5e-3 between two undisturbed runs, which would hide a real ordering bug."""
+    from jafpro_amd import ops
+
+    def run(parked):
+        M, tr, _, _, dbatch, _ = build(1)
+        for _ in range(2):
+            if parked:
+                for which in (0, 1, 2):
+                    with torch.cuda.stream(ops.aux_stream(which)):
+                        torch.cuda._sleep(int(6.0e8))
+            out = tr.train_step(dbatch, next_batch=dbatch)
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in out.items()}
+
+    a, b = run(False), run(True)
+    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
+        x, y = float(a[k].reshape(-1)[0]), float(b[k].reshape(-1)[0])
+        assert abs(x - y) <= 1e-4 * max(1.0, abs(x)), (k, x, y)
+    assert rel_l2(b["final_output"], a["final_output"]) <= 1e-4
