@@ -30,7 +30,7 @@ class float_estimate(nn.Module):
         return self.warp_image(src_img, flow)
 
     def cal_flow(self, src_cam, src_pose, src_vertices, src_shape, tgt_cam, tgt_pose, tgt_vertices, tgt_shape):
-        src_faces, _, _ = self.render.render_fim_wim(src_cam, src_vertices)
+        src_faces = self.render.project(src_cam, src_vertices)      # only the projected faces of the source mesh are used (:30)
         _, tsf_fim, tsf_wim = self.render.render_fim_wim(tgt_cam, tgt_vertices)
         # src_f2verts[..., 0:2] with y *= -1 (:30-31) is folded into the kernel
         return ops.bc_transform(src_faces, tsf_fim, tsf_wim)

@@ -42,8 +42,10 @@ class ConvLSTMCell(nn.Module):
         self.conv = _GateConv(input_dim + hidden_dim, 4 * hidden_dim, kernel_size, bias)
 
     def forward(self, input, prev_state):
-        """One step from an explicit state (src/convLSTM.py:41-56)."""
-        raise NotImplementedError("use ConvLSTM.forward; single-step stateful calls are not on the stage-4 path")
+        """One step from an explicit state (src/convLSTM.py:41-56): -> (h_next, c_next), both differentiable."""
+        h_cur, c_cur = prev_state
+        return ops.convlstm(input.contiguous().unsqueeze(0), self.conv.weight, self.conv.bias, groups=1, return_all=False,
+                            state=(h_cur.contiguous(), c_cur.contiguous()))
 
     def init_hidden(self, batch_size, cuda=True):
         dev = self.conv.weight.device
@@ -77,14 +79,17 @@ class ConvLSTM(nn.Module):
         self.cell_list = nn.ModuleList(cells)
 
     def forward(self, input, hidden_state=None):
-        if hidden_state is not None:
-            raise NotImplementedError("stateful ConvLSTM is not implemented (the reference never passes a state)")
+        # hidden_state: one (h0, c0) pair per layer, used as given; None is the zero state of get_init_states
+        # (src/convLSTM.py:119-120,128).
+        if hidden_state is not None and len(hidden_state) != self.num_layers:
+            raise ValueError("hidden_state must hold one (h, c) pair per layer")
         # kernel wants (t, b, c, h, w)
         x = input.permute(1, 0, 2, 3, 4) if self.batch_first else input
         layer_outputs, last_states = [], []
         cur = x.contiguous()
-        for cell in self.cell_list:
-            hs, c_last = ops.convlstm(cur, cell.conv.weight, cell.conv.bias, groups=1, return_all=True)
+        for li, cell in enumerate(self.cell_list):
+            st = None if hidden_state is None else (hidden_state[li][0].contiguous(), hidden_state[li][1].contiguous())
+            hs, c_last = ops.convlstm(cur, cell.conv.weight, cell.conv.bias, groups=1, return_all=True, state=st)
             layer_outputs.append(hs)
             last_states.append((hs[-1], c_last))
             cur = hs

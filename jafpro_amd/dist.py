@@ -24,6 +24,18 @@ class GradReducer:
         self.world = dist.get_world_size(group)
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.active = not (skip_single and self.world == 1)   # a 1-rank group still exercises the path in tests
+        # host-side metadata (per-rank face counts) travels over gloo: an RCCL group only moves device tensors,
+        # and reading those back would put a device sync into every step.  Every rank constructs the reducer,
+        # so every rank makes this collective new_group call.
+        self._host_group = group
+        if self.active and dist.get_backend(group) != "gloo":
+            self._host_group = dist.new_group(backend="gloo")
+
+    def host_allgather_int(self, value: int) -> List[int]:
+        t = torch.tensor([int(value)], dtype=torch.int64)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self._host_group)
+        return [int(o.item()) for o in out]
 
     def begin(self, buffers: Sequence[torch.Tensor]) -> List[Tuple[object, torch.Tensor]]:
         """Issues the sum over ranks of every flat buffer as <= bucket_bytes asynchronous messages

@@ -41,13 +41,17 @@ class SMPLRenderer(nn.Module):
         self.viewing_angle = viewing_angle
         self.eye = [0, 0, -(1. / np.tan(np.radians(self.viewing_angle)) + 1)]
 
+    def project(self, cam, vertices, faces=None):
+        """Projection + y-flip + look_at + vertices_to_faces (src/nmr.py:269-276) -> faces [B,NF,3,3]."""
+        fidx = self.faces if faces is None else faces[0].int().contiguous()
+        eye_z = float(np.float32(self.eye[2]))
+        return ops.project_faces(vertices.float().contiguous(), cam.float().contiguous(), fidx, eye_z)
+
     def render_fim_wim(self, cam, vertices, faces=None):
         """-> (faces [B,NF,3,3] after projection/look_at, fim int32 [B,S,S], wim [B,S,S,3]).
         rasterize_face_index_map_and_weight_map defaults: near 0.1, far 100, no anti-aliasing
         (src/nmr.py:277, rasterize.py:8-13)."""
-        fidx = self.faces if faces is None else faces[0].int().contiguous()
-        eye_z = float(torch.tensor(self.eye, dtype=torch.float32)[2])
-        f = ops.project_faces(vertices.float().contiguous(), cam.float().contiguous(), fidx, eye_z)
+        f = self.project(cam, vertices, faces)
         fim, wim = ops.rasterize_fim_wim(f, self.image_size, 0.1, 100.0)
         return f, fim, wim
 

@@ -81,6 +81,25 @@ def get_precision() -> str:
     return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
 
 
+class _arith:
+    """`with _arith(ctx.mode):` -- a backward pass runs in the arithmetic its forward ran in, whatever
+    set_precision says by then (its saved packed images / bf16 gates belong to that mode)."""
+    __slots__ = ("mode", "prev")
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        global _PRECISION, _USE_PACKED
+        self.prev = (_PRECISION, _USE_PACKED)
+        _PRECISION, _USE_PACKED = self.mode
+
+    def __exit__(self, *exc):
+        global _PRECISION, _USE_PACKED
+        _PRECISION, _USE_PACKED = self.prev
+        return False
+
+
 def _wgrad_dma_name(Cout: int, KS: int) -> str:
     """Template instantiation jaf_conv2d_wgrad_packed launches (same rule as csrc/wgrad_dma.hip), so that the
     bench's per-kernel rows carry the names rocprofv3 reports."""
@@ -441,6 +460,7 @@ class _ConvFn(Function):
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
         ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.meta = m
+        ctx.mode = (_PRECISION, _USE_PACKED)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.save_for_backward(weight, y if m.act != ACT_NONE else None, *srcs)
@@ -448,6 +468,11 @@ class _ConvFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        with _arith(ctx.mode):
+            return _ConvFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         m: _ConvMeta = ctx.meta
         weight, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
         srcs = ctx.saved_tensors[2:]
@@ -591,12 +616,13 @@ def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=
 # --------------------------------------------------------------------------------------------
 class _ConvLSTMFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, G: int, need_all: bool):
-        # x: [T, N, G*C, H, W]; weight: [G*4C, 2C, 3, 3]; bias [G*4C]
+    def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0):
+        # x: [T, N, G*C, H, W]; weight: [G*4C, 2C, 3, 3]; bias [G*4C]; h0/c0: [N, G*C, H, W] or None (zero state)
         T, N, GC, H, W = x.shape
         C = GC // G
         L = lib()
-        keep = any(ctx.needs_input_grad[:3])
+        keep = any(ctx.needs_input_grad[:3]) or ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        ctx.set_materialize_grads(False)
         hs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
         cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
         # on the packed bf16 path the saved gates are bf16 (they are the dominant traffic of the cell epilogue
@@ -605,7 +631,9 @@ class _ConvLSTMFn(Function):
         gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.bfloat16 if g16 else torch.float32) if keep else None
         xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
         for t in range(T):
-            first = t == 0
+            first = t == 0 and h0 is None
+            hprev = h0 if t == 0 else hs[t - 1]
+            cprev = c0 if t == 0 else cs[t - 1]
             specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
             Cin = C if first else 2 * C
             key = ("lstm", N, G, Cin, C, H, W)
@@ -614,19 +642,19 @@ class _ConvLSTMFn(Function):
             wpk = _packed(weight, 4 * C, d, pl, PACK_LSTM, key)
             ev = _PROF.begin() if _PROF is not None else None
             if _packed_path(d):
-                xp = pack_input([x[t]] if first else [x[t], hs[t - 1]], d)
+                xp = pack_input([x[t]] if first else [x[t], hprev], d)
                 if keep:
                     xps.append(xp)
                 check(L.jaf_convlstm_cell_fwd_packed(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
-                                                     None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
+                                                     None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
                                                      _p(gates[t]) if keep else None, 1 if g16 else 0),
                       "jaf_convlstm_cell_fwd_packed")
                 if ev is not None:
                     _PROF.end("conv_dma_kernel<%d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
-                                          None if first else _p(hs[t - 1]), _p(wpk), _p(bias),
-                                          None if first else _p(cs[t - 1]), _p(hs[t]), _p(cs[t]),
+                                          None if first else _p(hprev), _p(wpk), _p(bias),
+                                          None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
                                           _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd")
             if ev is not None:
                 _PROF.end(_kname(True, 3, 3, pl), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
@@ -634,21 +662,29 @@ class _ConvLSTMFn(Function):
         ctx.need_all = need_all
         ctx.bias_ref = bias
         ctx.xps = xps if (keep and len(xps) == T) else None
+        ctx.has_state = h0 is not None
+        ctx.mode = (_PRECISION, _USE_PACKED)        # backward uses the arithmetic the forward ran in
         if keep:
-            ctx.save_for_backward(x, weight, hs, cs, gates)
+            ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
         c_last = cs[T - 1].clone()
-        ctx.mark_non_differentiable(c_last)
         if need_all:
             return hs, c_last
         return hs[T - 1], c_last
 
     @staticmethod
-    def backward(ctx, dh_out, _dc_unused=None):
-        x, weight, hs, cs, gates = ctx.saved_tensors
+    def backward(ctx, dh_out, dc_last=None):
+        with _arith(ctx.mode):
+            return _ConvLSTMFn._backward(ctx, dh_out, dc_last)
+
+    @staticmethod
+    def _backward(ctx, dh_out, dc_last):
+        x, weight, hs, cs, gates, h0, c0 = ctx.saved_tensors
         G = ctx.G
         T, N, GC, H, W = x.shape
         C = GC // G
         L = lib()
+        if dh_out is None:          # only c_T was used downstream
+            dh_out = torch.zeros_like(hs) if ctx.need_all else torch.zeros_like(hs[0])
         dh_out = _c(dh_out)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         bias = ctx.bias_ref
@@ -664,11 +700,13 @@ class _ConvLSTMFn(Function):
             db = torch.zeros(4 * GC, device=x.device, dtype=torch.float32)
         else:
             db = torch.empty(4 * GC, device=x.device, dtype=torch.float32)
-        dc = None
+        dc = _c(dc_last) if dc_last is not None else None
         dh = None
         ng8 = (4 * C + 7) // 8
         for t in range(T - 1, -1, -1):
-            first = t == 0
+            first = t == 0 and not ctx.has_state
+            hprev = h0 if t == 0 else hs[t - 1]
+            cprev = c0 if t == 0 else cs[t - 1]
             if ctx.need_all:
                 dht = dh_out[t] if dh is None else dh_out[t] + dh
             else:
@@ -686,7 +724,7 @@ class _ConvLSTMFn(Function):
                 gtp = torch.empty(N * G * ng8 * H * W * 16, device=x.device, dtype=torch.uint8)
                 with _hbm("lstm_gates_bwd_pack_kernel", N * G * C * H * W * (4.0 * (4 if first else 5) + 4.0 * gt.element_size()) + gtp.numel()):
                     check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                                          1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev), _p(gtp),
+                                                          1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cprev), _p(cs[t]), _p(dc_prev), _p(gtp),
                                                           _p(db)), "jaf_convlstm_gates_bwd_packed")
                 wst = _WGRAD_STREAM if w_inplace else None      # see set_wgrad_stream
                 if wst is not None:
@@ -703,7 +741,7 @@ class _ConvLSTMFn(Function):
             else:
                 # gt is overwritten with the pre-activation gate gradients
                 check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                               None if first else _p(cs[t - 1]), _p(cs[t]), _p(dc_prev)),
+                                               None if first else _p(cprev), _p(cs[t]), _p(dc_prev)),
                       "jaf_convlstm_gates_bwd")
                 ev = _PROF.begin() if _PROF is not None else None
                 if ctx.xps is not None and _packed_path(d):
@@ -713,7 +751,7 @@ class _ConvLSTMFn(Function):
                                                     1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
                     wname = _wgrad_dma_name(4 * C, 3)
                 else:
-                    check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hs[t - 1]), None,
+                    check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hprev), None,
                                              _p(gt), _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
                     wname = _wgrad_name(3, 3)
                 if ev is not None:
@@ -727,14 +765,23 @@ class _ConvLSTMFn(Function):
                 dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
             dc = dc_prev
-        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None
+        dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None
+        dc0 = dc if (ctx.has_state and ctx.needs_input_grad[6]) else None
+        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0
 
 
-def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int = 1, return_all: bool = False):
-    """x: [T, N, G*C, H, W] -> (h_T [N, G*C, H, W] or all h_t, c_T).  Zero initial state
-    (src/convLSTM.py:58-63,119-120); gate order i,f,o,g (:46).  c_T carries no gradient."""
+def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int = 1, return_all: bool = False,
+             state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """x: [T, N, G*C, H, W] -> (h_T [N, G*C, H, W] or all h_t, c_T).  `state` = (h0, c0), default the zero
+    state of src/convLSTM.py:58-63,119-120; gate order i,f,o,g (:46).  Differentiable w.r.t. x, the parameters,
+    the initial state, and through both h and c_T (T = 1 with a state is ConvLSTMCell.forward, :41-56)."""
     _chk(x, "convlstm x"); _chk(weight, "convlstm weight"); _chk(bias, "convlstm bias")
-    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all)
+    h0 = c0 = None
+    if state is not None:
+        h0, c0 = _chk(state[0], "convlstm h0"), _chk(state[1], "convlstm c0")
+        if h0.shape != x.shape[1:] or c0.shape != x.shape[1:]:
+            raise RuntimeError("convlstm: state shape %s / %s does not match the input %s" % (tuple(h0.shape), tuple(c0.shape), tuple(x.shape[1:])))
+    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all, h0, c0)
 
 
 # --------------------------------------------------------------------------------------------

@@ -126,7 +126,26 @@ class PreparedClip:
     of the target frame (src/networks.py:118-125).  Produced on the side HIP stream by
     `prepare_clip`, either inside the same step (beside the texture pipeline) or one step ahead
     (beside the previous clip's loss backward, `Stage4Trainer.train_step(next_batch=...)`)."""
-    __slots__ = ("batch", "prosrc", "src0", "bg_output", "tsf", "event", "vgg_target", "vgg_event")
+    __slots__ = ("batch", "prosrc", "key", "src0", "bg_output", "tsf", "event", "vgg_target", "vgg_event")
+
+
+_PREP_KEYS = ("src_img", "src_mask_in_image0", "bg_noise", "src_cam", "src_verts", "src_cam_refs", "src_verts_refs",
+              "tgt_cam", "tgt_verts", "tgt_img")
+
+
+def _clip_key(b: Dict[str, torch.Tensor], prosrc: int):
+    """Identity of everything `prepare_clip` reads: a loader that recycles the same dict or the same device buffers
+    with new contents (copy_ bumps _version) must not be handed the previous clip's preparation."""
+    return (prosrc,) + tuple((k, b[k].data_ptr(), b[k]._version, tuple(b[k].shape)) for k in _PREP_KEYS if k in b)
+
+
+def _source_pose(b: Dict[str, torch.Tensor], prosrc: int):
+    """prev_smpl = the SMPL pose of the propagation source, smpl_vertices[:, 1 + random_prosrc] (train/4...py:263-266)."""
+    if "src_verts_refs" in b:
+        return b["src_cam_refs"][:, prosrc].contiguous(), b["src_verts_refs"][:, prosrc].contiguous()
+    if prosrc != 0:
+        raise ValueError("prosrc != 0 needs the per-reference SMPL poses (src_verts_refs / src_cam_refs)")
+    return b["src_cam"], b["src_verts"]
 
 
 def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int, with_loss_target: bool = False) -> PreparedClip:
@@ -134,14 +153,19 @@ def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int, with_
     side = _side_stream(main.device)
     side.wait_stream(main)          # the batch tensors were produced on the main stream
     p = PreparedClip()
-    p.batch, p.prosrc = b, prosrc
+    p.batch, p.prosrc, p.key = b, prosrc, _clip_key(b, prosrc)
     with torch.cuda.stream(side), torch.no_grad():
+        if side != main:
+            for k in _PREP_KEYS:    # read on the side stream: a batch freed early must not be reallocated under it
+                if k in b:
+                    b[k].record_stream(side)
         p.src0 = b["src_img"][:, 0].contiguous()
         bg_mask = 1.0 - b["src_mask_in_image0"]                                 # :230-231 (input prep)
         bg_incomplete = (bg_mask * p.src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
         p.bg_output = M.bg_model(bg_incomplete, M.image_size)                   # :319-320
         prev_img = b["src_img"][:, prosrc].contiguous()
-        p.tsf = M.flow_calculator(prev_img, [b["src_cam"], None, b["src_verts"], None],
+        src_cam, src_verts = _source_pose(b, prosrc)
+        p.tsf = M.flow_calculator(prev_img, [src_cam, None, src_verts, None],
                                   [b["tgt_cam"], None, b["tgt_verts"], None])    # :325
         p.event = torch.cuda.Event()
         p.event.record(side)
@@ -164,7 +188,7 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     # they run on a side HIP stream beside the texture pipeline (whose deep 13x13 / 25x25 levels
     # launch grids far smaller than the chip) and are joined before the fusion blend.
     main = torch.cuda.current_stream()
-    if prepared is None or prepared.batch is not b or prepared.prosrc != prosrc:
+    if prepared is None or prepared.key != _clip_key(b, prosrc) or (with_loss_target and "tgt_img" in b and prepared.vgg_target is None):
         prepared = prepare_clip(M, b, prosrc, with_loss_target)
     bg_output, tsf = prepared.bg_output, prepared.tsf
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
@@ -198,8 +222,12 @@ def face_crops(final, tgt_img, tgt_IUV, bbox: np.ndarray):
         fr.append(ops.resize(tgt_img[i:i + 1].contiguous(), (64, 64), False, crop=crop))
         fi.append(ops.resize(tgt_IUV[i:i + 1].contiguous(), (64, 64), False, nearest=True, crop=crop))
     if not fp:
-        raise RuntimeError("no valid face box in the batch (the reference crashes here too, :351)")
+        return None, None, None
     return torch.cat(fp, 0), torch.cat(fr, 0), torch.cat(fi, 0)
+
+
+def count_faces(bbox: np.ndarray) -> int:
+    return int(sum(1 for r in np.asarray(bbox) if int(r[0]) != int(r[1])))
 
 
 class Stage4Trainer:
@@ -221,23 +249,42 @@ class Stage4Trainer:
             ops.join_wgrad_stream()
             self.reducer.all_reduce_mean([self.flat[n].grad for n in names])
 
+    def _face_weight(self, n_face: int) -> float:
+        """The reference gathers the face crops of the WHOLE batch on device 0 and takes one BCE mean over them
+        (train/4...py:338-374), so with N ranks a rank holding n_r of the sum(n) valid faces must weigh its face
+        terms by n_r * N / sum(n) for the averaged gradient to be that mean (1.0 whenever the counts are equal).
+        The counts are host integers (src/data.py:702-716): they are exchanged on the host (no device sync), and a
+        batch without any valid face raises on EVERY rank, as the reference does (:351) -- never a hung collective."""
+        if self.reducer is not None and self.reducer.active:
+            counts = self.reducer.host_allgather_int(n_face)
+            tot = sum(counts)
+            if tot == 0:
+                raise RuntimeError("no valid face box on any rank (the reference crashes here too, :351)")
+            return n_face * len(counts) / tot
+        if n_face == 0:
+            raise RuntimeError("no valid face box in the batch (the reference crashes here too, :351)")
+        return 1.0
+
     def train_step(self, batch: Dict[str, torch.Tensor], used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0,
-                   align_corners: bool = False, next_batch: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+                   align_corners: bool = False, next_batch: Optional[Dict[str, torch.Tensor]] = None,
+                   next_prosrc: Optional[int] = None) -> Dict[str, torch.Tensor]:
         """One stage-4 iteration.  `next_batch` (already on the device) is the clip of the NEXT call:
         its parameter-independent preparation (SMPL projection/rasterisation/flow warp, frozen
         background CRN) is issued on the side HIP stream right before this clip's generator loss
-        backward and is picked up by that next call."""
+        backward and is picked up by that next call (`next_prosrc`: that call's propagation source)."""
         M, b = self.M, batch
         # weight-gradient kernels run on their own stream beside the data gradients (ops.set_wgrad_stream)
         prev_ws = ops.set_wgrad_stream(None if not WGRAD_STREAM else ops.aux_stream(1))
         try:
-            return self._train_step(batch, used, prosrc, align_corners, next_batch)
+            return self._train_step(batch, used, prosrc, align_corners, next_batch,
+                                    prosrc if next_prosrc is None else next_prosrc)
         finally:
             ops.join_wgrad_stream()
             ops.set_wgrad_stream(prev_ws)
 
-    def _train_step(self, batch, used, prosrc, align_corners, next_batch):
+    def _train_step(self, batch, used, prosrc, align_corners, next_batch, next_prosrc):
         M, b = self.M, batch
+        fw = self._face_weight(count_faces(b["face_bbox"]))      # before anything is enqueued: may raise on every rank
         for f in self.flat.values():                                             # :206-212
             f.zero_grad()
         prepared, self._prepared = self._prepared, None
@@ -257,7 +304,7 @@ class Stage4Trainer:
         mark("VGG+L1 loss forward")
         face_pred, face_real, face_IUV = face_crops(final, target, b["tgt_IUV"], b["face_bbox"])
         src0 = b["src_img"][:, 0].contiguous()
-        face_pred_d = face_pred.detach()
+        face_pred_d = face_pred.detach() if face_pred is not None else None
         # The image discriminator's Linear assumes 256x256 inputs (src/networks.py:409).  BASELINE config 5 (512x512, no
         # reference implementation) feeds it 2x average-pooled images; at 256 `dview` is the identity.
         if M.image_size == 512:
@@ -268,10 +315,13 @@ class Stage4Trainer:
             raise RuntimeError("train_step supports image_size 256 (reference) and 512 (config 5), got %d" % M.image_size)
         target_d, src0_d = dview(target), dview(src0)
         # ---- face discriminator, one update (:362-374)
-        F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
-        F_errD_real.backward()
-        F_errD_fake = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 0.0)
-        F_errD_fake.backward()
+        if face_pred is not None:
+            F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
+            (F_errD_real if fw == 1.0 else F_errD_real * fw).backward()
+            F_errD_fake = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 0.0)
+            (F_errD_fake if fw == 1.0 else F_errD_fake * fw).backward()
+        else:       # this rank holds no valid face (others do): zero contribution, but it still joins the exchange
+            F_errD_real = F_errD_fake = torch.zeros(1, device=final.device)
         self._reduce(["face"])
         self.flat["face"].adam(self.lrs["face"])
         mark("face-D update")
@@ -288,10 +338,11 @@ class Stage4Trainer:
         mark("D x3 updates")
         # ---- generator (:398-413)
         errG = ops.bce_loss(M.discriminator([dview(final), src0_d]), 1.0)
-        F_errG = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0)
+        F_errG = (ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0) if face_pred is not None
+                  else torch.zeros(1, device=final.device))
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
         if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
-            self._prepared = prepare_clip(M, next_batch, prosrc, with_loss_target=True)
+            self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True)
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
             # input (reverse graph order), beside the differentiation of the modules upstream of it

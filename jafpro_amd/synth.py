@@ -8,6 +8,7 @@ the SMPL counts (6890 vertices, 13776 faces).
 """
 from __future__ import annotations
 
+import functools
 import zlib
 from typing import Dict, Mapping
 
@@ -61,6 +62,12 @@ def load_synth(module, seed: int):
 # procedural body mesh
 # ------------------------------------------------------------------------------------------------
 def body_mesh():
+    verts, faces = _body_mesh()
+    return verts.copy(), faces.copy()
+
+
+@functools.lru_cache(maxsize=1)
+def _body_mesh():
     """Closed genus-0 surface with exactly 6890 vertices / 13776 triangles (82 rings x 84 segments
     + 2 poles), front faces counter-clockwise for the rasteriser's cull test
     (rasterize_cuda_kernel.cu:40 keeps (x1-x0)(y2-y0) - (y1-y0)(x2-x0) >= 0 after the y-flip)."""
@@ -171,6 +178,10 @@ def stage4_batch(seed: int, B: int, T: int = 4, S: int = 256) -> Dict[str, np.nd
     cam = np.zeros((B, 3), np.float32); cam[:, 0] = 0.9
     d["tgt_cam"] = cam.copy()
     d["src_cam"] = cam.copy()
+    # SMPL pose of every reference frame (smpl_vertices[:, 1 + t], train/4...py:263-266): the propagation source
+    # `prosrc` picks one of them; reference 0 is `src_verts` itself
+    d["src_verts_refs"] = np.stack([d["src_verts"]] + [posed_vertices(seed, "src_verts_r%d" % t, B) for t in range(1, T)], 1)
+    d["src_cam_refs"] = np.tile(cam[:, None], (1, T, 1))
     d["face_bbox"] = np.tile(np.array([[96, 160, 32, 96]], np.int64), (B, 1))   # x0, x1, y0, y1
     return d
 
@@ -181,7 +192,8 @@ def stage4_clip(seed: int, B: int, F: int, T: int = 4, S: int = 256) -> Dict[str
     (tgt_IUV255 [B,F,S,S,3], tgt_IUV / smpl_real_mask [B,F,3,S,S], tgt_verts [B,F,NV,3], tgt_cam [B,F,3])
     and `chosen_frame` [T]: the clip positions of the T reference frames (host integers, :256-262)."""
     d = stage4_batch(seed, B, T, S)
-    for k in ("tgt_img", "tgt_IUV255", "tgt_IUV", "smpl_real_mask", "tgt_verts", "tgt_cam", "face_bbox"):
+    for k in ("tgt_img", "tgt_IUV255", "tgt_IUV", "smpl_real_mask", "tgt_verts", "tgt_cam", "face_bbox", "src_verts_refs",
+              "src_cam_refs"):
         d.pop(k)
     iuv = np.stack([iuv255(seed, "clip_iuv_f%d" % f, B, S) for f in range(F)], 1)
     d["tgt_IUV255"] = iuv

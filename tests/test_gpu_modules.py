@@ -254,3 +254,60 @@ def test_ops_reject_cpu_tensors():
         ops.conv2d(torch.zeros(1, 3, 8, 8), torch.zeros(4, 3, 3, 3), None, pad=1)
     with pytest.raises(RuntimeError):
         ops.avg_pool(torch.zeros(1, 1, 4, 4), 2, 2, 0)
+
+
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 6e-2)])
+def test_convlstm_cell_single_step_and_explicit_state(mode, tol):
+    """ConvLSTMCell.forward(input, (h, c)) -> (h_next, c_next) (src/convLSTM.py:41-56) and ConvLSTM.forward with a passed
+    hidden_state (:119-128), against the oracle cell on CPU: values, and gradients w.r.t. the input, the initial
+    state (h0 AND c0), the weights and the bias, with a loss that uses both h_T and c_T."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.convLSTM import ConvLSTM
+    from oracle import torch_oracle as O
+    m = synth.load_synth(ConvLSTM((10, 12), 8, [8], [(3, 3)], 1, batch_first=True, bias=True), 21).cuda()
+    cell = m.cell_list[0]
+    Tn, B = 3, 2
+    xs = synth.uniform(21, "x", (B, Tn, 8, 10, 12))
+    h0n, c0n = synth.uniform(21, "h0", (B, 8, 10, 12)), synth.uniform(21, "c0", (B, 8, 10, 12))
+    ph, pc = synth.uniform(21, "ph", (B, 8, 10, 12)), synth.uniform(21, "pc", (B, 8, 10, 12))
+    # oracle
+    w = cell.conv.weight.detach().cpu().clone().requires_grad_(True)
+    bb = cell.conv.bias.detach().cpu().clone().requires_grad_(True)
+    x_c = torch.from_numpy(xs).requires_grad_(True)
+    h_c, c_c = torch.from_numpy(h0n).requires_grad_(True), torch.from_numpy(c0n).requires_grad_(True)
+    h, c = h_c, c_c
+    for t in range(Tn):
+        h, c = O.convlstm_cell(w, bb, x_c[:, t], h, c)
+    ((h * torch.from_numpy(ph)).sum() + (c * torch.from_numpy(pc)).sum()).backward()
+    prev = ops.set_precision(mode)
+    try:
+        # (a) chained single steps
+        x_g = T(xs).requires_grad_(True)
+        h_g, c_g = T(h0n).requires_grad_(True), T(c0n).requires_grad_(True)
+        hh, cc = h_g, c_g
+        for t in range(Tn):
+            hh, cc = cell(x_g[:, t], (hh, cc))
+        ((hh * T(ph)).sum() + (cc * T(pc)).sum()).backward()
+        ga = {"x": x_g.grad.clone(), "h0": h_g.grad.clone(), "c0": c_g.grad.clone(), "w": cell.conv.weight.grad.clone(),
+              "b": cell.conv.bias.grad.clone()}
+        # (b) the whole sequence with a passed hidden_state
+        cell.conv.weight.grad = None; cell.conv.bias.grad = None
+        x_g2 = T(xs).requires_grad_(True)
+        h_g2, c_g2 = T(h0n).requires_grad_(True), T(c0n).requires_grad_(True)
+        out, last = m(x_g2, [(h_g2, c_g2)])
+        ((last[0][0] * T(ph)).sum() + (last[0][1] * T(pc)).sum()).backward()
+        gb = {"x": x_g2.grad, "h0": h_g2.grad, "c0": c_g2.grad, "w": cell.conv.weight.grad, "b": cell.conv.bias.grad}
+    finally:
+        ops.set_precision(prev)
+    ref = {"x": x_c.grad, "h0": h_c.grad, "c0": c_c.grad, "w": w.grad, "b": bb.grad}
+
+    def rel(a, b):
+        return ((a.cpu().double() - b.double()).norm() / b.double().norm()).item()
+
+    for tag, (hv, cv, g) in (("steps", (hh, cc, ga)), ("sequence", (last[0][0], last[0][1], gb))):
+        assert rel(hv, h.detach()) <= tol and rel(cv, c.detach()) <= tol, (tag, rel(hv, h.detach()), rel(cv, c.detach()))
+        for k in ref:
+            r = rel(g[k], ref[k])
+            print("%s %-8s %-3s grad rel-L2 %.3e" % (mode, tag, k, r))
+            assert r <= tol, (mode, tag, k, r)
+    assert out.shape == (B, Tn, 8, 10, 12)

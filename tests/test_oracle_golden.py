@@ -136,3 +136,43 @@ def test_raster_oracle_edge_cases():
     assert set(np.unique(fim[1])) == {-1, 0, 2}
     on = fim[1] >= 0
     assert np.allclose(wim[1][on].sum(-1), 1.0, atol=1e-6) and (wim[1][~on] == 0).all()
+
+
+def test_step_oracle_rank_form_is_the_plain_step_on_identical_shards():
+    """oracle.train_step_ranks (per-shard BatchNorm statistics, averaged gradients) on two IDENTICAL
+    shards must reproduce the plain step on one of them: same losses, same gradients (g/2 + g/2 up to the order of
+    the fp32 additions), same Adam updates, both ranks' BatchNorm buffers equal to the plain step's, parameters shared
+    between the rank views and BatchNorm buffers private to each."""
+    import numpy as np
+    import torch
+    from jafpro_amd import synth
+    from oracle.step_oracle import LRS, OracleStage4
+    from tests._step_util import TRAINABLE, build_models
+    torch.set_num_threads(8)
+    _, _, sds, fidx = build_models()
+    b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.stage4_batch(350, 1).items()}
+    a, c = OracleStage4(sds, fidx), OracleStage4(sds, fidx)
+    ra = a.train_step(b, used=(2,), prosrc=2)
+    rc = c.train_step_ranks([b, b], used=(2,), prosrc=2)
+    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
+        for r in rc:
+            assert abs(float(ra[k]) - float(r[k])) <= 1e-5 * max(1.0, abs(float(ra[k]))), k
+    for n in TRAINABLE:
+        num = den = 0.0
+        for k, p in a.sd[n].items():
+            if p.requires_grad:
+                q = c.sd[n][k]
+                num += float(((p.grad - q.grad).double() ** 2).sum()); den += float((p.grad.double() ** 2).sum())
+                # first Adam step = lr * g / (|g| + eps): at most a sign flip of a ~zero gradient apart
+                assert (p.detach() - q.detach()).abs().max().item() <= 2.01 * LRS[n], (n, k)
+        assert (num / max(den, 1e-300)) ** 0.5 <= 1e-5, n
+    v = c._rank_views(2)
+    for n in ("flow", "D", "face"):
+        for k, t in a.sd[n].items():
+            if k.endswith("num_batches_tracked"):
+                assert torch.equal(t, v[0][n][k]) and torch.equal(t, v[1][n][k]), (n, k)
+            elif "running_" in k:
+                assert torch.allclose(t, v[0][n][k], rtol=1e-5, atol=1e-7) and torch.allclose(t, v[1][n][k], rtol=1e-5, atol=1e-7), (n, k)
+                assert v[0][n][k] is not v[1][n][k]
+    k0 = "Downsampler_list.0.enc1.enconv.0.weight"
+    assert v[0]["flow"] is c.sd["flow"] and v[1]["accu"][k0] is c.sd["accu"][k0]
