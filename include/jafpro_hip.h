@@ -272,6 +272,12 @@ int jaf_texture_warp_bwd(jaf_stream_t s, const float* dout, const uint8_t* iuv, 
 int jaf_grid_sample_fwd(jaf_stream_t s, const float* src, const float* grid, float* out,
                         int32_t B, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,
                         int padding_border, int align_corners);
+/* Its adjoint (ATen grid_sampler_2d_backward): dsrc[B,C,H,W] += by scatter-add (nullable), dgrid[B,OH,OW,2]
+ * (nullable); border clamping passes no gradient where it clipped.  Stage 4 never differentiates the flow warp
+ * (SURVEY App. D); this is the "differentiable flow" of SURVEY 8(f1): gradient to the SMPL vertices through T. */
+int jaf_grid_sample_bwd(jaf_stream_t s, const float* dout, const float* src, const float* grid, float* dsrc,
+                        float* dgrid, int32_t B, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                        int padding_border, int align_corners);
 
 /* out = a*m + b*(1-m), m broadcast over C (train/4...py:321; src/flow_net.py:98). */
 int jaf_blend_fwd(jaf_stream_t s, const float* a, const float* b, const float* m, float* out,
@@ -308,9 +314,50 @@ int jaf_project_faces(jaf_stream_t s, const float* verts, const float* cam,
 int64_t jaf_rasterize_workspace(int32_t B, int32_t NF, int32_t S);
 int jaf_rasterize_fim_wim(jaf_stream_t s, const float* faces, int32_t* fim, float* wim,
                           void* workspace, int32_t B, int32_t NF, int32_t S, float near_, float far_);
+/* The whole forward_face_index_map of the reference FFI (rasterize_cuda.cpp:70-95): besides fim / wim the
+ * depth map (far where nothing is hit, rasterize.py:52), the per-pixel inverse of the winning face
+ * (face_inv_map [B,S,S,3,3], return_depth) and the alpha map (rasterize.py:188-192); each of the three is
+ * nullable.  flip = 0 writes the maps as RasterizeFunction saves them for backward, flip = 1 vertically flipped
+ * as rasterize_rgbad returns them (rasterize.py:334-338). */
+int jaf_rasterize_maps(jaf_stream_t s, const float* faces, int32_t* fim, float* wim, float* depth,
+                       float* face_inv_map, float* alpha, void* workspace, int32_t B, int32_t NF, int32_t S,
+                       float near_, float far_, int flip);
+/* backward_pixel_map (rasterize_cuda.cpp:124-147, kernel rasterize_cuda_kernel.cu:245-491): grad_faces[B,NF,3,3]
+ * (caller zeroes it; front faces are overwritten) from the UNFLIPPED maps; the rgb pair and the alpha pair are
+ * each nullable (return_rgb / return_alpha), at least one must be given. */
+int jaf_rasterize_bwd_pixel_map(jaf_stream_t s, const float* faces, const int32_t* face_index_map,
+                                const float* rgb_map, const float* alpha_map, const float* grad_rgb_map,
+                                const float* grad_alpha_map, float* grad_faces, int32_t B, int32_t NF, int32_t S,
+                                float eps);
+/* backward_depth_map (rasterize_cuda.cpp:169-190, kernel :537-593): ADDS to grad_faces. */
+int jaf_rasterize_bwd_depth_map(jaf_stream_t s, const float* faces, const float* depth_map,
+                                const int32_t* face_index_map, const float* face_inv_map, const float* weight_map,
+                                const float* grad_depth_map, float* grad_faces, int32_t B, int32_t NF, int32_t S);
+/* Adjoint of jaf_project_faces (autograd of src/nmr.py:269-276 in the reference): dverts[B,NV,3] += , dcam[B,3] +=
+ * (nullable). */
+int jaf_project_faces_bwd(jaf_stream_t s, const float* dfaces, const float* verts, const float* cam,
+                          const int32_t* faces_idx, float* dverts, float* dcam, int32_t B, int32_t NV, int32_t NF);
+/* Adjoint of jaf_bc_transform w.r.t. the source faces (autograd of src/nmr.py:651-653): dsrc_faces[B,NF,3,3] +=. */
+int jaf_bc_transform_bwd(jaf_stream_t s, const float* dT, const int32_t* fim, const float* wim, float* dsrc_faces,
+                         int32_t B, int32_t NF, int32_t S);
 /* cal_bc_transform fused with the y re-flip of src/cal_flow.py:30-31: T[B,S,S,2]. */
 int jaf_bc_transform(jaf_stream_t s, const float* src_faces /*[B,NF,3,3]*/, const int32_t* fim,
                      const float* wim, float* T, int32_t B, int32_t NF, int32_t S);
+
+/* ------------------------------------------------------------------------------------------
+ * Device-side input pipeline (src/data.py:640-773, src/utils.py:369-394, train/4...py:216-237): raw uint8 frames
+ * in, the tensors of a stage-4 batch out.  The host keeps only what it needs as host integers (face boxes).
+ * ------------------------------------------------------------------------------------------ */
+/* in uint8 [N][HW][C] (cv2.imread layout, C = 1 or 3) -> out fp32 [N][C][HW]; mode 0: (x/255 - 0.5)*2
+ * (src/data.py:746-750), mode 1: x/255 (:751, :739); evaluated in float64 then cast, like the reference. */
+int jaf_u8_hwc_to_f32_chw(jaf_stream_t s, const uint8_t* in, float* out, int32_t N, int32_t HW, int32_t C, int mode);
+/* out fp32 [N][3][S][S] = 1 where IUV part index (channel 0 of uint8 [N][S][S][3]) is 1..24: TransferTexture of an
+ * all-ones atlas (src/data.py:690-695), i.e. src_mask_in_image / tgt_mask_in_image. */
+int jaf_iuv_part_mask(jaf_stream_t s, const uint8_t* iuv, float* out, int32_t N, int32_t S);
+/* TransferTexture (src/utils.py:369-394) on uint8: tex [N or 1][AH][AW][3] (4 x 6 cells), iuv [N][S][S][3], optional
+ * background im [N][S][S][3] -> out [N][S][S][3]. */
+int jaf_transfer_texture_u8(jaf_stream_t s, const uint8_t* tex, const uint8_t* iuv, const uint8_t* im, uint8_t* out,
+                            int32_t N, int32_t S, int32_t AH, int32_t AW, int tex_batched);
 
 /* ------------------------------------------------------------------------------------------
  * Losses, classifier head, optimiser.

@@ -562,12 +562,11 @@ int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, 
 template <int MT, int NT, int NS, bool LSTM>
 static int launch_one(const ConvBArgs& a, hipStream_t s) {
     auto k = conv_bf16_kernel<MT, NT, NS, LSTM>;
-    static int max_lds_set = 0;       // per instantiation; racing writers store the same attribute
+    static int optin[JAF_MAX_DEVICES];
     const int lds = a.p.lds_bytes;
-    if (lds > 48 * 1024 && lds > max_lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        max_lds_set = 160 * 1024;
+    if (lds > 48 * 1024) {
+        const int e = jaf_lds_optin((const void*)k, optin);
+        if (e) return e;
     }
     const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
     if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;

@@ -1012,12 +1012,11 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
 template <int MT, int NT, bool LSTM>
 static int cd_launch_one(const ConvDArgs& a, hipStream_t s) {
     auto k = conv_dma_kernel<MT, NT, LSTM>;
-    static int attr_set = 0;
+    static int optin[JAF_MAX_DEVICES];
     const int lds = a.p.lds_bytes;
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        attr_set = 1;
+    if (lds > 48 * 1024) {
+        const int e = jaf_lds_optin((const void*)k, optin);
+        if (e) return e;
     }
     const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
     if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;

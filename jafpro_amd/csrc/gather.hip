@@ -145,3 +145,61 @@ extern "C" int jaf_grid_sample_fwd(jaf_stream_t s, const float* src, const float
     hipLaunchKernelGGL(grid_sample_fwd_kernel, dim3(jaf_ew_grid((long)B * OH * OW)), dim3(256), 0, (hipStream_t)s, src, grid, out, B, C, H, W, OH, OW, padding_border, align_corners);
     return jaf_launch_status();
 }
+
+// Adjoint of grid_sample_fwd_kernel (ATen grid_sampler_2d_backward, bilinear): dsrc (+=, nullable) by scatter-add,
+// dgrid (nullable) [B,OH,OW,2].  Border mode: the clamp passes a gradient of 1 strictly inside (0, size-1) and 0
+// where it clipped (clip_coordinates_set_grad).
+__global__ void grid_sample_bwd_kernel(const float* dout, const float* src, const float* grid, float* dsrc, float* dgrid, int B,
+                                       int C, int H, int W, int OH, int OW, int border, int align) {
+    const long total = (long)B * OH * OW;
+    const long gs = (long)gridDim.x * blockDim.x;
+    const long OS = (long)OH * OW;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const long b = e / OS;
+        const long pix = e - b * OS;
+        float ix = gs_unnormalize(grid[e * 2], W, align);
+        float iy = gs_unnormalize(grid[e * 2 + 1], H, align);
+        float gix_mult = align ? (float)(W - 1) / 2.f : (float)W / 2.f;
+        float giy_mult = align ? (float)(H - 1) / 2.f : (float)H / 2.f;
+        if (border) {
+            if (ix <= 0.f) { ix = 0.f; gix_mult = 0.f; } else if (ix >= (float)(W - 1)) { ix = (float)(W - 1); gix_mult = 0.f; }
+            if (iy <= 0.f) { iy = 0.f; giy_mult = 0.f; } else if (iy >= (float)(H - 1)) { iy = (float)(H - 1); giy_mult = 0.f; }
+        }
+        const WarpTap t = make_tap(ix, iy);
+        const float ax = ix - (float)t.x0, ay = iy - (float)t.y0;
+        const bool xw = t.x0 >= 0 && t.x0 < W, xe = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+        const bool yn = t.y0 >= 0 && t.y0 < H, ys = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+        const long o = (long)t.y0 * W + t.x0;
+        float gix = 0.f, giy = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float g = dout[(b * C + c) * OS + pix];
+            const long pb = (b * C + c) * (long)H * W;
+            if (dsrc && g != 0.f) {
+                if (yn && xw) atomicAdd(&dsrc[pb + o], g * t.wnw);
+                if (yn && xe) atomicAdd(&dsrc[pb + o + 1], g * t.wne);
+                if (ys && xw) atomicAdd(&dsrc[pb + o + W], g * t.wsw);
+                if (ys && xe) atomicAdd(&dsrc[pb + o + W + 1], g * t.wse);
+            }
+            if (dgrid) {
+                const float* sp = src + pb;
+                const float nw = (yn && xw) ? sp[o] : 0.f, ne = (yn && xe) ? sp[o + 1] : 0.f;
+                const float sw = (ys && xw) ? sp[o + W] : 0.f, se = (ys && xe) ? sp[o + W + 1] : 0.f;
+                gix += g * ((ne - nw) * (1.f - ay) + (se - sw) * ay);
+                giy += g * ((sw - nw) * (1.f - ax) + (se - ne) * ax);
+            }
+        }
+        if (dgrid) {
+            dgrid[e * 2] = gix_mult * gix;
+            dgrid[e * 2 + 1] = giy_mult * giy;
+        }
+    }
+}
+
+extern "C" int jaf_grid_sample_bwd(jaf_stream_t s, const float* dout, const float* src, const float* grid, float* dsrc,
+                                   float* dgrid, int32_t B, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                                   int padding_border, int align_corners) {
+    JAF_REQUIRE(dout && src && grid && (dsrc || dgrid) && B >= 1 && C >= 1 && H >= 1 && W >= 1 && OH >= 1 && OW >= 1);
+    hipLaunchKernelGGL(grid_sample_bwd_kernel, dim3(jaf_ew_grid((long)B * OH * OW)), dim3(256), 0, (hipStream_t)s, dout, src, grid,
+                       dsrc, dgrid, B, C, H, W, OH, OW, padding_border, align_corners);
+    return jaf_launch_status();
+}

@@ -17,6 +17,23 @@ static inline int jaf_launch_status() {
 
 #define JAF_REQUIRE(cond) do { if (!(cond)) return JAF_EINVAL; } while (0)
 
+// Opt a kernel into > 48 KB of dynamic LDS.  The attribute belongs to the (kernel, DEVICE) pair, so the
+// "already done" flag is kept per device of the calling thread (`cache`: one zero-initialised int[JAF_MAX_DEVICES]
+// per kernel instantiation); racing callers store the same value.  Returns 0 or the hipError_t.
+#define JAF_MAX_DEVICES 64
+static inline int jaf_lds_optin(const void* kernel, int* cache) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= JAF_MAX_DEVICES) return JAF_EINVAL;
+    if (!cache[dev]) {
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        cache[dev] = 1;
+    }
+    return 0;
+}
+
 static inline int jaf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // grid for HBM-bound elementwise kernels: cap at 2048 blocks of 256 and grid-stride

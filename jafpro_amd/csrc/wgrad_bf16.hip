@@ -343,11 +343,10 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
 #define JAF_WGB(MT_)                                                                                   \
     do {                                                                                               \
         auto k = conv_wgrad_bf16_kernel<MT_>;                                                          \
-        static int attr_set = 0;                                                                       \
-        if (lds > 48 * 1024 && !attr_set) {                                                            \
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return (int)e;                                                        \
-            attr_set = 1;                                                                              \
+        static int optin[JAF_MAX_DEVICES];                                                             \
+        if (lds > 48 * 1024) {                                                                         \
+            const int e = jaf_lds_optin((const void*)k, optin);                                        \
+            if (e) return e;                                                                           \
         }                                                                                              \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)

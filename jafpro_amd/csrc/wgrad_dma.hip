@@ -313,11 +313,10 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
 #define JAF_WGD(MT_, KS_)                                                                              \
     do {                                                                                               \
         auto k = conv_wgrad_dma_kernel<MT_, KS_>;                                                      \
-        static int attr_set = 0;                                                                       \
-        if (lds > 48 * 1024 && !attr_set) {                                                            \
-            hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            if (e != hipSuccess) return (int)e;                                                        \
-            attr_set = 1;                                                                              \
+        static int optin[JAF_MAX_DEVICES];                                                             \
+        if (lds > 48 * 1024) {                                                                         \
+            const int e = jaf_lds_optin((const void*)k, optin);                                        \
+            if (e) return e;                                                                           \
         }                                                                                              \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)

@@ -175,7 +175,18 @@ class Accumulate_LSTM(Accumulate_LSTM_no_loss):
     def forward(self, x_in, src_texture_mask, tgt_texture_mask, tgt_texture_im):
         T = len(x_in[0])
         x = torch.cat([torch.cat([x_in[p][t] for p in range(NPARTS)], dim=1) for t in range(T)], dim=0)
-        out = self.forward_grouped(x, T)                      # [B,72,200,200]
+        return self._paste_and_loss(self.forward_grouped(x, T), src_texture_mask, tgt_texture_mask, tgt_texture_im)
+
+    def forward_atlas(self, src_texture_im, src_texture_mask, tgt_texture_mask, tgt_texture_im):
+        """Same as forward() with the reference textures given as atlases [B,T,3,800,1200] (the 24-part slicing of
+        train/1...py:151-158 runs in one kernel)."""
+        T = src_texture_im.shape[1]
+        return self._paste_and_loss(self.forward_grouped(ops.atlas_to_parts(src_texture_im.contiguous()), T),
+                                    src_texture_mask, tgt_texture_mask, tgt_texture_im)
+
+    def _paste_and_loss(self, out, src_texture_mask, tgt_texture_mask, tgt_texture_im):
+        """out [B,72,200,200] -> (atlas, loss), src/networks.py:1614-1639.  Masks are uint8 {0,1} with a singleton or
+        3-wide channel axis ((B,T,1|3,800,1200)); the loss always compares with target 0 (`tgt_texture_im[:,0]`, :1634)."""
         B = out.shape[0]
         # atlas paste (:1614-1620): part p -> rows (p//6)*200, cols (p%6)*200
         atlas = out.view(B, 4, 6, 3, 200, 200).permute(0, 3, 1, 4, 2, 5).reshape(B, 3, 800, 1200)
@@ -184,9 +195,10 @@ class Accumulate_LSTM(Accumulate_LSTM_no_loss):
             common = common | src_texture_mask[:, i]
         loss = None
         real = tgt_texture_im[:, 0].float().contiguous()
+        atlas_c = atlas.contiguous()
         for i in range(tgt_texture_mask.shape[1]):
             area = (common & tgt_texture_mask[:, i]).float().contiguous()
-            gen = ops.mul_bcast(atlas.contiguous(), area)
+            gen = ops.mul_bcast(atlas_c, area)
             rl = ops.mul_bcast(real, area)
             term = ops.l1_loss(gen, rl, 1.0)
             loss = term if loss is None else loss + term

@@ -40,6 +40,8 @@ class SMPLRenderer(nn.Module):
         self.near, self.far = near, far
         self.viewing_angle = viewing_angle
         self.eye = [0, 0, -(1. / np.tan(np.radians(self.viewing_angle)) + 1)]
+        self.rasterizer_eps = 1e-3          # src/nmr.py:170 (only the textured render path passes it on)
+        self.anti_aliasing = anti_aliasing
 
     def project(self, cam, vertices, faces=None):
         """Projection + y-flip + look_at + vertices_to_faces (src/nmr.py:269-276) -> faces [B,NF,3,3]."""
@@ -54,6 +56,25 @@ class SMPLRenderer(nn.Module):
         f = self.project(cam, vertices, faces)
         fim, wim = ops.rasterize_fim_wim(f, self.image_size, 0.1, 100.0)
         return f, fim, wim
+
+    def _supersampled(self, fn, cam, vertices, faces):
+        """rasterize_rgbad's anti-aliasing (rasterize.py:316-348): render at 2x, flip, 2x2 average pool."""
+        f = self.project(cam, vertices, faces)
+        if not self.anti_aliasing:
+            return fn(f, self.image_size, 0.1, 100.0, 1e-4)
+        img = fn(f, self.image_size * 2, 0.1, 100.0, 1e-4)
+        return ops.avg_pool(img.unsqueeze(1).contiguous(), 2, 2, 0)[:, 0]
+
+    def render_silhouettes(self, cam, vertices, faces=None):
+        """src/nmr.py:295-310: silhouette [B,S,S] of the projected mesh via neural_renderer.rasterize_silhouettes
+        (near 0.1, far 100, eps 1e-4: rasterize.py:8-13), differentiable w.r.t. vertices and camera with
+        neural_renderer's approximate silhouette gradient (rasterize_cuda_kernel.cu:245-491)."""
+        return self._supersampled(ops.rasterize_silhouettes, cam, vertices, faces)
+
+    def render_depth(self, cam, vertices, faces=None):
+        """Depth map [B,S,S] (far = 100 where nothing is hit).  The reference method is a stub that raises
+        (src/nmr.py:279-292); the renderer it was meant to call is neural_renderer.rasterize_depth (rasterize.py:455-481)."""
+        return self._supersampled(ops.rasterize_depth, cam, vertices, faces)
 
     def cal_bc_transform(self, src_f2pts, dst_fims, dst_wims):
         """src_f2pts: (bs, nf, 3, 2) source face vertices (x, y already re-flipped); returns T (bs,S,S,2)."""

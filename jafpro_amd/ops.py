@@ -55,6 +55,7 @@ def _c(t: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------
 _PLAN_CACHE = {}
 _PACK_CACHE = {}
+_PACK_CACHE_MAX = 4096
 _PACK_KEYS_BY_ID = {}
 _PROF = None
 _PRECISION = PREC_F32
@@ -237,9 +238,20 @@ def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mo
                 hit.buf.record_stream(cur)          # ... and keep the block from being reused under this stream's reads
                 hit.waited.add(sid)
         return hit.buf
-    if len(_PACK_CACHE) > 4096:
-        _PACK_CACHE.clear()
-        _PACK_KEYS_BY_ID.clear()
+    if len(_PACK_CACHE) >= _PACK_CACHE_MAX:
+        # bounded cache with first-in-first-out eviction of the oldest quarter (a stage-4 trainer holds ~700 images;
+        # the bound only matters for processes that keep building new models): the dropped images were
+        # record_stream-ed on every stream that wrote or read them, so freeing them here is safe
+        for ck in list(_PACK_CACHE)[:_PACK_CACHE_MAX // 4]:
+            ent = _PACK_CACHE.pop(ck)
+            keys = _PACK_KEYS_BY_ID.get(ck[0])
+            if keys is not None:
+                try:
+                    keys.remove(ck)
+                except ValueError:
+                    pass
+                if not keys:
+                    _PACK_KEYS_BY_ID.pop(ck[0], None)
     buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
     check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
           "jaf_conv2d_pack")
@@ -987,16 +999,41 @@ def texture_warp(tex: torch.Tensor, iuv255: torch.Tensor, align_corners: bool = 
     return _TextureWarpFn.apply(tex, iuv255, align_corners)
 
 
+class _GridSampleFn(Function):
+    @staticmethod
+    def forward(ctx, src, grid, padding_border, align_corners):
+        B, C, H, W = src.shape
+        OH, OW = grid.shape[1], grid.shape[2]
+        out = torch.empty((B, C, OH, OW), device=src.device, dtype=torch.float32)
+        with _hbm("grid_sample_fwd_kernel", 4.0 * B * (C * H * W + 2 * OH * OW + C * OH * OW)):
+            check(lib().jaf_grid_sample_fwd(_s(), _p(src), _p(grid), _p(out), B, C, H, W, OH, OW, 1 if padding_border else 0,
+                                            1 if align_corners else 0), "jaf_grid_sample_fwd")
+        ctx.cfg = (padding_border, align_corners)
+        ctx.save_for_backward(src, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, grid = ctx.saved_tensors
+        padding_border, align_corners = ctx.cfg
+        B, C, H, W = src.shape
+        OH, OW = grid.shape[1], grid.shape[2]
+        dout = _c(dout)
+        dsrc = torch.zeros_like(src) if ctx.needs_input_grad[0] else None
+        dgrid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        check(lib().jaf_grid_sample_bwd(_s(), _p(dout), _p(src), _p(grid), _p(dsrc), _p(dgrid), B, C, H, W, OH, OW,
+                                        1 if padding_border else 0, 1 if align_corners else 0), "jaf_grid_sample_bwd")
+        return dsrc, dgrid, None, None
+
+
 def grid_sample(src, grid, padding_border: bool, align_corners: bool = False):
-    """Forward-only bilinear grid_sample (the flow warp carries no gradient on this path)."""
+    """Bilinear F.grid_sample (zeros or border padding).  Stage 4 only runs it forward (the flow warp carries no
+    gradient there); the adjoint w.r.t. the image and the grid is the differentiable flow of SURVEY 8(f1)."""
     _chk(src, "grid_sample src"); _chk(grid, "grid_sample grid")
-    B, C, H, W = src.shape
-    OH, OW = grid.shape[1], grid.shape[2]
-    out = torch.empty((B, C, OH, OW), device=src.device, dtype=torch.float32)
-    with _hbm("grid_sample_fwd_kernel", 4.0 * B * (C * H * W + 2 * OH * OW + C * OH * OW)):
-        check(lib().jaf_grid_sample_fwd(_s(), _p(src), _p(grid), _p(out), B, C, H, W, OH, OW, 1 if padding_border else 0,
-                                        1 if align_corners else 0), "jaf_grid_sample_fwd")
-    return out
+    if src.requires_grad or grid.requires_grad:
+        return _GridSampleFn.apply(src, grid, bool(padding_border), bool(align_corners))
+    with torch.no_grad():
+        return _GridSampleFn.apply(src, grid, bool(padding_border), bool(align_corners))
 
 
 class _BlendFn(Function):
@@ -1239,14 +1276,93 @@ def axpby(a: float, x, b: float, y):
 # --------------------------------------------------------------------------------------------
 # renderer path (forward only: vertices carry no gradient in stage 4)
 # --------------------------------------------------------------------------------------------
+class _ProjectFacesFn(Function):
+    @staticmethod
+    def forward(ctx, verts, cam, faces_idx, eye_z):
+        B, NV, _ = verts.shape
+        NF = faces_idx.shape[0]
+        out = torch.empty((B, NF, 3, 3), device=verts.device, dtype=torch.float32)
+        check(lib().jaf_project_faces(_s(), _p(verts), _p(cam), _p(faces_idx), _p(out), B, NV, NF, eye_z),
+              "jaf_project_faces")
+        ctx.save_for_backward(verts, cam, faces_idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dfaces):
+        verts, cam, faces_idx = ctx.saved_tensors
+        B, NV, _ = verts.shape
+        NF = faces_idx.shape[0]
+        dfaces = _c(dfaces)
+        dverts = torch.zeros_like(verts)
+        dcam = torch.zeros_like(cam) if ctx.needs_input_grad[1] else None
+        check(lib().jaf_project_faces_bwd(_s(), _p(dfaces), _p(verts), _p(cam), _p(faces_idx), _p(dverts), _p(dcam), B, NV, NF),
+              "jaf_project_faces_bwd")
+        return dverts, dcam, None, None
+
+
 def project_faces(verts, cam, faces_idx, eye_z: float):
+    """src/nmr.py:269-276 in one kernel: orthographic projection, y flip, look_at translation, vertices_to_faces.
+    Differentiable w.r.t. the vertices and the camera."""
     _chk(verts, "verts"); _chk(cam, "cam"); _chk(faces_idx, "faces", torch.int32)
-    B, NV, _ = verts.shape
-    NF = faces_idx.shape[0]
-    out = torch.empty((B, NF, 3, 3), device=verts.device, dtype=torch.float32)
-    check(lib().jaf_project_faces(_s(), _p(verts), _p(cam), _p(faces_idx), _p(out), B, NV, NF, eye_z),
-          "jaf_project_faces")
-    return out
+    return _ProjectFacesFn.apply(verts, cam, faces_idx, float(eye_z))
+
+
+class _RasterizeFn(Function):
+    """RasterizeFunction of neural_renderer (rasterize.py:16-160) without its texture branch: forward fills the
+    face-index / weight / depth / face-inverse / alpha maps, backward is backward_pixel_map (alpha) followed by
+    backward_depth_map.  Maps are UNFLIPPED here, like the reference Function's; the wrappers below flip."""
+
+    @staticmethod
+    def forward(ctx, faces, image_size, near, far, eps, return_alpha, return_depth):
+        B, NF = faces.shape[0], faces.shape[1]
+        S = image_size
+        L = lib()
+        dev = faces.device
+        ws = torch.empty(int(L.jaf_rasterize_workspace(B, NF, S)), device=dev, dtype=torch.uint8)
+        fim = torch.empty((B, S, S), device=dev, dtype=torch.int32)
+        wim = torch.empty((B, S, S, 3), device=dev, dtype=torch.float32)
+        depth = torch.empty((B, S, S), device=dev, dtype=torch.float32)
+        finv = torch.empty((B, S, S, 3, 3), device=dev, dtype=torch.float32) if return_depth else None
+        alpha = torch.empty((B, S, S), device=dev, dtype=torch.float32)
+        check(L.jaf_rasterize_maps(_s(), _p(faces), _p(fim), _p(wim), _p(depth), _p(finv), _p(alpha), _p(ws), B, NF, S,
+                                   near, far, 0), "jaf_rasterize_maps")
+        ctx.cfg = (S, eps, return_alpha, return_depth)
+        ctx.save_for_backward(faces, fim, wim, depth, finv, alpha)
+        ctx.mark_non_differentiable(fim, wim)
+        ctx.set_materialize_grads(False)
+        return alpha.clone(), depth.clone(), fim, wim
+
+    @staticmethod
+    def backward(ctx, g_alpha, g_depth, _g_fim, _g_wim):
+        faces, fim, wim, depth, finv, alpha = ctx.saved_tensors
+        S, eps, return_alpha, return_depth = ctx.cfg
+        B, NF = faces.shape[0], faces.shape[1]
+        L = lib()
+        g = torch.zeros_like(faces)
+        if return_alpha and g_alpha is not None:
+            check(L.jaf_rasterize_bwd_pixel_map(_s(), _p(faces), _p(fim), None, _p(alpha), None, _p(_c(g_alpha)), _p(g), B, NF, S,
+                                                eps), "jaf_rasterize_bwd_pixel_map")
+        if return_depth and g_depth is not None:
+            check(L.jaf_rasterize_bwd_depth_map(_s(), _p(faces), _p(depth), _p(fim), _p(finv), _p(wim), _p(_c(g_depth)), _p(g),
+                                                B, NF, S), "jaf_rasterize_bwd_depth_map")
+        return g, None, None, None, None, None, None
+
+
+def rasterize(faces, image_size: int, near: float = 0.1, far: float = 100.0, eps: float = 1e-4, return_alpha: bool = True,
+              return_depth: bool = False):
+    """-> (alpha, depth, fim, wim), unflipped (see _RasterizeFn); differentiable w.r.t. `faces` through alpha / depth."""
+    _chk(faces, "faces")
+    return _RasterizeFn.apply(faces, int(image_size), float(near), float(far), float(eps), bool(return_alpha), bool(return_depth))
+
+
+def rasterize_silhouettes(faces, image_size: int, near: float = 0.1, far: float = 100.0, eps: float = 1e-4):
+    """neural_renderer.rasterize_silhouettes without anti-aliasing (rasterize.py:428-452): alpha [B,S,S], flipped (:334-338)."""
+    return torch.flip(rasterize(faces, image_size, near, far, eps, True, False)[0], dims=(1,))
+
+
+def rasterize_depth(faces, image_size: int, near: float = 0.1, far: float = 100.0, eps: float = 1e-4):
+    """neural_renderer.rasterize_depth without anti-aliasing (rasterize.py:455-481): depth [B,S,S], flipped."""
+    return torch.flip(rasterize(faces, image_size, near, far, eps, False, True)[1], dims=(1,))
 
 
 def rasterize_fim_wim(faces, image_size: int, near: float = 0.1, far: float = 100.0):
@@ -1261,10 +1377,28 @@ def rasterize_fim_wim(faces, image_size: int, near: float = 0.1, far: float = 10
     return fim, wim
 
 
+class _BcTransformFn(Function):
+    @staticmethod
+    def forward(ctx, src_faces, fim, wim):
+        B, NF = src_faces.shape[0], src_faces.shape[1]
+        S = fim.shape[1]
+        T = torch.empty((B, S, S, 2), device=fim.device, dtype=torch.float32)
+        check(lib().jaf_bc_transform(_s(), _p(src_faces), _p(fim), _p(wim), _p(T), B, NF, S), "jaf_bc_transform")
+        ctx.save_for_backward(fim, wim)
+        ctx.shape = (B, NF, S)
+        return T
+
+    @staticmethod
+    def backward(ctx, dT):
+        fim, wim = ctx.saved_tensors
+        B, NF, S = ctx.shape
+        d = torch.zeros((B, NF, 3, 3), device=dT.device, dtype=torch.float32)
+        check(lib().jaf_bc_transform_bwd(_s(), _p(_c(dT)), _p(fim), _p(wim), _p(d), B, NF, S), "jaf_bc_transform_bwd")
+        return d, None, None
+
+
 def bc_transform(src_faces, fim, wim):
+    """cal_bc_transform (src/nmr.py:617-659) with the y re-flip of src/cal_flow.py:30-31; differentiable w.r.t. the
+    source faces (the index / weight maps carry no gradient, as in the reference)."""
     _chk(src_faces, "src_faces"); _chk(fim, "fim", torch.int32); _chk(wim, "wim")
-    B, NF = src_faces.shape[0], src_faces.shape[1]
-    S = fim.shape[1]
-    T = torch.empty((B, S, S, 2), device=fim.device, dtype=torch.float32)
-    check(lib().jaf_bc_transform(_s(), _p(src_faces), _p(fim), _p(wim), _p(T), B, NF, S), "jaf_bc_transform")
-    return T
+    return _BcTransformFn.apply(src_faces, fim, wim)

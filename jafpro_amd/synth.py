@@ -205,3 +205,28 @@ def stage4_clip(seed: int, B: int, F: int, T: int = 4, S: int = 256) -> Dict[str
     d["chosen_frame"] = np.array([(t * max(F - 1, 1)) // max(T - 1, 1) for t in range(T)], np.int64)
     return d
 
+
+
+def stage1_batch(seed: int, B: int, T: int = 4, Z: int = 3) -> Dict[str, np.ndarray]:
+    """BASELINE config 1 inputs: reference atlases and masks, Z target atlases and masks
+    (Fusion_dataset_textonly after the permutes of train/1.text_accu_LSTM.py:121-127)."""
+    return {"src_texture_im": uniform(seed, "s1_src_tex", (B, T, 3, 800, 1200)),
+            "src_mask_im": rect_masks(seed, "s1_src_mask", (B, T, 800, 1200)),
+            "tgt_texture_im": uniform(seed, "s1_tgt_tex", (B, Z, 3, 800, 1200)),
+            "tgt_mask_im": rect_masks(seed, "s1_tgt_mask", (B, Z, 800, 1200))}
+
+
+def stage4_raw(seed: int, B: int, T: int = 4, S: int = 256) -> Dict[str, np.ndarray]:
+    """A stage-4 sample batch as the dataset holds it right after decoding (uint8, HWC, BGR order is irrelevant here):
+    input of jafpro_amd.data.stage4_batch_from_uint8 / oracle.data_oracle.stage4_batch."""
+    r = _rng(seed, "raw")
+    d: Dict[str, np.ndarray] = {}
+    d["src_texture_u8"] = r.integers(0, 256, (B, T, 800, 1200, 3), dtype=np.uint8)
+    d["src_mask_u8"] = (rect_masks(seed, "raw_mask", (B, T, 800, 1200)) * 255).astype(np.uint8)
+    d["src_img_u8"] = r.integers(0, 256, (B, T, S, S, 3), dtype=np.uint8)
+    d["tgt_img_u8"] = r.integers(0, 256, (B, S, S, 3), dtype=np.uint8)
+    d["src_IUV0_u8"] = iuv255(seed, "raw_src_iuv", B, S)
+    d["tgt_IUV_u8"] = iuv255(seed, "raw_tgt_iuv", B, S)
+    d["smpl_real_mask_u8"] = np.repeat(((d["tgt_IUV_u8"][..., 0] > 0) * 255).astype(np.uint8)[..., None], 3, -1)
+    d["smpl_real_mask_u8"][:, ::7, ::5] = 131                 # soft edges: values other than 0 / 255
+    return d

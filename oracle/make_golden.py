@@ -332,6 +332,90 @@ def g_stage1():
     np.savez_compressed(os.path.join(GOLD, "stage1_b1_t2.npz"), **st)
 
 
+# ---- 10b. BASELINE config 1 in full: stage-1 step at T=4 with backward + Adam(1e-4) (train/1...py:140-176) -------
+def g_stage1_t4():
+    from oracle.stage_oracle import OracleStage1
+    st = {}
+    m = synth.load_synth(RN.Accumulate_LSTM(), 111)
+    sd0 = sd_of(m)
+    b = {k: T(v) for k, v in synth.stage1_batch(611, 1).items()}
+    used = [0, 1, 2, 3]
+    x_in = [[b["src_texture_im"][:, t, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200] for t in used] for i in range(4) for j in range(6)]
+    src_mask = b["src_mask_im"].byte().unsqueeze(2).repeat(1, 1, 3, 1, 1)
+    tgt_mask = b["tgt_mask_im"].byte().unsqueeze(2).repeat(1, 1, 3, 1, 1)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    opt.zero_grad()
+    atlas, loss = m(x_in, src_mask, tgt_mask, b["tgt_texture_im"])
+    loss.sum().backward()
+    grads = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    opt.step()
+    after = sd_of(m)
+    orc = OracleStage1(sd0)
+    ro = orc.train_step(b, used)
+    report["stage1_t4_loss"] = close(ro["total_loss"].reshape(1), loss.reshape(1), 1e-6, "stage-1 T=4 loss")
+    num = den = 0.0
+    for k, g in grads.items():
+        num += float(((orc.sd[k].grad - g).double() ** 2).sum()); den += float((g.double() ** 2).sum())
+    report["stage1_t4_grad_rel"] = (num / den) ** 0.5
+    print("  oracle vs reference stage-1 T=4 gradients rel-L2 = %.3e" % report["stage1_t4_grad_rel"])
+    assert report["stage1_t4_grad_rel"] <= 1e-5
+    report["stage1_t4_adam_max"] = max(float((orc.sd[k].detach() - v).abs().max()) for k, v in after.items())
+    assert report["stage1_t4_adam_max"] <= 2.01e-4        # lr * sign(g) apart at worst (a ~zero gradient flipping sign)
+    put(st, "loss", loss.reshape(1), True); put(st, "atlas", atlas)
+    keys = ["Downsampler_list.0.enc1.enconv.0.weight", "Downsampler_list.5.convLSTM1.cell_list.0.conv.weight",
+            "Downsampler_list.11.convLSTM5.cell_list.0.conv.bias", "Downsampler_list.17.enc8.enconv.0.weight",
+            "Upsampler_list.3.dec2.myconv.0.weight", "Upsampler_list.23.conv.weight"]
+    for k in keys:
+        put(st, "grad." + k, grads[k], True)
+        put(st, "delta." + k, after[k] - sd0[k], True)
+    # whole-model digests: sum of squares of every gradient, per parameter family
+    fam = {}
+    for k, g in grads.items():
+        f = ".".join(k.split(".")[2:])
+        fam[f] = fam.get(f, 0.0) + float((g.double() ** 2).sum())
+    st["gradsq.families"] = np.array(sorted(fam), dtype="U64")
+    st["gradsq.values"] = np.array([fam[f] for f in sorted(fam)], np.float64)
+    np.savez_compressed(os.path.join(GOLD, "stage1_b1_t4_step.npz"), **st)
+
+
+# ---- 10c. checkpoint files go both ways (train/3...py:481-494, train/4...py:121-140,518-533) --------------------
+def g_checkpoints():
+    import hashlib
+    import tempfile
+    from jafpro_amd import crn_model, flow_net, networks, stages
+    pairs = {"accu": (RN.Accumulate_LSTM_no_loss, networks.Accumulate_LSTM_no_loss), "inpaint": (RN.UNet_inpainter, networks.UNet_inpainter),
+             "bg": (lambda: RCRN(3), lambda: crn_model.CRN_smaller(3)), "refine": (lambda: RCRN(3, fg=True), lambda: crn_model.CRN_smaller(3, fg=True)),
+             "D": (lambda: RN.ImageDiscriminator(32, 6), lambda: networks.ImageDiscriminator(32, 6)),
+             "face": (lambda: RN.FaceDiscriminator(32, 6), lambda: networks.FaceDiscriminator(32, 6)),
+             "flow": (lambda: RPro(9, 32, 2, 3, use_deconv=False), lambda: flow_net.Propagation3DFlowNet(9, 32, 2, 3, use_deconv=False))}
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for i, (name, (mk_ref, mk_mir)) in enumerate(pairs.items()):
+            ref, mir = synth.load_synth(mk_ref(), 700 + i), mk_mir()
+            # reference -> file -> mirror (what loading the released Accu_/inpaint_/bg_/refine_/pro_iter_*.pth does)
+            rp = os.path.join(td, "ref_%s.pth" % name)
+            torch.save(ref.state_dict(), rp)
+            res = stages.load_checkpoint(mir, rp, strict=True)
+            ok_in = not res.missing_keys and not res.unexpected_keys and all(
+                torch.equal(a, b) for a, b in zip(ref.state_dict().values(), mir.state_dict().values()))
+            # mirror -> file -> reference
+            mp = stages.save_checkpoints(td, 36000, {name: mir})[name]
+            assert os.path.basename(mp) == "%s_iter_36000.pth" % stages.CKPT_PREFIX[name]
+            ref2 = mk_ref()
+            res2 = ref2.load_state_dict(torch.load(mp), strict=True)
+            ok_out = all(torch.equal(a, b) for a, b in zip(ref.state_dict().values(), ref2.state_dict().values()))
+            keys_same = list(torch.load(mp).keys()) == list(ref.state_dict().keys())
+            h = hashlib.sha256()
+            for k, v in ref.state_dict().items():
+                h.update(k.encode()); h.update(v.detach().cpu().contiguous().numpy().tobytes())
+            out[name] = {"file": os.path.basename(mp), "reference_to_mirror": bool(ok_in), "mirror_to_reference": bool(ok_out),
+                         "key_order_equal": bool(keys_same), "entries": len(ref.state_dict()), "seed": 700 + i, "sha256": h.hexdigest()}
+            print("  checkpoint %-8s in %s out %s order %s" % (name, ok_in, ok_out, keys_same))
+            assert ok_in and ok_out and keys_same
+    json.dump(out, open(os.path.join(GOLD, "checkpoint_pin.json"), "w"), indent=1, sort_keys=True)
+    report["checkpoint_files_roundtrip"] = len(out)
+
+
 # ---- 11. state_dict schema of the boundary modules -------------------------------
 def g_schema():
     mods = {"Accumulate_LSTM_no_loss": RN.Accumulate_LSTM_no_loss(), "UNet_inpainter": RN.UNet_inpainter(),

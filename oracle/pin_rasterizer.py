@@ -5,6 +5,8 @@ golden vectors for the rasteriser path:
   * tests/test_rasterize_silhouettes.py:16-35  teapot silhouette == tests/data/teapot_blender.png
   * tests/test_look_at.py:9-25                 look_at known answers
   * tests/test_perspective.py:9-14             perspective known answer
+  * tests/test_rasterize_depth.py:37-54        teapot depth map == tests/data/test_depth.png (atol 1e-2)
+  * tests/test_rasterize_silhouettes.py:37-99  the two known-answer vertex gradients of the silhouette (rtol 1e-2)
 and writes tests/golden/raster_pin.json with the verdicts plus a small fixture of OUR OWN
 (single triangle / tetrahedron-like / procedural body mesh digests) that the CPU and GPU tests
 replay.  No reference file content is copied into the repo.
@@ -67,9 +69,38 @@ def main():
     res["teapot_silhouette_equal"] = bool(np.allclose(ref, sil))
     res["teapot_mismatch_pixels"] = int((ref != sil).sum())
     res["teapot_coverage"] = float(sil.mean())
+    # depth (tests/test_rasterize_depth.py:16-54): Renderer.render_depth -> rasterize_depth, same camera
+    from oracle import raster_autograd as RA
+    _, _, depth, _ = raster_oracle.rasterize_maps(f33, 256, 0.1, 100.0, flip=True)
+    image = depth[0].copy()
+    res["teapot_depth_silhouette_equal"] = bool(np.allclose(ref, (image != image.max()).astype(np.float32)))
+    image[image == image.max()] = image.min()
+    image = (image - image.min()) / (image.max() - image.min())
+    dref = np.asarray(Image.open(os.path.join(REF, "test_depth.png"))).astype(np.float32) / 255.
+    res["teapot_depth_max_abs_diff"] = float(np.abs(image - dref).max())
+    res["teapot_depth_allclose_1e-2"] = bool(np.allclose(image, dref, atol=1e-2))
+    # digests of OUR depth map so that the CPU / GPU tests can replay this pin without the reference's files
+    res["teapot_depth_digest"] = {"sum": float(depth[0].astype(np.float64).sum()), "min": float(depth[0].min()),
+                                  "fg_mean": float(depth[0][fim[0] >= 0].astype(np.float64).mean())}
+
+    # known-answer vertex gradients of the silhouette (tests/test_rasterize_silhouettes.py:37-99)
+    def kat(verts, pyi, pxi, minus1):
+        v = torch.zeros(4, 3, 3)
+        v[2] = torch.tensor(verts)
+        v.requires_grad_(True)
+        img = RA.rasterize_silhouettes(RA.renderer_faces(v, np.array([[0, 1, 2]]), perspective=False), 64)
+        torch.sum(torch.abs(img[:, pyi, pxi] - (1 if minus1 else 0))).backward()
+        return v.grad[2].numpy()
+    g1 = kat([[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]], 25, 35, True)
+    g2 = kat([[0.8, 0.8, 1.], [-0.5, -0.8, 1.], [0.8, -0.8, 1.]], 40, 50, False)
+    r1 = np.array([[1.6725862, -0.26021874, 0.], [1.41986704, -1.64284933, 0.], [0., 0., 0.]], np.float32)
+    r2 = np.array([[0.98646867, 1.04628897, 0.], [-1.03415668, -0.10403691, 0.], [3.00094461, -1.55173182, 0.]], np.float32)
+    res["silhouette_grad_kat1"] = bool(np.allclose(g1, r1, rtol=1e-2))
+    res["silhouette_grad_kat2"] = bool(np.allclose(g2, r2, rtol=1e-2))
     json.dump(res, open(OUT, "w"), indent=1)
     print(res)
     assert res["look_at_kat"] and res["perspective_kat"] and res["teapot_silhouette_equal"], res
+    assert res["teapot_depth_allclose_1e-2"] and res["silhouette_grad_kat1"] and res["silhouette_grad_kat2"], res
 
 
 if __name__ == "__main__":

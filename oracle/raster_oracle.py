@@ -17,21 +17,80 @@ def build():
     if os.path.exists(SO) and os.path.getmtime(SO) >= os.path.getmtime(src):
         return SO
     os.makedirs(os.path.dirname(SO), exist_ok=True)
-    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, src])
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-o", SO, src, "-lm"])
     return SO
 
 
 _lib = None
 
 
-def rasterize_fim_wim(faces: np.ndarray, image_size: int = 256, near: float = 0.1, far: float = 100.0):
-    """faces float32 [B,NF,3,3] -> (fim int32 [B,S,S], wim float32 [B,S,S,3])."""
+def _load():
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(build())
-        _lib.raster_oracle_fim_wim.restype = ctypes.c_int
-        _lib.raster_oracle_fim_wim.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                               ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float]
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        _lib.raster_oracle_fim_wim.restype = ci
+        _lib.raster_oracle_fim_wim.argtypes = [vp, vp, vp, ci, ci, ci, cf, cf]
+        _lib.raster_oracle_maps.restype = ci
+        _lib.raster_oracle_maps.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, cf, cf, ci]
+        _lib.raster_oracle_bwd_pixel_map.restype = ci
+        _lib.raster_oracle_bwd_pixel_map.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf]
+        _lib.raster_oracle_bwd_depth_map.restype = ci
+        _lib.raster_oracle_bwd_depth_map.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def rasterize_maps(faces: np.ndarray, image_size: int, near: float = 0.1, far: float = 100.0, flip: bool = False):
+    """faces float32 [B,NF,3,3] -> (fim int32 [B,S,S], wim [B,S,S,3], depth [B,S,S], face_inv_map [B,S,S,9]);
+    flip=False gives the maps RasterizeFunction saves for backward, flip=True what rasterize_rgbad returns."""
+    L = _load()
+    faces = np.ascontiguousarray(faces, np.float32)
+    B, NF, S = faces.shape[0], faces.shape[1], image_size
+    fim = np.empty((B, S, S), np.int32)
+    wim = np.empty((B, S, S, 3), np.float32)
+    depth = np.empty((B, S, S), np.float32)
+    finv = np.empty((B, S, S, 9), np.float32)
+    if L.raster_oracle_maps(faces.ctypes.data, fim.ctypes.data, wim.ctypes.data, depth.ctypes.data, finv.ctypes.data, B, NF, S,
+                            near, far, 1 if flip else 0) != 0:
+        raise RuntimeError("raster oracle failed")
+    return fim, wim, depth, finv
+
+
+def backward_pixel_map(faces, fim, alpha_map=None, grad_alpha_map=None, rgb_map=None, grad_rgb_map=None, eps: float = 1e-4):
+    """-> grad_faces [B,NF,3,3] (zeros for back faces); maps unflipped."""
+    L = _load()
+    faces = np.ascontiguousarray(faces, np.float32)
+    fim = np.ascontiguousarray(fim, np.int32)
+    B, NF, S = faces.shape[0], faces.shape[1], fim.shape[1]
+    arrs = [None if a is None else np.ascontiguousarray(a, np.float32) for a in (rgb_map, alpha_map, grad_rgb_map, grad_alpha_map)]
+    g = np.zeros((B, NF, 3, 3), np.float32)
+    if L.raster_oracle_bwd_pixel_map(faces.ctypes.data, fim.ctypes.data, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2]), _ptr(arrs[3]),
+                                     g.ctypes.data, B, NF, S, eps) != 0:
+        raise RuntimeError("raster oracle failed")
+    return g
+
+
+def backward_depth_map(faces, depth, fim, face_inv_map, wim, grad_depth, grad_faces):
+    """ADDS the depth gradient to grad_faces [B,NF,3,3] in place and returns it."""
+    L = _load()
+    faces = np.ascontiguousarray(faces, np.float32)
+    B, NF, S = faces.shape[0], faces.shape[1], fim.shape[1]
+    a = [np.ascontiguousarray(x, np.float32) for x in (depth, face_inv_map, wim, grad_depth)]
+    fim = np.ascontiguousarray(fim, np.int32)
+    assert grad_faces.dtype == np.float32 and grad_faces.flags["C_CONTIGUOUS"]
+    if L.raster_oracle_bwd_depth_map(faces.ctypes.data, a[0].ctypes.data, fim.ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+                                     a[3].ctypes.data, grad_faces.ctypes.data, B, NF, S) != 0:
+        raise RuntimeError("raster oracle failed")
+    return grad_faces
+
+
+def rasterize_fim_wim(faces: np.ndarray, image_size: int = 256, near: float = 0.1, far: float = 100.0):
+    """faces float32 [B,NF,3,3] -> (fim int32 [B,S,S], wim float32 [B,S,S,3])."""
+    _lib = _load()
     faces = np.ascontiguousarray(faces, np.float32)
     B, NF = faces.shape[0], faces.shape[1]
     fim = np.empty((B, image_size, image_size), np.int32)

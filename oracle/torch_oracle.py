@@ -178,6 +178,12 @@ def crn_smaller_forward(sd: SD, label, sp: int, fg: bool):
 # src/flow_net.py:6-141 (ctor args (9,32,2,3,use_deconv=False), train/4...py:146)
 # ------------------------------------------------------------------------------------------------
 def _bn(sd: SD, pre: str, x, training: bool):
+    """nn.BatchNorm2d.forward: momentum 0.1, eps 1e-5; in train mode the running statistics are updated in place and
+    num_batches_tracked is incremented (torch/nn/modules/batchnorm.py, as used by src/flow_net.py:13-44 and
+    src/networks.py:369-390)."""
+    nbt = sd.get(pre + ".num_batches_tracked")
+    if training and nbt is not None:
+        nbt.add_(1)
     return F.batch_norm(x, sd[pre + ".running_mean"], sd[pre + ".running_var"], sd[pre + ".weight"], sd[pre + ".bias"],
                         training, 0.1, 1e-5)
 

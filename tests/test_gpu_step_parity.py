@@ -82,10 +82,11 @@ def test_train_step_parity_reference_subsets(used, prosrc):
 
 
 # bf16 mode (BASELINE configs[2] arithmetic, the bench default): operands of every convolution are rounded to 8
-# significant bits, forward AND backward, so gradients agree with the fp32 oracle to a few per cent in relative L2, not
-# to 1e-3.  Bars = 2x what was measured on MI355X at B=2 (printed below); a wrong dgrad/wgrad kernel, a stale packed
-# weight image or a dropped term shows up as O(1).
-BF16_GRAD_BARS = {"accu": 0.30, "inpaint": 0.30, "refine": 0.30, "flow": 0.30, "D": 0.10, "face": 0.10}
+# significant bits, forward AND backward, and every L1 term's sign(a - b) flips wherever the 1e-2 forward perturbation
+# exceeds |a - b|, so gradients agree with the fp32 oracle to 5-16 % in relative L2, not to 1e-3.  Bars = 2x what was
+# measured on MI355X at B=2 (accu 0.155, inpaint 0.158, refine 0.079, flow 0.054, D 0.082, face 0.122); a wrong
+# dgrad/wgrad kernel, a stale packed weight image or a dropped term shows up as O(1).
+BF16_GRAD_BARS = {"accu": 0.30, "inpaint": 0.30, "refine": 0.16, "flow": 0.12, "D": 0.16, "face": 0.25}
 
 
 def test_train_step_bf16_gradients():
@@ -205,6 +206,11 @@ def test_two_rank_trainer_vs_chunked_oracle(tmp_path, drop_face_rank):
                     assert (v - o).abs().max().item() <= 1e-4 * max(1e-6, o.abs().max().item()) + 1e-7, (r, n, k)
     for n in TRAINABLE:
         num = den = pnum = pden = 0.0
+        gsq = cnt = 0.0
+        for k, p in orc.sd[n].items():
+            if p.requires_grad:
+                gsq += float((p.grad.double() ** 2).sum()); cnt += p.numel()
+        rms = (gsq / cnt) ** 0.5
         for k, p in orc.sd[n].items():
             if not p.requires_grad:
                 continue
@@ -213,10 +219,13 @@ def test_two_rank_trainer_vs_chunked_oracle(tmp_path, drop_face_rank):
             d = g0.double() - p.grad.double()
             num += float((d * d).sum()); den += float((p.grad.double() ** 2).sum())
             assert torch.equal(res[0]["params"][n][k], res[1]["params"][n][k]), (n, k)
-            du = (res[0]["params"][n][k].double() - before[n][k].double()) - (p.detach().double() - before[n][k].double())
-            pnum += float((du * du).sum()); pden += float(((p.detach().double() - before[n][k].double()) ** 2).sum())
+            # Adam moves an element by ~lr * sign(g) on its first step(s): where the gradient is not small against the
+            # module's RMS gradient its sign is certain and the updates must agree; elsewhere a 1e-3 gradient error may flip it
+            sure = p.grad.abs() > 0.05 * rms
+            du_ref = (p.detach().double() - before[n][k].double())[sure]
+            du = (res[0]["params"][n][k].double() - before[n][k].double())[sure]
+            pnum += float(((du - du_ref) ** 2).sum()); pden += float((du_ref ** 2).sum())
         rel, prel = (num / max(den, 1e-300)) ** 0.5, (pnum / max(pden, 1e-300)) ** 0.5
-        print("2 ranks: grad rel-L2 %-8s %.3e   Adam update rel-L2 %.3e" % (n, rel, prel))
+        print("2 ranks: grad rel-L2 %-8s %.3e   Adam update rel-L2 (|g| > 5%% of rms) %.3e" % (n, rel, prel))
         assert rel <= 5e-3, (n, rel)
-        # the first Adam step is lr * g / (|g| + eps): ~lr * sign(g), so only gradients within ~1e-8 of zero may differ
-        assert prel <= 5e-2, (n, prel)
+        assert prel <= 1e-2, (n, prel)

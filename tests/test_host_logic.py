@@ -114,3 +114,29 @@ def test_product_has_no_oracle_dependency():
         if fn.endswith(".py"):
             txt = open(os.path.join(root, fn)).read()
             assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_face_bbox_host_logic_and_transfer_texture_oracle():
+    """src/data.py:699-716 on the host (the boxes are host integers in the step): margins, the uint8 wrap of an edge at
+    256, the invalid all-zero box; and the TransferTexture restatement on a hand-made case (src/utils.py:369-394)."""
+    import numpy as np
+    from jafpro_amd import data, synth
+    from oracle import data_oracle
+    iuv = np.zeros((3, 256, 256, 3), np.uint8)
+    iuv[0, 100:120, 50:70, 0] = 23
+    iuv[0, 110:130, 60:90, 0] = 24
+    iuv[1, 240:256, 250:256, 0] = 24                      # touches the right / bottom border: 256 wraps to 0
+    bb = data.face_bbox_from_iuv(iuv)
+    assert bb.tolist() == [[48, 92, 98, 132], [248, 0, 238, 0], [0, 0, 0, 0]]
+    for i in range(3):
+        assert np.array_equal(bb[i], data_oracle.face_bbox(iuv[i]))
+    tex = np.zeros((800, 1200, 3), np.uint8)
+    tex[200 + 199, 400 + 0] = (7, 8, 9)                   # part 9 = cell (1, 2); U = 255 -> row 199, V = 255 -> column 199-199
+    m = np.zeros((4, 4, 3), np.uint8)
+    m[1, 2] = (9, 255, 255)
+    m[3, 3] = (25, 10, 10)                                # part ids above 24 are background
+    out = data_oracle.transfer_texture(tex, m, im=np.full((4, 4, 3), 5, np.uint8))
+    assert out[1, 2].tolist() == [7, 8, 9] and out[3, 3].tolist() == [5, 5, 5] and out[0, 0].tolist() == [5, 5, 5]
+    raw = synth.stage4_raw(3, 1, S=64)
+    b = data_oracle.stage4_batch(raw)
+    assert b["src_texture_im"].min() >= -1 and b["src_texture_im"].max() <= 1 and b["smpl_real_mask"].max() == 1.0

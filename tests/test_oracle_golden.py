@@ -176,3 +176,124 @@ def test_step_oracle_rank_form_is_the_plain_step_on_identical_shards():
                 assert v[0][n][k] is not v[1][n][k]
     k0 = "Downsampler_list.0.enc1.enconv.0.weight"
     assert v[0]["flow"] is c.sd["flow"] and v[1]["accu"][k0] is c.sd["accu"][k0]
+
+
+# ---- rasteriser backward / depth: the oracle against the reference's own known answers ----
+def _silhouette_kat(verts, pyi, pxi, minus1):
+    import numpy as np
+    import torch
+    from oracle import raster_autograd as RA
+    v = torch.zeros(4, 3, 3)                     # utils.to_minibatch: batch of 4, the mesh in slot 2
+    v[2] = torch.tensor(verts)
+    v.requires_grad_(True)
+    img = RA.rasterize_silhouettes(RA.renderer_faces(v, np.array([[0, 1, 2]]), perspective=False), 64)
+    torch.sum(torch.abs(img[:, pyi, pxi] - (1 if minus1 else 0))).backward()
+    return v.grad
+
+
+def test_raster_backward_known_answers():
+    """third_party/neural_renderer/tests/test_rasterize_silhouettes.py:37-99: the two hand-checked vertex gradients of a
+    single triangle's silhouette (non-zero loss gradient outside / on the face), rtol 1e-2 as there."""
+    import numpy as np
+    g1 = _silhouette_kat([[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]], 25, 35, True)
+    r1 = np.array([[1.6725862, -0.26021874, 0.], [1.41986704, -1.64284933, 0.], [0., 0., 0.]], np.float32)
+    g2 = _silhouette_kat([[0.8, 0.8, 1.], [-0.5, -0.8, 1.], [0.8, -0.8, 1.]], 40, 50, False)
+    r2 = np.array([[0.98646867, 1.04628897, 0.], [-1.03415668, -0.10403691, 0.], [3.00094461, -1.55173182, 0.]], np.float32)
+    assert np.allclose(g1[2].numpy(), r1, rtol=1e-2) and np.allclose(g2[2].numpy(), r2, rtol=1e-2)
+    for b in (0, 1, 3):                          # the empty batch slots carry no gradient
+        assert float(g1[b].abs().max()) == 0.0 and float(g2[b].abs().max()) == 0.0
+
+
+def test_raster_depth_backward_matches_finite_differences():
+    """third_party/neural_renderer/tests/test_rasterize_depth.py:56-93: depth gradient of one triangle vs forward differences."""
+    import numpy as np
+    import torch
+    from oracle import raster_autograd as RA
+    base = torch.tensor([[-0.9, -0.9, 2.], [-0.8, 0.8, 1.], [0.8, 0.8, 0.5]])
+    fi = np.array([[0, 1, 2], [2, 1, 0]])                          # Renderer.fill_back (renderer.py:100-102)
+
+    def loss_of(v):
+        faces = v[None][:, torch.as_tensor(fi).long()]            # camera_mode 'none': the vertices are used as given
+        img = RA.rasterize_depth(faces, 64)
+        return torch.sum((img[0, 15, 20] - 1) ** 2)
+
+    v = base.clone().requires_grad_(True)
+    loss = loss_of(v)
+    loss.backward()
+    num = np.zeros((3, 3), np.float32)
+    for i in range(3):
+        for j in range(3):
+            v2 = base.clone()
+            v2[i, j] += 1e-3
+            num[i, j] = float((loss_of(v2) - loss.detach()) / 1e-3)
+    assert float(v.grad.abs().max()) > 1e-3
+    assert np.allclose(v.grad.numpy(), num, atol=1e-3)
+
+
+def test_raster_pin_covers_depth_and_gradients(golden_dir):
+    import json
+    import os
+    pin = json.load(open(os.path.join(golden_dir, "raster_pin.json")))
+    for k in ("teapot_silhouette_equal", "teapot_depth_silhouette_equal", "teapot_depth_allclose_1e-2", "silhouette_grad_kat1",
+              "silhouette_grad_kat2", "look_at_kat", "perspective_kat"):
+        assert pin[k] is True, k
+    assert pin["teapot_depth_max_abs_diff"] <= 1e-2
+
+
+# ---- stage 1 (BASELINE config 1) and checkpoint files (SURVEY 8(f3)) ----
+def test_stage1_config1_step_golden(golden_dir):
+    """BASELINE configs[0]: one stage-1 step, B=1, T=4 -- loss, gradients and Adam(1e-4) updates of the oracle against the
+    REFERENCE module's (oracle/make_golden.py g_stage1_t4, train/1.text_accu_LSTM.py:140-176)."""
+    import torch
+    from jafpro_amd.networks import Accumulate_LSTM
+    from oracle.stage_oracle import OracleStage1
+    st = load(golden_dir, "stage1_b1_t4_step.npz")
+    sd = sd_for(Accumulate_LSTM(), 111)
+    orc = OracleStage1(sd)
+    before = {k: v.detach().clone() for k, v in orc.sd.items()}
+    out = orc.train_step({k: T(v) for k, v in synth.stage1_batch(611, 1).items()}, (0, 1, 2, 3))
+    assert abs(float(out["total_loss"]) - float(st["loss"][0])) <= 1e-6
+    same(st, "atlas", out["output_texture"])
+    for k in [k[5:] for k in st if k.startswith("grad.")]:
+        assert (orc.sd[k].grad - torch.from_numpy(st["grad." + k])).abs().max().item() <= 1e-6 * max(1.0, float(abs(st["grad." + k]).max())), k
+        assert (orc.sd[k].detach() - before[k] - torch.from_numpy(st["delta." + k])).abs().max().item() <= 2.01e-4, k
+    fam = {}
+    for k, p in orc.sd.items():
+        f = ".".join(k.split(".")[2:])
+        fam[f] = fam.get(f, 0.0) + float((p.grad.double() ** 2).sum())
+    for f, v in zip(st["gradsq.families"], st["gradsq.values"]):
+        assert abs(fam[str(f)] - float(v)) <= 1e-5 * float(v), f
+
+
+def test_checkpoint_files_match_the_reference_format(golden_dir, tmp_path):
+    """tests/golden/checkpoint_pin.json records (made with the imported reference modules) that a file written by
+    stages.save_checkpoints loads strictly into the reference module and a reference file loads strictly into the mirror.
+    Here the same seeded weights are written again: same file names, same key order, same bytes."""
+    import hashlib
+    import json
+    import os
+    import torch
+    from jafpro_amd import crn_model, flow_net, networks, stages
+    pin = json.load(open(os.path.join(golden_dir, "checkpoint_pin.json")))
+    mk = {"accu": networks.Accumulate_LSTM_no_loss, "inpaint": networks.UNet_inpainter, "bg": lambda: crn_model.CRN_smaller(3),
+          "refine": lambda: crn_model.CRN_smaller(3, fg=True), "D": lambda: networks.ImageDiscriminator(32, 6),
+          "face": lambda: networks.FaceDiscriminator(32, 6), "flow": lambda: flow_net.Propagation3DFlowNet(9, 32, 2, 3, use_deconv=False)}
+    assert set(pin) == set(mk)
+    for name, rec in pin.items():
+        assert rec["reference_to_mirror"] and rec["mirror_to_reference"] and rec["key_order_equal"], name
+        m = synth.load_synth(mk[name](), rec["seed"])
+        path = stages.save_checkpoints(str(tmp_path), 36000, {name: m})[name]
+        assert os.path.basename(path) == rec["file"]
+        sd = torch.load(path, weights_only=True)
+        assert len(sd) == rec["entries"]
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            h.update(k.encode()); h.update(v.contiguous().numpy().tobytes())
+        assert h.hexdigest() == rec["sha256"], name
+        m2 = mk[name]()
+        res = stages.load_checkpoint(m2, path)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    assert os.path.basename(stages.checkpoint_path("x", "accu", 5000, stage1=True)) == "iter_5000.pth"
+    assert stages.multistep_lr(1e-4, 1) == 1e-4 and stages.multistep_lr(1e-4, 100000) == 1e-4
+    assert abs(stages.multistep_lr(1e-4, 100001) - 3e-5) < 1e-12 and abs(stages.multistep_lr(1e-4, 150001) - 9e-6) < 1e-12
