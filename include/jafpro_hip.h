@@ -155,11 +155,39 @@ int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const j
                                  const float* c_prev, float* h_out, float* c_out, void* gates_out,
                                  int gates_bf16 /* gates_out is bf16 [N, G*4C, H, W] instead of fp32 */);
 
+/* Packed-image plumbing of the bf16 path: activations that only convolutions consume never exist as fp32 NCHW.
+ * A producer (conv / ConvLSTM epilogue, LayerNorm, resize, pool) writes its result straight into the CONSUMER's packed
+ * image [N][G][ng8_tot][H*W][8] bf16 at a channel offset -- the concatenation `cat[x, h]`, `cat[up, skip]` is laid out
+ * by the producers -- and a consumer may read the leading planes of a larger image (enc_{i+1} reads x_i out of the
+ * ConvLSTM's [x_i, h] image).  Values are the RNE bf16 roundings jaf_conv2d_pack_input would have produced.
+ * All-zero / NULL = the plain behaviour. */
+typedef struct jaf_packed_io {
+    int32_t in_ng8_tot;      /* planes per (image, group) of the packed INPUT image; 0 = ceil(Cin/8) */
+    void* dst;               /* destination packed image of this launch's outputs (NULL: none) */
+    int32_t dst_ng8_tot;     /* its planes per (image, group) */
+    int32_t dst_coff;        /* first destination channel within the group; multiple of 4 */
+    int32_t dst_img_off;     /* destination image index = n + dst_img_off */
+    int32_t dst_pad_tail;    /* also write zeros to the channels up to the next multiple of 8 (last source of the image) */
+    int32_t skip_f32;        /* do not write the fp32 output tensor (its pointer may be NULL) */
+} jaf_packed_io;
+int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                             const void* packed_in, const void* packed_w, const float* bias, float* out,
+                             double* stats, int32_t stat_slots, const jaf_packed_io* io);
+/* ConvLSTM cell: `io->dst` receives h_t (4 * hidden = Cout rows -> hidden channels); skip_f32 drops the fp32 h_out
+ * (c_out and the saved gates are always written). */
+int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                    const void* packed_in, const void* packed_w, const float* bias,
+                                    const float* c_prev, float* h_out, float* c_out, void* gates_out,
+                                    int gates_bf16, const jaf_packed_io* io);
+
 /* 3x3 weight gradient from the packed input of the forward conv and the packed dz of the data
  * gradient (csrc/wgrad_dma.hip).  Returns JAF_EUNSUPPORTED for shapes it does not cover (stride-2
  * layers with more than 16 input channels): use jaf_conv2d_wgrad there.                          */
 int jaf_conv2d_wgrad_packed(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x,
                             const void* packed_dz, float* dw, int accumulate);
+/* Same with packed_x an image of x_ng8_tot >= ceil(Cin/8) planes per (image, group) (see jaf_packed_io). */
+int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
+                               const void* packed_dz, float* dw, int accumulate);
 
 /* dW[G][Cout][w_cin_tot][KH][KW] (+)= sum over n,pixels of dz * input patch; dz is laid out as
  * the forward output (out_ctot/out_coff).  accumulate=0 zeroes the touched slice first.        */
@@ -206,6 +234,12 @@ int jaf_layernorm_finalize(jaf_stream_t s, double* sums, int32_t N, int32_t slot
 int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                             const float* beta, float* y, int32_t N, int32_t C, int32_t HW,
                             float slope);
+/* Same, and the result is ALSO written (RNE bf16) into channels [dst_coff, dst_coff + C) of the consumer convolution's
+ * packed image (groups == 1; dst_coff a multiple of 8; the channels up to the next multiple of 8 are zeroed); y may be
+ * NULL when nothing reads the fp32 result. */
+int jaf_layernorm_lrelu_fwd_packed(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
+                                   const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
+                                   int32_t N, int32_t C, int32_t HW, float slope);
 /* Backward through lrelu + affine + normalisation.  x is the conv output (pre-norm).
  * dgamma/dbeta are accumulated (+=).                                                            */
 int jaf_layernorm_lrelu_bwd(jaf_stream_t s, const float* dy, const float* x, const float* stats,
@@ -360,6 +394,19 @@ int jaf_transfer_texture_u8(jaf_stream_t s, const uint8_t* tex, const uint8_t* i
                             int32_t N, int32_t S, int32_t AH, int32_t AW, int tex_batched);
 
 /* ------------------------------------------------------------------------------------------
+ * Evaluation metrics (test/video_evaluation.py:165-212; third-party arithmetic restated: OpenCV BGR2GRAY,
+ * scikit-image 0.16.2 compare_ssim, scikit-video 1.1.11 psnr / msssim -- requirements.txt).
+ * ------------------------------------------------------------------------------------------ */
+/* cv2.cvtColor(img, COLOR_BGR2GRAY) on uint8 [npix][3] -> [npix] (video_evaluation.py:169-170). */
+int jaf_bgr_to_gray_u8(jaf_stream_t s, const uint8_t* in, uint8_t* out, int64_t npix);
+/* sums[n] += (sum of SSIM, sum of contrast-structure) over the valid win x win windows of the fp32 pair x, y [N][H][W];
+ * weights[win*win] fp64, cov_norm = NP/(NP-1) for skimage's sample covariance or 1; caller zeroes sums[N][2]. */
+int jaf_ssim_window_sums(jaf_stream_t s, const float* x, const float* y, const double* weights, double* sums,
+                         int32_t N, int32_t H, int32_t W, int32_t win, double cov_norm, double C1, double C2);
+/* sums[n] += (sum (a-b)^2, sum |a-b|) of uint8 frames [N][P] (exact); caller zeroes sums[N][2]. */
+int jaf_frame_error_sums_u8(jaf_stream_t s, const uint8_t* a, const uint8_t* b, double* sums, int32_t N, int64_t P);
+
+/* ------------------------------------------------------------------------------------------
  * Losses, classifier head, optimiser.
  * ------------------------------------------------------------------------------------------ */
 /* vgg_preprocess src/networks.py:109-116: y = 255*(x+1)/2 - mean[c]. */
@@ -395,6 +442,9 @@ int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float* y, int64_
 int jaf_ubench_mfma_bf16(jaf_stream_t s, int32_t blocks, int32_t iters, float* sink);
 /* dst[i] = src[i], 16 bytes per lane, grid-stride: the streaming-copy HBM rate (n16 = 16-byte items). */
 int jaf_ubench_copy(jaf_stream_t s, const void* src, void* dst, int64_t n16);
+/* The same copy with `variant` choosing loads in flight per lane / nontemporal accesses and an explicit grid
+ * (bench.py reports the best as this box's HBM ceiling): 0: 4 in flight, 1: 4 nt, 2: 8 nt, 3: 2 nt, 4: 1 nt, 5: 1. */
+int jaf_ubench_copy_variant(jaf_stream_t s, const void* src, void* dst, int64_t n16, int32_t variant, int32_t blocks);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,8 @@ def parse_header(path: str = HEADER):
                     argtypes.append(ctypes.c_int64)
                 elif a.startswith("float"):
                     argtypes.append(ctypes.c_float)
+                elif a.startswith("double"):
+                    argtypes.append(ctypes.c_double)
                 elif a.startswith("int32_t") or a.startswith("int"):
                     argtypes.append(ctypes.c_int)
                 else:
@@ -71,6 +73,13 @@ class ConvPlan(ctypes.Structure):
         ("nsteps", ctypes.c_int32), ("nsteps_last", ctypes.c_int32), ("npos", ctypes.c_int32),
         ("plane", ctypes.c_int32), ("PWp_slots_unused", ctypes.c_int32), ("ilv", ctypes.c_int32), ("pf", ctypes.c_int32),
     ]
+
+
+class PackedIO(ctypes.Structure):
+    """jaf_packed_io (include/jafpro_hip.h)."""
+    _fields_ = [("in_ng8_tot", ctypes.c_int32), ("dst", ctypes.c_void_p), ("dst_ng8_tot", ctypes.c_int32),
+                ("dst_coff", ctypes.c_int32), ("dst_img_off", ctypes.c_int32), ("dst_pad_tail", ctypes.c_int32),
+                ("skip_f32", ctypes.c_int32)]
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4

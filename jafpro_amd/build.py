@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libjafpro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["conv.hip", "conv_bf16.hip", "conv_dma.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_dma.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
-           "raster.hip", "linear.hip", "ubench.hip", "input_pipeline.hip"]
+           "raster.hip", "linear.hip", "ubench.hip", "input_pipeline.hip", "metrics.hip"]
 # raster.hip must keep the reference's fp32 expression trees (no FMA contraction): see its header.
 EXTRA = {"raster.hip": ["-ffp-contract=off"]}
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]

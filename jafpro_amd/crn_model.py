@@ -42,10 +42,11 @@ class LayerNorm(nn.Module):
         self.beta = nn.Parameter(torch.zeros(num_features))
         self.pre_stats = ops.LNStats()
 
-    def forward(self, x, slope: float = 1.0, pre=None):
-        """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01 and the statistics
-        its convolution's epilogue already accumulated (ops.LNStats)."""
-        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope, pre)
+    def forward(self, x, slope: float = 1.0, pre=None, dst=None):
+        """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01, the statistics
+        its convolution's epilogue already accumulated (ops.LNStats) and, on the packed bf16 path, the packed image of
+        the convolution that consumes the result (ops.PackedDst)."""
+        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope, pre, dst)
 
 
 class ConvBlock(nn.Module):
@@ -59,13 +60,20 @@ class ConvBlock(nn.Module):
         self.conv_block = nn.Sequential(*layers)
         self.n_repeats, self.pad = n_repeats, pad
 
-    def forward(self, x):
-        """x: tensor or list of tensors (read as their channel concatenation)."""
+    def forward(self, x, out_image=None):
+        """x: tensor or list of tensors (read as their channel concatenation).  On the packed bf16 path each LayerNorm
+        writes its result straight into the packed input image of the convolution that follows it (the next repeat's, or
+        `out_image`: a single-source consumer of the block's output such as the CRN's 1x1 heads)."""
+        img_in = None
         for r in range(self.n_repeats):
             conv, ln = self.conv_block[3 * r], self.conv_block[3 * r + 1]
             st = ln.pre_stats          # this LayerNorm's own side channel (zeroed once, kept clean by the finalize kernel)
-            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE, ln_stats=st)
-            x = ln(x, 0.01, st)
+            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE, ln_stats=st, prepacked=img_in)
+            img_out = out_image
+            if r + 1 < self.n_repeats and ops.packed_active():
+                img_out = ops.PackedImage(x.shape[0], 1, x.shape[1], x.shape[2], x.shape[3], x.device)
+            x = ln(x, 0.01, st, img_out.slot(0) if img_out is not None else None)
+            img_in = img_out
         return x
 
 
@@ -108,13 +116,14 @@ class CRN_smaller(nn.Module):
         net_3 = up(self.conv3_decoder([down(sp // 8), pool3, net_4]), sp // 4)
         net_2 = up(self.conv2_decoder([down(sp // 4), pool2, net_3]), sp // 2)
         net_1 = up(self.conv1_decoder([down(sp // 2), pool1, net_2]), sp)
-        net = self.decoder([label, net_1])
+        head_img = ops.PackedImage(label.shape[0], 1, 256, sp, sp, label.device) if ops.packed_active() else None
+        net = self.decoder([label, net_1], out_image=head_img)
         if self.fg:
             # the rgb head (256 -> 3) and the mask head (256 -> 1, sigmoid) read the same 256-channel tensor: one 1x1
             # convolution with the four output rows stacked packs `net` once and sends ONE gradient back to it
             # (separately: two packs of a 537 MB tensor, two data gradients and their 537 MB sum, per step at B=8)
             w = torch.cat([self.out_conv.weight, self.fg_conv.weight], 0)
             b = torch.cat([self.out_conv.bias, self.fg_conv.bias], 0)
-            y = ops.conv2d(net, w, b, stride=1, pad=0, act=ACT_NONE)
+            y = ops.conv2d(net, w, b, stride=1, pad=0, act=ACT_NONE, prepacked=head_img)
             return y[:, :3].contiguous(), torch.sigmoid(y[:, 3:4]).contiguous()
-        return ops.conv2d(net, self.out_conv.weight, self.out_conv.bias, stride=1, pad=0, act=ACT_NONE)
+        return ops.conv2d(net, self.out_conv.weight, self.out_conv.bias, stride=1, pad=0, act=ACT_NONE, prepacked=head_img)

@@ -44,7 +44,19 @@ struct ConvDArgs {
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
     double* stats;     // nullable: [N][slots][2] += (sum, sum of squares) of the image's outputs (act NONE, G == 1):
     int stat_slots;    // the statistics pass of the LayerNorm that follows, taken while the values are in registers
+    // packed-image plumbing (jaf_packed_io): the input image may have more planes per (image, group) than this layer
+    // reads, and the epilogue may write its (activated) outputs straight into the consumer's packed bf16 image
+    int in_ng8;            // planes per (image, group) of the INPUT image (>= ngroups8)
+    unsigned char* dst;    // destination packed image (nullable)
+    int dst_ng8, dst_coff, dst_img_off, dst_pad_tail;
+    int skip_f32;          // the fp32 output tensor is not written (nobody reads it)
 };
+
+// Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
+// planes: 2 bytes at ((ng*ng8 + dc/8)*HW + pix)*16 + (dc%8)*2.
+__device__ __forceinline__ unsigned char* cd_dst_ptr(unsigned char* base, long ng, int ng8, int dc, int OHW, int pix) {
+    return base + ((ng * ng8 + (dc >> 3)) * (long)OHW + pix) * 16 + (dc & 7) * 2;
+}
 
 __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
     f32x2 v = {a, b};
@@ -540,6 +552,39 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
     const bool vec = a.vec && (NT > 1);
     if (!LSTM) {
         float st1 = 0.f, st2 = 0.f;     // LayerNorm statistics of this lane's outputs (ACT NONE + a.stats only)
+        if (a.dst) {
+            // The lane's 4 rows of a tile are 4 consecutive output channels = half of a 16-byte packed item
+            // (dst_coff % 4 == 0); lanes q and q^1 complete the item within the same store instruction.
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
+            const int cpad = a.dst_pad_tail ? ((a.dst_coff + d.Cout + 7) & ~7) - a.dst_coff : d.Cout;   // rows < cpad are written
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int co0 = mb * MR + mt * 16 + q * 4;
+                if (co0 >= cpad) continue;
+                float bv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = (a.bias && co0 + j < d.Cout) ? a.bias[g * d.Cout + co0 + j] : 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    if (opix[nt] < 0) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = (co0 + j < d.Cout) ? jaf_act(acc[mt][nt][j] + bv[j], d.act, d.slope) : 0.f;
+                    u32x2 w = {cd_pack2(v[0], v[1]), cd_pack2(v[2], v[3])};
+                    if (co0 + 4 <= cpad || a.dst_pad_tail) {
+                        *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]) = w;
+                    } else {           // a 4-group that straddles the end of this source: channel by channel
+                        unsigned short* hp = (unsigned short*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]);
+                        const unsigned int ww[2] = {w[0], w[1]};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (co0 + j < d.Cout) hp[j] = (unsigned short)(ww[j >> 1] >> ((j & 1) * 16));
+                    }
+                }
+            }
+        }
+        if (a.skip_f32) return;
 #define CD_EPILOGUE(ACT_, ST_)                                                                        \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
@@ -616,7 +661,13 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     vh[nt] = vo[nt] * jaf_tanh(vc[nt]);
                 }
                 *(fvec*)(a.c_out + hc + opix[0]) = vc;
-                *(fvec*)(a.h_out + hc + opix[0]) = vh;
+                if (!a.skip_f32) *(fvec*)(a.h_out + hc + opix[0]) = vh;
+                if (a.dst) {     // h_t straight into the consumer's packed image (next step's [x, h] / the decoder's skip)
+                    const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        *(__bf16*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt) = (__bf16)vh[nt];
+                }
                 if (a.gates_out) {
                     if (a.gates_bf16) {
                         __bf16* gp = (__bf16*)a.gates_out + gc + opix[0];
@@ -643,7 +694,10 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     const float cp = a.c_prev ? a.c_prev[hc + opix[nt]] : 0.f;
                     const float cc = gf * cp + gi * gg;
                     a.c_out[hc + opix[nt]] = cc;
-                    a.h_out[hc + opix[nt]] = go * jaf_tanh(cc);
+                    const float hv = go * jaf_tanh(cc);
+                    if (!a.skip_f32) a.h_out[hc + opix[nt]] = hv;
+                    if (a.dst)
+                        *(__bf16*)cd_dst_ptr(a.dst, ((long)(n + a.dst_img_off)) * d.G + g, a.dst_ng8, a.dst_coff + ch, OHW, opix[nt]) = (__bf16)hv;
                     if (a.gates_out) {
                         if (a.gates_bf16) {
                             __bf16* gp = (__bf16*)a.gates_out + gc + opix[nt];
@@ -778,7 +832,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
         }
     }
     // plane (group8 = 0) of this (image, group); consecutive group8 planes are HW*16 bytes apart
-    const unsigned char* xbase = a.xp + (((long)n * d.G + g) * a.ngroups8) * (long)HW * 16;
+    const unsigned char* xbase = a.xp + (((long)n * d.G + g) * a.in_ng8) * (long)HW * 16;
     const int plane_bytes = HW * 16;
 
     f32x4 acc[MT][NT];
@@ -1064,6 +1118,54 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.gates_bf16 = 0;
     a.stats = nullptr;
     a.stat_slots = 1;
+    a.in_ng8 = a.ngroups8;
+    a.dst = nullptr;
+    a.dst_ng8 = a.dst_coff = a.dst_img_off = a.dst_pad_tail = 0;
+    a.skip_f32 = 0;
+}
+
+static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
+    if (!io) return true;
+    if (io->in_ng8_tot != 0 && io->in_ng8_tot < jaf_cdiv(d->Cin, 8)) return false;
+    const int cout = lstm ? (d->Cout >> 2) : d->Cout;        // channels this launch writes per group (LSTM: the hidden state)
+    if (io->dst) {
+        if (io->dst_ng8_tot < 1 || io->dst_coff < 0 || (io->dst_coff & 3) || io->dst_img_off < 0) return false;
+        const int end = io->dst_coff + (io->dst_pad_tail ? ((cout + 7) & ~7) : cout);
+        if (end > io->dst_ng8_tot * 8) return false;
+        if (lstm && io->dst_pad_tail) return false;
+    } else if (io->skip_f32 && !lstm) {
+        return false;                                         // a launch that writes nothing
+    }
+    return true;
+}
+
+static void cd_apply_io(ConvDArgs& a, const jaf_packed_io* io) {
+    if (!io) return;
+    if (io->in_ng8_tot) a.in_ng8 = io->in_ng8_tot;
+    a.dst = (unsigned char*)io->dst;
+    a.dst_ng8 = io->dst_ng8_tot;
+    a.dst_coff = io->dst_coff;
+    a.dst_img_off = io->dst_img_off;
+    a.dst_pad_tail = io->dst_pad_tail ? 1 : 0;
+    a.skip_f32 = io->skip_f32 ? 1 : 0;
+}
+
+extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                        const void* packed_in, const void* packed_w, const float* bias, float* out,
+                                        double* stats, int32_t stat_slots, const jaf_packed_io* io) {
+    JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && cd_io_ok(d, io, false));
+    JAF_REQUIRE(out || (io && io->skip_f32));
+    JAF_REQUIRE(!stats || (d->act == JAF_ACT_NONE && d->G == 1 && stat_slots >= 1 && stat_slots <= 64 && !(io && io->skip_f32)));
+    ConvDArgs a;
+    cd_fill(a, d, plan);
+    cd_apply_io(a, io);
+    a.xp = (const unsigned char*)packed_in;
+    a.wpk = (const unsigned char*)packed_w;
+    a.bias = bias;
+    a.out = out;
+    a.stats = stats;
+    a.stat_slots = stats ? stat_slots : 1;
+    return cd_launch_mt<false>(a, (hipStream_t)s);
 }
 
 extern "C" int jaf_conv2d_fwd_packed_stats(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
@@ -1091,11 +1193,21 @@ extern "C" int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc*
                                             const void* packed_in, const void* packed_w, const float* bias,
                                             const float* c_prev, float* h_out, float* c_out, void* gates_out,
                                             int gates_bf16) {
-    JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && bias && h_out && c_out);
+    return jaf_convlstm_cell_fwd_packed_io(s, d, plan, packed_in, packed_w, bias, c_prev, h_out, c_out, gates_out, gates_bf16,
+                                           nullptr);
+}
+
+extern "C" int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
+                                               const void* packed_in, const void* packed_w, const float* bias,
+                                               const float* c_prev, float* h_out, float* c_out, void* gates_out,
+                                               int gates_bf16, const jaf_packed_io* io) {
+    JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && bias && c_out && cd_io_ok(d, io, true));
+    JAF_REQUIRE(h_out || (io && io->skip_f32 && io->dst));
     JAF_REQUIRE(d->KH == 3 && d->KW == 3 && d->stride == 1 && (d->Cout & 3) == 0);
     JAF_REQUIRE(d->Cout % (16 * plan->MT) == 0 && d->H == d->OH && d->W == d->OW);
     ConvDArgs a;
     cd_fill(a, d, plan);
+    cd_apply_io(a, io);
     a.xp = (const unsigned char*)packed_in;
     a.wpk = (const unsigned char*)packed_w;
     a.bias = bias;

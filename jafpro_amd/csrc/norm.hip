@@ -144,6 +144,74 @@ extern "C" int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const flo
     return jaf_launch_status();
 }
 
+// Same, and ALSO written as the consumer convolution's packed bf16 image [n][ng8][HW][8] (jaf_packed_io): a lane
+// owns 8 channels x V pixels so that every 16-byte item it stores is complete.  grid (pixel blocks, ceil(C/8), N).
+template <int V>
+__global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* __restrict__ y, unsigned char* __restrict__ dst, int dst_ng8,
+                                                                  int dst_cg0, int C, int HW, float slope) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int cg = blockIdx.y, n = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const float mean = stats[2 * n], r = stats[2 * n + 1];
+    float o[8][V];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[j][k] = 0.f;
+        if (c < C) {
+            const long e = ((long)n * C + c) * HW + pix;
+            const float g = gamma[c], b = beta[c];
+            if (V == 4) {
+                const f32x4 xv = *(const f32x4*)(x + e);
+                f32x4 ov;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z = (xv[k] - mean) * r * g + b;
+                    ov[k] = z > 0.f ? z : z * slope;
+                    o[j][k] = ov[k];
+                }
+                if (y) *(f32x4*)(y + e) = ov;
+            } else {
+                const float z = (x[e] - mean) * r * g + b;
+                o[j][0] = z > 0.f ? z : z * slope;
+                if (y) y[e] = o[j][0];
+            }
+        }
+    }
+    unsigned char* op = dst + (((long)n * dst_ng8 + dst_cg0 + cg) * (long)HW + pix) * 16;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        u32x4 w;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x2 v2 = {o[2 * u][k], o[2 * u + 1][k]};
+            w[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2));
+        }
+        *(u32x4*)(op + k * 16) = w;
+    }
+}
+
+extern "C" int jaf_layernorm_lrelu_fwd_packed(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
+                                              const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
+                                              int32_t N, int32_t C, int32_t HW, float slope) {
+    JAF_REQUIRE(x && stats && gamma && beta && dst && N >= 1 && C >= 1 && HW >= 1 && N <= 65535);
+    JAF_REQUIRE(dst_coff >= 0 && (dst_coff & 7) == 0 && dst_coff / 8 + jaf_cdiv(C, 8) <= dst_ng8_tot && jaf_cdiv(C, 8) <= 65535);
+    const dim3 block(256);
+    if ((HW % 4 == 0) && al16(x, y))
+        hipLaunchKernelGGL(ln_lrelu_fwd_packed_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), jaf_cdiv(C, 8), N), block, 0, (hipStream_t)s, x,
+                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope);
+    else
+        hipLaunchKernelGGL(ln_lrelu_fwd_packed_kernel<1>, dim3(jaf_cdiv(HW, 256), jaf_cdiv(C, 8), N), block, 0, (hipStream_t)s, x,
+                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope);
+    return jaf_launch_status();
+}
+
 // pass A: per (c, n) block: a = sum dz, b = sum dz*xhat ; dbeta[c] += a, dgamma[c] += b,
 // ws[n][c % 16][0] += gamma_c*a (S1), ws[n][c % 16][1] += gamma_c*b (S2): the C workgroups of one image spread their
 // fp64 atomics over 16 slots (one address per image cost a ~21 us floor per launch), folded by ln_bwd_fold_kernel.

@@ -48,3 +48,38 @@ extern "C" int jaf_ubench_copy(jaf_stream_t s, const void* src, void* dst, int64
     hipLaunchKernelGGL(ubench_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)s, (const u32x4*)src, (u32x4*)dst, (long)n16);
     return jaf_launch_status();
 }
+
+// Variants of the streaming copy (measurement only): nontemporal accesses and different amounts of work in flight.
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void ubench_copy_var_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, long n16) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = NT ? __builtin_nontemporal_load(src + i + k * stride) : src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            if (NT) __builtin_nontemporal_store(v[k], dst + i + k * stride);
+            else dst[i + k * stride] = v[k];
+        }
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+
+extern "C" int jaf_ubench_copy_variant(jaf_stream_t s, const void* src, void* dst, int64_t n16, int32_t variant, int32_t blocks) {
+    JAF_REQUIRE(src && dst && n16 >= 1 && blocks >= 1);
+    JAF_REQUIRE(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0);
+    const u32x4* a = (const u32x4*)src;
+    u32x4* b = (u32x4*)dst;
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((ubench_copy_var_kernel<4, false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, (long)n16); break;
+        case 1: hipLaunchKernelGGL((ubench_copy_var_kernel<4, true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, (long)n16); break;
+        case 2: hipLaunchKernelGGL((ubench_copy_var_kernel<8, true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, (long)n16); break;
+        case 3: hipLaunchKernelGGL((ubench_copy_var_kernel<2, true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, (long)n16); break;
+        case 4: hipLaunchKernelGGL((ubench_copy_var_kernel<1, true>), dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, (long)n16); break;
+        case 5: hipLaunchKernelGGL((ubench_copy_var_kernel<1, false>), dim3(blocks), dim3(256), 0, (hipStream_t)s, a, b, (long)n16); break;
+        default: return JAF_EINVAL;
+    }
+    return jaf_launch_status();
+}

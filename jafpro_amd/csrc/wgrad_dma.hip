@@ -41,6 +41,7 @@ struct WgDArgs {
     int nx;                // DMA instructions per ci-tile plane
     int off_dz;
     int ngin8, ngout8;
+    int xng8;              // planes per (image, group) of the packed input image (>= ngin8)
     float inv_pwp;
 };
 
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
-    const int xbytes = a.ngin8 * HW * 16;
+    const int xbytes = a.xng8 * HW * 16;
     const int zbytes = a.ngout8 * OHW * 16;
 
     for (int item = split; item < items; item += a.nsplit) {
@@ -261,7 +262,13 @@ static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 
 extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x,
                                        const void* packed_dz, float* dw, int accumulate) {
+    return jaf_conv2d_wgrad_packed_ex(s_, d, packed_x, 0, packed_dz, dw, accumulate);
+}
+
+extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
+                                          const void* packed_dz, float* dw, int accumulate) {
     JAF_REQUIRE(d && packed_x && packed_dz && dw);
+    JAF_REQUIRE(x_ng8_tot == 0 || x_ng8_tot >= jaf_cdiv(d->Cin, 8));
     JAF_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5) && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
     const int KS = d->KH;
     JAF_REQUIRE(d->N >= 1 && d->G >= 1 && d->Cin >= 1 && d->Cout >= 1 && d->w_cin_off >= 0 && d->w_cin_off + d->Cin <= d->w_cin_tot);
@@ -296,8 +303,9 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
     a.off_dz = a.WC * a.xplane;
     a.ngin8 = jaf_cdiv(d->Cin, 8);
     a.ngout8 = jaf_cdiv(d->Cout, 8);
+    a.xng8 = x_ng8_tot ? x_ng8_tot : a.ngin8;
     a.inv_pwp = 1.0f / (float)a.PWp;
-    JAF_REQUIRE((long)a.ngin8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
+    JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
     int lds = a.off_dz + MTW * 4096;
     const int lds_ep = 4 * 16 * WD_EP * 4;
     if (KS == 3 && lds < lds_ep) lds = lds_ep;

@@ -72,8 +72,9 @@ class _GroupedStateDict(nn.Module):
                 state_dict[prefix + name] = torch.cat([state_dict.pop(k) for k in keys], 0)
 
 
-def _lrelu_conv(x_srcs, w, b, stride=1, pad=1, shared=None):
-    return ops.conv2d(x_srcs, w, b, stride=stride, pad=pad, act=ACT_LRELU, slope=0.2, groups=NPARTS, shared=shared)
+def _lrelu_conv(x_srcs, w, b, stride=1, pad=1, shared=None, prepacked=None, dst=None):
+    return ops.conv2d(x_srcs, w, b, stride=stride, pad=pad, act=ACT_LRELU, slope=0.2, groups=NPARTS, shared=shared,
+                      prepacked=prepacked, dst=dst)
 
 
 class _PartEncoderMixin:
@@ -89,14 +90,36 @@ class _PartEncoderMixin:
             self._add("enc%d_b" % (i + 1), "Downsampler_list.{p}.enc%d.enconv.0.bias" % (i + 1), b)
             cin = c
 
-    def _encode(self, x):
+    def _encode(self, x, tap=None):
+        """enc1..enc9 -> [x1, x3, x5, x7, x9].  On the packed bf16 path every layer writes its output straight into the
+        next layer's packed input image (ops.PackedImage): no separate packing pass between the convolutions.
+        `tap(level, x_level, image)` (accumulate: the ConvLSTM of that level) is called as soon as a skip feature exists;
+        it receives the image the feature was written into -- for the accumulate network that image is the ConvLSTM's
+        [x, h] sequence image, whose x half enc_{i+1} then reads in place -- and returns what to collect for the level."""
         feats = []
+        img_in = None
+        packed = ops.packed_active()
         for i in range(9):
             k, s = ENC_K[i], ENC_S[i]
-            x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2)
+            c = ENC_NC[i]
+            N, H, W = x.shape[0], x.shape[2], x.shape[3]
+            OH, OW = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+            img_out, dst = None, None
+            if packed and (i < 8 or tap is not None):
+                # skip features of the accumulate network share the ConvLSTM's image (2c channels: x then h)
+                lstm_img = tap is not None and i % 2 == 0
+                img_out = ops.PackedImage(N, NPARTS, 2 * c if lstm_img else c, OH, OW, x.device)
+                if lstm_img and c % 8:
+                    # x and h share a plane (12 channels): the h quarter of step 0's images is read (against zero weights)
+                    # before anything writes it
+                    img_out.images(0, N // tap.T).buf.zero_()
+                dst = img_out.slot(0, 0, pad_tail=not lstm_img)
+            x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2,
+                            prepacked=img_in, dst=dst)
             if i % 2 == 0:
-                feats.append(x)
-        return feats     # x1, x3, x5, x7, x9
+                feats.append(x if tap is None else tap(i // 2, x, img_out))
+            img_in = img_out
+        return feats     # x1, x3, x5, x7, x9 (or what `tap` made of them)
 
 
 def _as_grouped(parts: Sequence[torch.Tensor]) -> torch.Tensor:
@@ -147,13 +170,16 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
         """x: [T*B, 72, 200, 200] with image index t*B + b  ->  [B, 72, 200, 200]."""
         TB = x.shape[0]
         B = TB // T
-        feats = self._encode(x)
-        hs = []
-        for i, f in enumerate(feats):
+
+        def lstm(level, f, image):
+            # runs right after the encoder layer that made f: the ConvLSTM only needs that level, and on the packed path it
+            # completes the [x, h] image before enc_{i+1} reads x out of it
             seq = f.view(T, B, f.shape[1], f.shape[2], f.shape[3])
-            h, _ = ops.convlstm(seq, getattr(self, "lstm%d_w" % (i + 1)), getattr(self, "lstm%d_b" % (i + 1)),
-                                groups=NPARTS, return_all=False)
-            hs.append(h)
+            h, _ = ops.convlstm(seq, getattr(self, "lstm%d_w" % (level + 1)), getattr(self, "lstm%d_b" % (level + 1)),
+                                groups=NPARTS, return_all=False, seq_image=image)
+            return h
+        lstm.T = T
+        hs = self._encode(x, tap=lstm)
         x = hs[4]
         for i in range(4):            # Upsampler_SE: bilinear(AC=True) to a fixed size, cat skip, conv+lrelu
             skip = hs[3 - i]
@@ -399,14 +425,22 @@ class VGG19_CRN(nn.Module):
 
     def forward(self, x):
         feats = []
-        for kind, idx in self._layers:
-            if idx > self.TAPS[-1]:
-                break
+        layers = [l for l in self._layers if l[1] <= self.TAPS[-1]]
+        img_in = None
+        for li, (kind, idx) in enumerate(layers):
             if kind == "pool":
                 x = ops.avg_pool(x, 2, 2, 0)
+                img_in = None
             else:
                 conv = getattr(self.vgg_model, str(idx))
-                x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=1, act=ACT_RELU)
+                # conv -> conv edges: the epilogue writes the next layer's packed input image (packed bf16 path only)
+                nxt_is_conv = li + 1 < len(layers) and layers[li + 1][0] == "conv"
+                img_out = None
+                if nxt_is_conv and ops.packed_active():
+                    img_out = ops.PackedImage(x.shape[0], 1, conv.weight.shape[0], x.shape[2], x.shape[3], x.device)
+                x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=1, act=ACT_RELU, prepacked=img_in,
+                               dst=img_out.slot(0, 0, pad_tail=True) if img_out is not None else None)
+                img_in = img_out
                 if idx in self.TAPS:
                     feats.append(x)
         return feats

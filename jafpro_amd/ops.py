@@ -16,7 +16,7 @@ import torch
 from torch.autograd import Function
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DGRAD, PACK_FWD,
-                   PACK_LSTM, PREC_BF16, PREC_BF16X3, PREC_F32, ConvDesc, ConvPlan, check, lib)
+                   PACK_LSTM, PREC_BF16, PREC_BF16X3, PREC_F32, ConvDesc, ConvPlan, PackedIO, check, lib)
 
 __all__ = ["set_precision", "get_precision", "conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
            "reflect_pad", "texture_warp", "grid_sample", "blend", "mul_bcast", "part_mask_mul",
@@ -224,6 +224,76 @@ def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc) -> torch.Tensor:
     return xp
 
 
+class PackedImage:
+    """A convolution's input as the kernels want it -- bf16 [N][G][ng8][H*W][8], `C` channels per group padded to a
+    multiple of 8 -- allocated BEFORE its producers run: each producer (conv / ConvLSTM epilogue, LayerNorm, ...)
+    writes its channels into its slot, so the concatenation the consumer reads (`cat[x, h]`, `cat[up, skip]`) is
+    never built in fp32 and no separate packing pass exists (include/jafpro_hip.h, jaf_packed_io).  Only made while
+    the packed bf16 path is active (`packed_active()`); module code passes None otherwise and everything falls back to
+    jaf_conv2d_pack_input."""
+    __slots__ = ("buf", "N", "G", "C", "ng8", "H", "W")
+
+    def __init__(self, N: int, G: int, C: int, H: int, W: int, device, zero: bool = False, buf: Optional[torch.Tensor] = None):
+        self.N, self.G, self.C, self.H, self.W = int(N), int(G), int(C), int(H), int(W)
+        self.ng8 = (self.C + 7) // 8
+        n = self.N * self.G * self.ng8 * self.H * self.W * 16
+        if buf is None:
+            buf = (torch.zeros if zero else torch.empty)(n, device=device, dtype=torch.uint8)
+        self.buf = buf
+
+    def images(self, n0: int, n: int) -> "PackedImage":
+        """The sub-image holding images n0 .. n0+n (a view of the same memory)."""
+        per = self.G * self.ng8 * self.H * self.W * 16
+        return PackedImage(n, self.G, self.C, self.H, self.W, self.buf.device, buf=self.buf[n0 * per:(n0 + n) * per])
+
+    def slot(self, coff: int = 0, img_off: int = 0, pad_tail: bool = False) -> "PackedDst":
+        return PackedDst(self, coff, img_off, pad_tail)
+
+
+class PackedDst:
+    """Where a producer writes inside a PackedImage: channels [coff, coff + Cout) of every group of image n + img_off;
+    `pad_tail`: this producer owns the image's last channels and also zeroes the padding up to the next multiple of 8."""
+    __slots__ = ("image", "coff", "img_off", "pad_tail")
+
+    def __init__(self, image: PackedImage, coff: int, img_off: int, pad_tail: bool):
+        if coff % 4:
+            raise ValueError("packed destination channel offset must be a multiple of 4")
+        self.image, self.coff, self.img_off, self.pad_tail = image, int(coff), int(img_off), bool(pad_tail)
+
+
+_PACKED_IMAGES = os.environ.get("JAF_NO_PACKED_IMAGES") is None
+
+
+def set_packed_images(flag: bool) -> bool:
+    """A/B switch: False sends every layer back through jaf_conv2d_pack_input (same numbers, one more pass per layer)."""
+    global _PACKED_IMAGES
+    prev, _PACKED_IMAGES = _PACKED_IMAGES, bool(flag)
+    return prev
+
+
+def packed_active() -> bool:
+    """True while convolutions run on the packed-input bf16 kernels (the only mode PackedImages apply to)."""
+    return _PACKED_IMAGES and _USE_PACKED and _PRECISION == PREC_BF16
+
+
+def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False) -> Optional[PackedIO]:
+    if prepacked is None and dst is None:
+        return None
+    io = PackedIO()
+    io.in_ng8_tot = prepacked.ng8 if prepacked is not None else 0
+    if dst is not None:
+        io.dst = dst.image.buf.data_ptr()
+        io.dst_ng8_tot, io.dst_coff, io.dst_img_off, io.dst_pad_tail = dst.image.ng8, dst.coff, dst.img_off, 1 if dst.pad_tail else 0
+    io.skip_f32 = 1 if skip_f32 else 0
+    return io
+
+
+def _check_image(img: PackedImage, N, G, Cin, H, W, what: str):
+    if (img.N, img.G, img.H, img.W) != (N, G, H, W) or img.C < Cin:
+        raise RuntimeError("%s: packed image [N=%d G=%d C=%d %dx%d] does not fit N=%d G=%d Cin=%d %dx%d"
+                           % (what, img.N, img.G, img.C, img.H, img.W, N, G, Cin, H, W))
+
+
 def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mode: int, key) -> torch.Tensor:
     """Packs `weight` for (desc, plan, mode); cached while the SAME tensor object is not modified
     (the entry holds a weak reference: a new tensor that reuses a freed address must not hit)."""
@@ -383,7 +453,8 @@ class LNStats:
 def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_tot: int, mode: int,
               bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
-              xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None):
+              xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
+              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None):
     if out is None:
         out_ctot = G * Cout
         out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
@@ -394,17 +465,26 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
     pl = _plan(key, d, 0)
     wpk = _packed(weight, w_rows_tot, d, pl, mode, key[:17])
     if _packed_path(d):
-        if xp is None:
+        if prepacked is not None:           # the producers already wrote this layer's input image
+            _check_image(prepacked, N, G, Cin, H, W, "conv2d")
+            xp = prepacked.buf
+        elif xp is None:
             xp = pack_input(srcs, d)
+        if dst is not None:
+            _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
+            if dst.img_off + N > dst.image.N:
+                raise RuntimeError("conv2d destination: images %d..%d outside the packed image (%d)" % (dst.img_off, dst.img_off + N, dst.image.N))
+        io = _io_struct(prepacked, dst)
         sums = None
         if ln_stats is not None:
             ln_stats.filled = False
             if act == ACT_NONE and G == 1:
                 sums = ln_stats.buffer(N, out.device)
         ev = _PROF.begin() if _PROF is not None else None
-        check(lib().jaf_conv2d_fwd_packed_stats(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out),
-                                                _p(sums), ln_stats.slots if sums is not None else 1),
-              "jaf_conv2d_fwd_packed_stats")
+        check(lib().jaf_conv2d_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out),
+                                             _p(sums), ln_stats.slots if sums is not None else 1,
+                                             ctypes.byref(io) if io is not None else None),
+              "jaf_conv2d_fwd_packed_io")
         if sums is not None:
             ln_stats.filled = True
         if ev is not None:
@@ -432,7 +512,7 @@ def _grad_inplace(p: torch.Tensor) -> bool:
 
 class _ConvMeta:
     __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
-                 "KH", "KW", "cin_tot", "ln_stats")
+                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst")
 
 
 def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
@@ -450,8 +530,8 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
             dzd = _make_desc(m.N, m.G, m.Cout, 1, m.OH, m.OW, m.OH, m.OW, 1, 1, 1, 0, 0, 1,
                              [(m.Cout, m.G * m.Cout, 0, m.Cout)], 1, 0, m.G, 0, ACT_NONE, 0.0)
             dzp = pack_input([dz], dzd)
-        check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xp), _p(dzp), _p(dw), 1 if inplace else 0),
-              "jaf_conv2d_wgrad_packed")
+        check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
+                                           1 if inplace else 0), "jaf_conv2d_wgrad_packed_ex")
         wname = _wgrad_dma_name(m.Cout, m.KH)
     else:
         check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
@@ -466,11 +546,13 @@ class _ConvFn(Function):
     @staticmethod
     def forward(ctx, weight, bias, meta: _ConvMeta, *srcs):
         m = meta
+        use_img = packed_active()
         y, xp = _conv_raw(srcs, m.specs, weight, m.Cout, PACK_FWD, bias, m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW,
                           m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True,
-                          ln_stats=m.ln_stats)
+                          ln_stats=m.ln_stats, prepacked=m.prepacked if use_img else None, dst=m.dst if use_img else None)
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
         ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
+        ctx.xp_ng8 = m.prepacked.ng8 if (use_img and m.prepacked is not None) else 0
         ctx.meta = m
         ctx.mode = (_PRECISION, _USE_PACKED)
         ctx.has_bias = bias is not None
@@ -561,9 +643,12 @@ class _ConvFn(Function):
 
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0,
            act: int = ACT_NONE, slope: float = 0.0, groups: int = 1, shared: Optional[Sequence[bool]] = None,
-           ln_stats: Optional[LNStats] = None):
+           ln_stats: Optional[LNStats] = None, prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None):
     """Grouped convolution over the channel concatenation of `srcs` with fused bias + activation.
     `ln_stats`: see LNStats (filled only on the packed bf16 path with act NONE and groups 1).
+    `prepacked`: the packed bf16 image of exactly this concatenation, already written by the producers of `srcs`
+    (then `srcs` are only the autograd edges); `dst`: the consumer's image slot the outputs are also written to.
+    Both are honoured on the packed bf16 path only (see PackedImage).
 
     srcs[i]: [N, groups*c_i, H, W] (or [N, c_i, H, W] when shared[i]: every group reads the same
     channels).  weight: [groups*Cout, sum(c_i), KH, KW] or [groups, Cout, sum(c_i), KH, KW].
@@ -600,6 +685,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     m.specs, m.N, m.Cin, m.Cout, m.H, m.W = specs, int(N), Cin, Cout, int(H), int(W)
     m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
     m.ln_stats = ln_stats
+    m.prepacked, m.dst = prepacked, dst
     return _ConvFn.apply(weight, bias, m, *srcs)
 
 
@@ -628,8 +714,10 @@ def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=
 # --------------------------------------------------------------------------------------------
 class _ConvLSTMFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0):
+    def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0, seq_image=None, final_dst=None):
         # x: [T, N, G*C, H, W]; weight: [G*4C, 2C, 3, 3]; bias [G*4C]; h0/c0: [N, G*C, H, W] or None (zero state)
+        # seq_image (packed bf16 path only): PackedImage of T*N images x 2C channels whose x halves the producer of `x`
+        # already wrote; step t reads image block t and its epilogue writes h_t into block t+1 (final_dst: where h_T goes)
         T, N, GC, H, W = x.shape
         C = GC // G
         L = lib()
@@ -642,6 +730,12 @@ class _ConvLSTMFn(Function):
         g16 = _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
         gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.bfloat16 if g16 else torch.float32) if keep else None
         xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
+        use_img = seq_image is not None and packed_active() and h0 is None
+        if use_img:
+            _check_image(seq_image, T * N, G, 2 * C, H, W, "convlstm")
+        # with the images, h_t for t < T-1 exists only as bf16 inside the next step's image (nothing reads it in fp32:
+        # the fused gate backward needs c_t and the gates, the weight gradient the packed images)
+        skip_h = use_img and g16 and not need_all
         for t in range(T):
             first = t == 0 and h0 is None
             hprev = h0 if t == 0 else hs[t - 1]
@@ -654,13 +748,26 @@ class _ConvLSTMFn(Function):
             wpk = _packed(weight, 4 * C, d, pl, PACK_LSTM, key)
             ev = _PROF.begin() if _PROF is not None else None
             if _packed_path(d):
-                xp = pack_input([x[t]] if first else [x[t], hprev], d)
+                io = None
+                if use_img:
+                    xp = seq_image.images(t * N, N).buf
+                    hdst = seq_image.slot(C, (t + 1) * N) if t + 1 < T else final_dst
+                    if hdst is not None:
+                        # n + img_off indexes the destination image from ITS base; the input block starts at t*N
+                        io = _io_struct(seq_image, hdst, skip_f32=(skip_h and t + 1 < T))
+                    else:
+                        io = _io_struct(seq_image, None)
+                else:
+                    xp = pack_input([x[t]] if first else [x[t], hprev], d)
+                    if final_dst is not None and t + 1 == T and packed_active():
+                        io = _io_struct(None, final_dst)
                 if keep:
                     xps.append(xp)
-                check(L.jaf_convlstm_cell_fwd_packed(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
-                                                     None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
-                                                     _p(gates[t]) if keep else None, 1 if g16 else 0),
-                      "jaf_convlstm_cell_fwd_packed")
+                check(L.jaf_convlstm_cell_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
+                                                        None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
+                                                        _p(gates[t]) if keep else None, 1 if g16 else 0,
+                                                        ctypes.byref(io) if io is not None else None),
+                      "jaf_convlstm_cell_fwd_packed_io")
                 if ev is not None:
                     _PROF.end("conv_dma_kernel<%d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
@@ -675,6 +782,8 @@ class _ConvLSTMFn(Function):
         ctx.bias_ref = bias
         ctx.xps = xps if (keep and len(xps) == T) else None
         ctx.has_state = h0 is not None
+        ctx.xp_ng8 = seq_image.ng8 if use_img else 0
+        ctx.h_skipped = skip_h
         ctx.mode = (_PRECISION, _USE_PACKED)        # backward uses the arithmetic the forward ran in
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
@@ -704,7 +813,7 @@ class _ConvLSTMFn(Function):
         dw = weight.grad if w_inplace else torch.empty_like(weight)
         # fused path: gate backward writes the packed bf16 gate gradients + the bias sums directly
         fused = ctx.xps is not None and _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
-        if gates.dtype == torch.bfloat16 and not fused:
+        if (gates.dtype == torch.bfloat16 or ctx.h_skipped) and not fused:
             raise RuntimeError("convlstm: precision changed between forward and backward")
         if b_inplace:
             db = bias.grad
@@ -743,8 +852,8 @@ class _ConvLSTMFn(Function):
                     wst.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(wst if wst is not None else torch.cuda.current_stream()):
                     ev = _PROF.begin() if _PROF is not None else None
-                    check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
-                                                    1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
+                    check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
+                                                       1 if w_inplace else acc), "jaf_conv2d_wgrad_packed_ex")
                     if ev is not None:
                         _PROF.end(_wgrad_dma_name(4 * C, 3), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:
@@ -759,8 +868,8 @@ class _ConvLSTMFn(Function):
                 if ctx.xps is not None and _packed_path(d):
                     gd = _make_desc(N, G, 4 * C, 1, H, W, H, W, 1, 1, 1, 0, 0, 1, gspec, 1, 0, G, 0, ACT_NONE, 0.0)
                     gtp = pack_input([gt], gd)
-                    check(L.jaf_conv2d_wgrad_packed(_s(), ctypes.byref(d), _p(ctx.xps[t]), _p(gtp), _p(dw),
-                                                    1 if w_inplace else acc), "jaf_conv2d_wgrad_packed")
+                    check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
+                                                       1 if w_inplace else acc), "jaf_conv2d_wgrad_packed_ex")
                     wname = _wgrad_dma_name(4 * C, 3)
                 else:
                     check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hprev), None,
@@ -779,11 +888,12 @@ class _ConvLSTMFn(Function):
             dc = dc_prev
         dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None
         dc0 = dc if (ctx.has_state and ctx.needs_input_grad[6]) else None
-        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0
+        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0, None, None
 
 
 def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int = 1, return_all: bool = False,
-             state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+             state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seq_image: Optional[PackedImage] = None,
+             final_dst: Optional[PackedDst] = None):
     """x: [T, N, G*C, H, W] -> (h_T [N, G*C, H, W] or all h_t, c_T).  `state` = (h0, c0), default the zero
     state of src/convLSTM.py:58-63,119-120; gate order i,f,o,g (:46).  Differentiable w.r.t. x, the parameters,
     the initial state, and through both h and c_T (T = 1 with a state is ConvLSTMCell.forward, :41-56)."""
@@ -793,7 +903,7 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
         h0, c0 = _chk(state[0], "convlstm h0"), _chk(state[1], "convlstm c0")
         if h0.shape != x.shape[1:] or c0.shape != x.shape[1:]:
             raise RuntimeError("convlstm: state shape %s / %s does not match the input %s" % (tuple(h0.shape), tuple(c0.shape), tuple(x.shape[1:])))
-    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all, h0, c0)
+    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all, h0, c0, seq_image, final_dst)
 
 
 # --------------------------------------------------------------------------------------------
@@ -801,7 +911,7 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
 # --------------------------------------------------------------------------------------------
 class _LayerNormLReLUFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats]):
+    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats], dst=None):
         N, C, H, W = x.shape
         L = lib()
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
@@ -812,8 +922,15 @@ class _LayerNormLReLUFn(Function):
             ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
             check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")
         y = torch.empty_like(x)
-        check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
-              "jaf_layernorm_lrelu_fwd")
+        if dst is not None and packed_active():
+            _check_image(dst.image, N, 1, 0, H, W, "layernorm destination")
+            if dst.img_off or dst.coff % 8 or dst.coff + C > dst.image.ng8 * 8:
+                raise RuntimeError("layernorm destination: slot does not fit")
+            check(L.jaf_layernorm_lrelu_fwd_packed(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(dst.image.buf),
+                                                   dst.image.ng8, dst.coff, N, C, H * W, slope), "jaf_layernorm_lrelu_fwd_packed")
+        else:
+            check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
+                  "jaf_layernorm_lrelu_fwd")
         ctx.eps, ctx.slope = eps, slope
         ctx.save_for_backward(x, gamma, beta, stats)
         return y
@@ -832,12 +949,14 @@ class _LayerNormLReLUFn(Function):
         check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
                                             _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
               "jaf_layernorm_lrelu_bwd")
-        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None
+        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None
 
 
-def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01, pre: Optional[LNStats] = None):
+def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01, pre: Optional[LNStats] = None,
+                    dst: Optional[PackedDst] = None):
+    """`dst`: the consumer convolution's packed image slot (packed bf16 path only, see PackedImage)."""
     _chk(x, "layernorm x"); _chk(gamma, "gamma"); _chk(beta, "beta")
-    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre)
+    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre, dst)
 
 
 class _BatchNormActFn(Function):

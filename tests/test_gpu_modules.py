@@ -311,3 +311,47 @@ def test_convlstm_cell_single_step_and_explicit_state(mode, tol):
             print("%s %-8s %-3s grad rel-L2 %.3e" % (mode, tag, k, r))
             assert r <= tol, (mode, tag, k, r)
     assert out.shape == (B, Tn, 8, 10, 12)
+
+
+def test_packed_images_are_bit_identical_to_the_packing_pass():
+    """bf16 path: producers writing straight into the consumer's packed image (ops.PackedImage: encoder chains, the
+    ConvLSTM [x, h] sequence images, h_t only as bf16 for t < T-1) must give the very numbers of the path that packs every
+    layer's input with jaf_conv2d_pack_input -- outputs, input gradient and every parameter gradient."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.crn_model import CRN_smaller
+    from jafpro_amd.networks import Accumulate_LSTM_no_loss, UNet_inpainter, VGG19_CRN
+    prev = ops.set_precision("bf16")
+    try:
+        for cls, seed, T_ in ((Accumulate_LSTM_no_loss, 21, 3), (UNet_inpainter, 31, 1), (CRN_smaller, 41, 0), (VGG19_CRN, 71, 0)):
+            res = []
+            for images in (True, False):
+                pi = ops.set_packed_images(images)
+                try:
+                    B = 2
+                    if cls is CRN_smaller:
+                        m = synth.load_synth(CRN_smaller(3, fg=True), seed).cuda()
+                        x = T(synth.uniform(seed, "x", (B, 3, 128, 128))).requires_grad_(True)
+                        rgb, mask = m(x, 128)
+                        out = torch.cat([rgb, mask], 1)
+                    elif cls is VGG19_CRN:
+                        m = synth.load_synth(VGG19_CRN(requires_grad=True), seed).cuda()
+                        x = T(synth.uniform(seed, "x", (B, 3, 64, 64), -100, 100)).requires_grad_(True)
+                        fs = m(x)
+                        out = torch.cat([f.reshape(B, -1) for f in fs], 1)
+                    else:
+                        m = synth.load_synth(cls(), seed).cuda()
+                        x = T(synth.uniform(seed, "x", (T_ * B, 72, 200, 200))).requires_grad_(True)
+                        out = m.forward_grouped(x, T_) if cls is Accumulate_LSTM_no_loss else m.forward_grouped(x)
+                    proj = T(synth.uniform(seed, "proj", tuple(out.shape)))
+                    (out * proj).sum().backward()
+                    res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+                finally:
+                    ops.set_packed_images(pi)
+            (o1, g1, p1), (o0, g0, p0) = res
+            assert torch.equal(o1, o0), cls.__name__
+            assert torch.equal(g1, g0), cls.__name__
+            for k in p0:       # weight gradients: fp32 atomics -> summation order only
+                d = (p1[k] - p0[k]).abs().max().item()
+                assert d <= 1e-5 * max(1.0, p0[k].abs().max().item()), (cls.__name__, k, d)
+    finally:
+        ops.set_precision(prev)

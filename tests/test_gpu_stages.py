@@ -121,11 +121,11 @@ def test_checkpoints_through_a_gpu_trainer(tmp_path):
     from tests._step_util import build
     M, tr, _, _, dbatch, _ = build(1)
     tr.train_step(dbatch)
+    with torch.no_grad():       # (train-mode BatchNorm: this forward moves the running statistics, so it comes before the save)
+        a = generator_forward(M, dbatch, (0, 1, 2, 3), 0)["final_output"]
     paths = stages.save_checkpoints(str(tmp_path), 12, stages.stage4_modules(M))
     assert sorted(os.path.basename(p) for p in paths.values()) == sorted(
         "%s_iter_12.pth" % p for p in ("Accu", "inpaint", "bg", "refine", "D", "FD", "pro"))
-    with torch.no_grad():
-        a = generator_forward(M, dbatch, (0, 1, 2, 3), 0)["final_output"]
     M2, tr2, _, _, _, _ = build(1)
     with torch.no_grad():
         before = generator_forward(M2, dbatch, (0, 1, 2, 3), 0)["final_output"]

@@ -215,7 +215,13 @@ def test_two_rank_trainer_vs_chunked_oracle(tmp_path, drop_face_rank):
             if not p.requires_grad:
                 continue
             g0, g1 = res[0]["grads"][n][k], res[1]["grads"][n][k]
-            assert torch.equal(g0, g1), (n, k)                      # both ranks hold the same averaged gradient
+            if n in ("D", "face"):
+                # what is left in the discriminators' buffers = the all-reduced gradients of their own updates + the
+                # never-used deposit of the generator's backward pass (F10), which stays rank-local: the ranks differ by
+                # that deposit and their MEAN is the oracle's buffer
+                g0 = (g0.double() + g1.double()) / 2
+            else:
+                assert torch.equal(g0, g1), (n, k)                  # both ranks hold the same averaged gradient
             d = g0.double() - p.grad.double()
             num += float((d * d).sum()); den += float((p.grad.double() ** 2).sum())
             assert torch.equal(res[0]["params"][n][k], res[1]["params"][n][k]), (n, k)

@@ -297,3 +297,22 @@ def test_checkpoint_files_match_the_reference_format(golden_dir, tmp_path):
     assert os.path.basename(stages.checkpoint_path("x", "accu", 5000, stage1=True)) == "iter_5000.pth"
     assert stages.multistep_lr(1e-4, 1) == 1e-4 and stages.multistep_lr(1e-4, 100000) == 1e-4
     assert abs(stages.multistep_lr(1e-4, 100001) - 3e-5) < 1e-12 and abs(stages.multistep_lr(1e-4, 150001) - 9e-6) < 1e-12
+
+
+def test_metric_oracle_known_answers():
+    """Closed-form pins of oracle/metrics_oracle.py (the libraries test/video_evaluation.py calls are absent offline)."""
+    from oracle import metrics_oracle as MO
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 200, 90]]], np.uint8)   # BGR
+    assert MO.bgr_to_gray(px)[0].tolist() == [29, 150, 76, 255, 0, int(round(0.114 * 10 + 0.587 * 200 + 0.299 * 90))]
+    r = np.random.default_rng(0)
+    a = r.integers(0, 256, (64, 64), dtype=np.uint8)
+    assert abs(MO.compare_ssim(a, a) - 1.0) < 1e-12 and abs(MO.msssim(a, a) - 1.0) < 1e-9
+    b = np.clip(a.astype(int) + 10, 0, 255).astype(np.uint8)
+    c = r.integers(0, 256, (64, 64), dtype=np.uint8)
+    assert MO.compare_ssim(a, c) < 0.1 < MO.compare_ssim(a, b) < 1.0
+    d = a.copy(); d[::2, ::2] ^= 1                                   # mse = 0.25 exactly
+    assert abs(MO.psnr(a, d) - 10 * np.log10(255.0 ** 2 / 0.25)) < 1e-12
+    # a constant image pair: SSIM reduces to the luminance term
+    u, v = np.full((32, 32), 100, np.uint8), np.full((32, 32), 120, np.uint8)
+    C1 = (0.01 * 255) ** 2
+    assert abs(MO.compare_ssim(u, v) - (2 * 100 * 120 + C1) / (100 ** 2 + 120 ** 2 + C1)) < 1e-12
