@@ -50,6 +50,16 @@ def _c(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+_GRID_Z = 65535
+
+
+def _n_chunks(N: int, planes_per_image: int):
+    """(n0, n1) image ranges whose plane count fits the z extent of a HIP grid: the per-plane kernels put
+    (image, channel) on blockIdx.z, so batches beyond 65535 planes go out as several launches instead of failing."""
+    per = max(1, _GRID_Z // max(1, planes_per_image))
+    return [(n0, min(N, n0 + per)) for n0 in range(0, N, per)]
+
+
 # --------------------------------------------------------------------------------------------
 # convolution core
 # --------------------------------------------------------------------------------------------
@@ -218,9 +228,20 @@ def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc) -> torch.Tensor:
     if nbytes <= 0:
         raise RuntimeError("jaf_conv2d_packed_input_bytes: invalid descriptor")
     xp = torch.empty(nbytes, device=srcs[0].device, dtype=torch.uint8)
-    ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+    ng8 = (d.Cin + 7) // 8
+    chunks = _n_chunks(d.N, d.G * ng8)
     with _hbm("conv_pack_input_kernel", 4.0 * d.N * d.G * d.Cin * d.H * d.W + nbytes):
-        check(lib().jaf_conv2d_pack_input(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(xp)), "jaf_conv2d_pack_input")
+        if len(chunks) == 1:
+            ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
+            check(lib().jaf_conv2d_pack_input(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(xp)), "jaf_conv2d_pack_input")
+        else:       # more (image, group, plane) triples than a grid's z extent: a few launches over image ranges
+            per = nbytes // d.N
+            for n0, n1 in chunks:
+                dc = type(d).from_buffer_copy(d)
+                dc.N = n1 - n0
+                ps = [_p(t[n0:n1]) for t in srcs] + [None] * (3 - len(srcs))
+                check(lib().jaf_conv2d_pack_input(_s(), ctypes.byref(dc), ps[0], ps[1], ps[2], _p(xp[n0 * per:n1 * per])),
+                      "jaf_conv2d_pack_input")
     return xp
 
 
@@ -592,8 +613,11 @@ class _ConvFn(Function):
             ng8 = (m.Cout + 7) // 8
             dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16, device=dy.device, dtype=torch.uint8)
             with _hbm("conv_pack_dz_kernel", dy.numel() * (4.0 + (4.0 if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
-                check(L.jaf_conv2d_pack_dz(_s(), _p(dy), _p(y) if m.act != ACT_NONE else None, m.N, m.G, m.Cout, m.OH, m.OW,
-                                           m.act, m.slope, _p(dzp), _p(dz), _p(dbt)), "jaf_conv2d_pack_dz")
+                per = dzp.numel() // m.N
+                for n0, n1 in _n_chunks(m.N, m.G * ng8):
+                    check(L.jaf_conv2d_pack_dz(_s(), _p(dy[n0:n1]), _p(y[n0:n1]) if m.act != ACT_NONE else None, n1 - n0, m.G, m.Cout,
+                                               m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
+                                               _p(dz[n0:n1]) if dz is not None else None, _p(dbt)), "jaf_conv2d_pack_dz")
         elif m.act != ACT_NONE:
             dz = torch.empty_like(dy)
             check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
@@ -1014,7 +1038,8 @@ class _AvgPoolFn(Function):
         N, C, H, W = x.shape
         OH, OW = _out_size(H, k, stride, pad), _out_size(W, k, stride, pad)
         y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32)
-        check(lib().jaf_avgpool_fwd(_s(), _p(x), _p(y), N * C, H, W, OH, OW, k, stride, pad), "jaf_avgpool_fwd")
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_avgpool_fwd(_s(), _p(x[n0:n1]), _p(y[n0:n1]), (n1 - n0) * C, H, W, OH, OW, k, stride, pad), "jaf_avgpool_fwd")
         ctx.cfg = (N, C, H, W, OH, OW, k, stride, pad)
         return y
 
@@ -1023,7 +1048,8 @@ class _AvgPoolFn(Function):
         N, C, H, W, OH, OW, k, stride, pad = ctx.cfg
         dy = _c(dy)
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
-        check(lib().jaf_avgpool_bwd(_s(), _p(dy), _p(dx), N * C, H, W, OH, OW, k, stride, pad), "jaf_avgpool_bwd")
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_avgpool_bwd(_s(), _p(dy[n0:n1]), _p(dx[n0:n1]), (n1 - n0) * C, H, W, OH, OW, k, stride, pad), "jaf_avgpool_bwd")
         return dx, None, None, None
 
 
@@ -1037,8 +1063,9 @@ class _ResizeFn(Function):
         N, C, H, W = x.shape
         y0, x0, ch, cw = crop if crop is not None else (0, 0, H, W)
         y = torch.empty((N, C, OH, OW), device=x.device, dtype=torch.float32)
-        check(lib().jaf_resize_fwd(_s(), _p(x), _p(y), N, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0,
-                                   1 if nearest else 0), "jaf_resize_fwd")
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_resize_fwd(_s(), _p(x[n0:n1]), _p(y[n0:n1]), n1 - n0, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0,
+                                       1 if nearest else 0), "jaf_resize_fwd")
         ctx.cfg = (N, C, H, W, y0, x0, ch, cw, OH, OW, align, nearest)
         return y
 
@@ -1049,8 +1076,9 @@ class _ResizeFn(Function):
             raise RuntimeError("nearest resize has no backward on this path")
         dy = _c(dy)
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
-        check(lib().jaf_resize_bwd(_s(), _p(dy), _p(dx), N, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0),
-              "jaf_resize_bwd")
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_resize_bwd(_s(), _p(dy[n0:n1]), _p(dx[n0:n1]), n1 - n0, C, H, W, y0, x0, ch, cw, OH, OW, 1 if align else 0),
+                  "jaf_resize_bwd")
         return dx, None, None, None, None, None
 
 
@@ -1064,7 +1092,8 @@ class _ReflectPadFn(Function):
     def forward(ctx, x, p):
         N, C, H, W = x.shape
         y = torch.empty((N, C, H + 2 * p, W + 2 * p), device=x.device, dtype=torch.float32)
-        check(lib().jaf_reflect_pad_fwd(_s(), _p(x), _p(y), N * C, H, W, p), "jaf_reflect_pad_fwd")
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_reflect_pad_fwd(_s(), _p(x[n0:n1]), _p(y[n0:n1]), (n1 - n0) * C, H, W, p), "jaf_reflect_pad_fwd")
         ctx.cfg = (N, C, H, W, p)
         return y
 
@@ -1073,7 +1102,8 @@ class _ReflectPadFn(Function):
         N, C, H, W, p = ctx.cfg
         dy = _c(dy)
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
-        check(lib().jaf_reflect_pad_bwd(_s(), _p(dy), _p(dx), N * C, H, W, p), "jaf_reflect_pad_bwd")
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_reflect_pad_bwd(_s(), _p(dy[n0:n1]), _p(dx[n0:n1]), (n1 - n0) * C, H, W, p), "jaf_reflect_pad_bwd")
         return dx, None
 
 

@@ -564,3 +564,32 @@ def test_layernorm_statistics_from_conv_epilogue(N, Cin, Cout, H, W):
     st2 = ops.LNStats()
     ops.conv2d(x, w, b, stride=1, pad=1, act=0, ln_stats=st2)      # f32 mode
     assert not st2.filled
+
+
+def test_launches_split_over_the_batch_beyond_the_grid_z_extent(monkeypatch):
+    """The per-plane kernels put (image, channel) on blockIdx.z (<= 65535): larger batches go out as several launches over
+    image ranges (ops._n_chunks).  With the limit lowered to 7 planes the chunked results must equal the single launch."""
+    ops = _ops()
+    x = dev(R(1, 5, 6, 20, 24))
+    w, b = dev(R(2, 8, 6, 3, 3)), dev(R(3, 8))
+
+    def run():
+        xr = x.clone().requires_grad_(True)
+        wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.avg_pool(ops.reflect_pad(ops.resize(xr, (30, 36), True), 2), 3, 2, 1)
+        z = ops.conv2d(y, wr, br, stride=1, pad=1, act=ops.ACT_LRELU, slope=0.2)
+        (z * z).sum().backward()
+        return z.detach(), xr.grad, wr.grad, br.grad
+
+    for mode in ("f32", "bf16"):
+        prev = ops.set_precision(mode)
+        try:
+            ref = run()
+            monkeypatch.setattr(ops, "_GRID_Z", 7)
+            got = run()
+            monkeypatch.setattr(ops, "_GRID_Z", 65535)
+        finally:
+            ops.set_precision(prev)
+        assert len(ops._n_chunks(5, 6)) == 1
+        for a, r in zip(got, ref):
+            assert maxerr(a, r) <= 1e-5 * max(1.0, float(r.abs().max())), mode

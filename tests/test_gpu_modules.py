@@ -344,13 +344,18 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                         out = m.forward_grouped(x, T_) if cls is Accumulate_LSTM_no_loss else m.forward_grouped(x)
                     proj = T(synth.uniform(seed, "proj", tuple(out.shape)))
                     (out * proj).sum().backward()
-                    res.append((out.detach().clone(), x.grad.clone(), {k: p.grad.clone() for k, p in m.named_parameters()}))
+                    res.append((out.detach().clone(), x.grad.clone(),
+                                {k: (p.grad.clone() if p.grad is not None else None) for k, p in m.named_parameters()}))
                 finally:
                     ops.set_packed_images(pi)
             (o1, g1, p1), (o0, g0, p0) = res
             assert torch.equal(o1, o0), cls.__name__
             assert torch.equal(g1, g0), cls.__name__
-            for k in p0:       # weight gradients: fp32 atomics -> summation order only
+            assert sum(v is not None for v in p0.values()) >= 0.8 * len(p0)
+            for k in p0:       # weight gradients: fp32 atomics -> summation order only (None: layers past the last VGG tap)
+                assert (p1[k] is None) == (p0[k] is None), k
+                if p0[k] is None:
+                    continue
                 d = (p1[k] - p0[k]).abs().max().item()
                 assert d <= 1e-5 * max(1.0, p0[k].abs().max().item()), (cls.__name__, k, d)
     finally:
