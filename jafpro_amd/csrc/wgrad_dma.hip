@@ -42,7 +42,6 @@ struct WgDArgs {
     int off_dz;
     int ngin8, ngout8;
     int xng8;              // planes per (image, group) of the packed input image (>= ngin8)
-    int bufstride;         // bytes between the two LDS tile buffers (0: single buffer)
     float inv_pwp;
 };
 
@@ -146,8 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     const int xbytes = a.xng8 * HW * 16;
     const int zbytes = a.ngout8 * OHW * 16;
 
-    // DMA of one (image, pixel tile) item into LDS buffer `bufoff`
-    auto issue = [&](int item, int bufoff) {
+    for (int item = split; item < items; item += a.nsplit) {
         const int n = item / tiles;
         const int tile = item - n * tiles;
         const int ty = tile / a.tiles_x;
@@ -155,62 +153,48 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         const int oy0 = ty * WD_TH, ox0 = tx * WD_TW;
         const int iy0 = oy0 * s - d.pad_t;
         const int ix0 = ox0 * s - d.pad_l;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.xp + ((long)n * d.G + g) * (long)xbytes), 0, xbytes, 0x00020000);
-        const int tbase = (iy0 * d.W + ix0) * 16;
+
+        __syncthreads();   // previous tile consumed
+
+        {
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.xp + ((long)n * d.G + g) * (long)xbytes), 0, xbytes, 0x00020000);
+            const int tbase = (iy0 * d.W + ix0) * 16;
 #pragma unroll
-        for (int j = 0; j < WD_XI; ++j) {
-            const int i = wave + 4 * j;
-            if (i < nxi) {
-                const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
-                const int iy = iy0 + r, ix = ix0 + c;
-                const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
-                const int tci = i / a.nx;
+            for (int j = 0; j < WD_XI; ++j) {
+                const int i = wave + 4 * j;
+                if (i < nxi) {
+                    const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
+                    const int tci = i / a.nx;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rx, (__attribute__((address_space(3))) void*)(s_x + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
+                        ok ? x_goff[j] + tbase : WD_OOB, 0, 0, 0);
+                }
+            }
+            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(a.dzp + ((long)n * d.G + g) * (long)zbytes), 0, zbytes, 0x00020000);
+            const int y = z_yx >> 16, x = z_yx & 0xffff;
+            const bool okp = (oy0 + y < d.OH) && (ox0 + x < d.OW);
+            const int zb = z_goff + (oy0 * d.OW + ox0) * 16;
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const int grp8 = (co0 >> 3) + 2 * mt + z_half;
+                const bool ok = okp && (grp8 < a.ngout8);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rx, (__attribute__((address_space(3))) void*)(s_x + bufoff + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
-                    ok ? x_goff[j] + tbase : WD_OOB, 0, 0, 0);
+                    rz, (__attribute__((address_space(3))) void*)(s_dz + mt * 4096 + wave * 1024), 16,
+                    ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB, 0, 0, 0);
             }
         }
-        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(a.dzp + ((long)n * d.G + g) * (long)zbytes), 0, zbytes, 0x00020000);
-        const int y = z_yx >> 16, x = z_yx & 0xffff;
-        const bool okp = (oy0 + y < d.OH) && (ox0 + x < d.OW);
-        const int zb = z_goff + (oy0 * d.OW + ox0) * 16;
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            const int grp8 = (co0 >> 3) + 2 * mt + z_half;
-            const bool ok = okp && (grp8 < a.ngout8);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rz, (__attribute__((address_space(3))) void*)(s_dz + bufoff + mt * 4096 + wave * 1024), 16,
-                ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB, 0, 0, 0);
-        }
-    };
-
-    // Two LDS buffers when they cost no resident workgroup (a.bufstride != 0): the next item's tiles are in flight while
-    // this item's MFMAs run, and one barrier per item orders both "tiles landed" and "previous buffer no longer read".
-    // Small-channel layers are per-item latency bound (a few dozen MFMAs behind a DMA round trip); the wide ones keep one
-    // buffer and two resident workgroups per CU instead.
-    int bufoff = 0;
-    if (a.bufstride && split < items) issue(split, 0);
-    for (int item = split; item < items; item += a.nsplit) {
-        if (a.bufstride) {
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (item + a.nsplit < items) issue(item + a.nsplit, bufoff ^ a.bufstride);
-        } else {
-            __syncthreads();   // previous tile consumed
-            issue(item, 0);
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-        }
-        const unsigned char* cx = s_x + bufoff;
-        const unsigned char* cz = s_dz + bufoff;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
 
         for (int ks = wk; ks < 4; ks += WK) {
             bf16x8 af[MTW];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
-                const unsigned char* ap = cz + mt * 4096 + ks * 1024;
+                const unsigned char* ap = s_dz + mt * 4096 + ks * 1024;
                 const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[0]));
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[1]));
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -222,8 +206,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 for (int kx = 0; kx < KS; ++kx) {
                     const int a0 = (bbase[0][kx] + rowoff) ^ bswz[0][kx];
                     const int a1 = (bbase[1][kx] + rowoff) ^ bswz[1][kx];
-                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(cx + a0));
-                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(cx + a1));
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a0));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a1));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
@@ -231,7 +215,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 }
             }
         }
-        bufoff ^= a.bufstride;
     }
 
     // ---- epilogue.  3x3: transpose through LDS, then atomics along dW's memory order.  5x5 / 7x7 (a few
@@ -324,15 +307,6 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     a.inv_pwp = 1.0f / (float)a.PWp;
     JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
     int lds = a.off_dz + MTW * 4096;
-    // second tile buffer when it does not cost a resident workgroup: the register file holds `occ` workgroups of the
-    // instantiation per CU (VGPRs: <1,3> 111, <2,3> 141, <3,3> 181, <4,3> 222, <1,5> 168, <*,1> 47-71), so 160 KB / occ of
-    // LDS per workgroup is free
-    a.bufstride = 0;
-    const int occ = KS == 1 ? 6 : (KS == 5 ? 3 : (MTW == 1 ? 4 : (MTW == 2 ? 3 : 2)));
-    if (getenv("JAF_WGRAD_SINGLE_BUFFER") == nullptr && 2 * lds + 1024 <= 160 * 1024 / occ) {
-        a.bufstride = (lds + 1023) & ~1023;
-        lds = a.bufstride + lds;
-    }
     const int lds_ep = 4 * 16 * WD_EP * 4;
     if (KS == 3 && lds < lds_ep) lds = lds_ep;
     JAF_REQUIRE(lds <= 160 * 1024);

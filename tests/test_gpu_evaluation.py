@@ -45,7 +45,7 @@ def test_video_evaluator_end_to_end():
     from jafpro_amd import evaluation as E, synth
     from oracle import metrics_oracle as MO
     from oracle import torch_oracle as O
-    pred, gt = _video(1, F=2, S=128)
+    pred, gt = _video(1, F=2, S=192)
     ev = E.VideoEvaluator()
     synth.load_synth(ev, 808)
     sd = {k: v.detach().clone() for k, v in ev.state_dict().items()}
