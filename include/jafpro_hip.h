@@ -134,6 +134,12 @@ int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* s
  * jaf_act_bwd + jaf_channel_sum + jaf_conv2d_pack_input.                                         */
 int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t N, int32_t G, int32_t C,
                        int32_t H, int32_t W, int act, float slope, void* packed, float* dz, float* dbias);
+/* Same with the activation output read from the packed bf16 image the forward epilogue wrote (y_packed: planes
+ * y_ng8_tot per (image, group), this tensor's channels from y_coff, a multiple of 8) instead of an fp32 y -- for
+ * layers whose fp32 output was never written (jaf_packed_io.skip_f32).  ReLU / LeakyReLU only (the sign survives bf16). */
+int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                          int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                          void* packed, float* dz, float* dbias);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
  * [N][G][4C/8][H*W][8] (order i,f,o,g per group) and their per-channel sums ADDED to dbias[G*4C];
  * `gates` (fp32 or bf16, as the forward cell wrote them) is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0.                                   */
@@ -141,6 +147,11 @@ int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t 
                                   const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                   const float* c_cur, float* dc_prev, void* packed, float* dbias);
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
+/* flags: JAF_PLAN_NO_INTERLEAVE keeps a lane's pixel tiles 16 pixels apart (no pixel interleave): the layout that makes
+ * the 16-byte items of a packed bf16 OUTPUT image (jaf_packed_io) contiguous across the lanes of a store -- for launches
+ * that write no fp32 output (skip_f32). */
+#define JAF_PLAN_NO_INTERLEAVE 1
+int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int flags, jaf_conv_plan* plan);
 int jaf_conv2d_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                           const void* packed_in, const void* packed_w, const float* bias, float* out);
 /* Same, and the epilogue ADDS (sum, sum of squares) of every image's outputs to stats[n][slot][2] (fp64,
@@ -374,6 +385,12 @@ int jaf_project_faces_bwd(jaf_stream_t s, const float* dfaces, const float* vert
 /* Adjoint of jaf_bc_transform w.r.t. the source faces (autograd of src/nmr.py:651-653): dsrc_faces[B,NF,3,3] +=. */
 int jaf_bc_transform_bwd(jaf_stream_t s, const float* dT, const int32_t* fim, const float* wim, float* dsrc_faces,
                          int32_t B, int32_t NF, int32_t S);
+/* float_estimate.forward fused (src/cal_flow.py:28-39): out[B,C,S,S] = grid_sample(src[B,C,H,W], T, border) with T the
+ * barycentric flow of jaf_bc_transform computed per pixel and never stored; `mask` (nullable, [B,mask_c,S,S], mask_c 1 or C)
+ * multiplies the result (src/flow_net.py:91).  Forward only. */
+int jaf_flow_warp_fwd(jaf_stream_t s, const float* src, const float* src_faces, const int32_t* fim, const float* wim,
+                      const float* mask, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t NF, int32_t S,
+                      int32_t mask_c, int align_corners);
 /* cal_bc_transform fused with the y re-flip of src/cal_flow.py:30-31: T[B,S,S,2]. */
 int jaf_bc_transform(jaf_stream_t s, const float* src_faces /*[B,NF,3,3]*/, const int32_t* fim,
                      const float* wim, float* T, int32_t B, int32_t NF, int32_t S);

@@ -26,6 +26,12 @@ class float_estimate(nn.Module):
     def forward(self, src_img, src_smpl, tgt_smpl):
         src_cam, _, src_vertices, _ = src_smpl
         tgt_cam, _, tgt_vertices, _ = tgt_smpl
+        if not (torch.is_grad_enabled() and (src_img.requires_grad or src_vertices.requires_grad or src_cam.requires_grad)):
+            # stage 4: nothing differentiates the warp -> projection, rasterisation and one fused
+            # flow + border-sample kernel; the flow field T is never written
+            src_faces = self.render.project(src_cam, src_vertices)
+            _, fim, wim = self.render.render_fim_wim(tgt_cam, tgt_vertices)
+            return ops.flow_warp(src_img.contiguous(), src_faces, fim, wim, None, self.align_corners)
         flow = self.cal_flow(src_cam, None, src_vertices, None, tgt_cam, None, tgt_vertices, None)
         return self.warp_image(src_img, flow)
 

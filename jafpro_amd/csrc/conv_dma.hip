@@ -178,6 +178,8 @@ extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, con
 struct PackDzArgs {
     const float* dy;
     const float* y;        // activation output (nullable when act == NONE)
+    const unsigned char* yp;   // ... or the same values as the packed bf16 image the forward epilogue wrote (jaf_packed_io)
+    int yp_ng8, yp_cg0;        // its planes per (image, group) and the first plane of this tensor's channels
     unsigned char* out;    // packed dz
     float* dz;             // fp32 dz (nullable)
     float* dbias;          // [G*C] += sum over n, pixels (nullable)
@@ -208,6 +210,19 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
     const long HW = (long)a.H * a.W;
     float v[8][V];
     float part[8];
+    float ypk[8][V];       // y from the packed image: item (pixel i) holds this lane's 8 channels
+    if (a.yp && live) {
+        const unsigned char* ip = a.yp + ((((long)n * a.G + g) * a.yp_ng8 + a.yp_cg0 + cg) * HW + (long)yy * a.W + x) * 16;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const u32x4 w = *(const u32x4*)(ip + i * 16);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ypk[2 * u][i] = __builtin_bit_cast(float, w[u] << 16);
+                ypk[2 * u + 1][i] = __builtin_bit_cast(float, w[u] & 0xffff0000u);
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cg * 8 + j;
@@ -219,7 +234,8 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
             if (V == 4) {
                 const f32x4 gq = *(const f32x4*)(a.dy + e);
                 f32x4 yq = {0.f, 0.f, 0.f, 0.f};
-                if (a.act != JAF_ACT_NONE) yq = *(const f32x4*)(a.y + e);
+                if (a.yp) { yq[0] = ypk[j][0]; yq[1] = ypk[j][V > 1 ? 1 : 0]; yq[2] = ypk[j][V > 2 ? 2 : 0]; yq[3] = ypk[j][V > 3 ? 3 : 0]; }
+                else if (a.act != JAF_ACT_NONE) yq = *(const f32x4*)(a.y + e);
                 f32x4 o;
                 o[0] = dz_of(gq[0], yq[0], a.act, a.slope);
                 o[1] = dz_of(gq[1], yq[1], a.act, a.slope);
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
                 if (a.dz) *(f32x4*)(a.dz + e) = o;
                 part[j] = (o[0] + o[1]) + (o[2] + o[3]);
             } else {
-                const float o = dz_of(a.dy[e], a.act != JAF_ACT_NONE ? a.y[e] : 0.f, a.act, a.slope);
+                const float o = dz_of(a.dy[e], a.yp ? ypk[j][0] : (a.act != JAF_ACT_NONE ? a.y[e] : 0.f), a.act, a.slope);
                 v[j][0] = o;
                 if (a.dz) a.dz[e] = o;
                 part[j] = o;
@@ -267,10 +283,20 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
 
 extern "C" int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t N, int32_t G, int32_t C,
                                   int32_t H, int32_t W, int act, float slope, void* packed, float* dz, float* dbias) {
+    return jaf_conv2d_pack_dz_ex(s, dy, y, nullptr, 0, 0, N, G, C, H, W, act, slope, packed, dz, dbias);
+}
+
+extern "C" int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                                     int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                                     void* packed, float* dz, float* dbias) {
     JAF_REQUIRE(dy && packed && N >= 1 && G >= 1 && C >= 1 && H >= 1 && W >= 1);
-    JAF_REQUIRE(act == JAF_ACT_NONE || y);
+    JAF_REQUIRE(act == JAF_ACT_NONE || y || y_packed);
+    // y from the packed image: only its sign is used (ReLU / LeakyReLU), which bf16 rounding keeps
+    JAF_REQUIRE(!y_packed || ((act == JAF_ACT_LRELU || act == JAF_ACT_RELU) && y_coff >= 0 && (y_coff & 7) == 0 &&
+                              y_coff / 8 + jaf_cdiv(C, 8) <= y_ng8_tot));
     PackDzArgs a;
     a.dy = dy; a.y = y; a.out = (unsigned char*)packed; a.dz = dz; a.dbias = dbias;
+    a.yp = (const unsigned char*)y_packed; a.yp_ng8 = y_ng8_tot; a.yp_cg0 = y_coff / 8;
     const bool al = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
     if (al && W % 4 != 0 && ((long)H * W) % 4 == 0 && (long)H * W < (1L << 30)) { W = H * W; H = 1; }   // as in jaf_conv2d_pack_input
     a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;
@@ -918,7 +944,12 @@ static bool cd_desc_ok(const jaf_conv_desc* d) {
 }
 
 extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan) {
+    return jaf_conv2d_plan_packed_ex(d, lstm, 0, plan);
+}
+
+extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int flags, jaf_conv_plan* plan) {
     JAF_REQUIRE(cd_desc_ok(d) && plan);
+    const bool no_ilv = (flags & JAF_PLAN_NO_INTERLEAVE) != 0;
     if (lstm) JAF_REQUIRE((d->Cout & 3) == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1);
     const int M = d->Cout;
     const int taps = d->KH * d->KW;
@@ -955,7 +986,7 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
             }
             const int PH = (rows_span - 1) * d->stride + d->KH;
             const int PW = (TW - 1) * d->stride + d->KW;
-            const int ilv = (ci < 3 && NT > 1) ? 1 : 0;
+            const int ilv = (ci < 3 && NT > 1 && !no_ilv) ? 1 : 0;
             const int PWp = ilv ? rup_d(PW, NT) : PW;
             const int npos = PH * PWp;
             if (npos > 64 * 4 * CD_RPW) continue;
@@ -1012,7 +1043,7 @@ extern "C" int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv
     plan->TWIN = bTW;
     plan->PH = (rows_span - 1) * d->stride + d->KH;
     plan->PW = (bTW - 1) * d->stride + d->KW;
-    plan->ilv = (!linear && bNT > 1) ? 1 : 0;
+    plan->ilv = (!linear && bNT > 1 && !no_ilv) ? 1 : 0;
     plan->pf = 0;
     plan->PWp = plan->ilv ? rup_d(plan->PW, bNT) : plan->PW;
     plan->npos = plan->PH * plan->PWp;

@@ -203,3 +203,56 @@ extern "C" int jaf_grid_sample_bwd(jaf_stream_t s, const float* dout, const floa
                        dsrc, dgrid, B, C, H, W, OH, OW, padding_border, align_corners);
     return jaf_launch_status();
 }
+
+// float_estimate.forward in one pass (src/cal_flow.py:28-39 + src/flow_net.py:91): barycentric flow T of a pixel from the
+// target face-index / weight maps and the SOURCE faces (cal_bc_transform, src/nmr.py:617-659), the border-mode bilinear
+// sample of the source image at T, and (optionally) the multiplication with the target's SMPL mask that the propagater
+// applies first.  Same arithmetic, in the same order, as jaf_bc_transform -> jaf_grid_sample_fwd -> jaf_mul_bcast; the flow
+// field T [B,S,S,2] (8 B per pixel written and read back) never exists.
+__global__ void flow_warp_fwd_kernel(const float* __restrict__ src, const float* __restrict__ src_faces, const int* __restrict__ fim,
+                                     const float* __restrict__ wim, const float* __restrict__ mask, float* __restrict__ out, int B,
+                                     int C, int H, int W, int NF, int S, int mask_c, int align) {
+    const long total = (long)B * S * S;
+    const long gs = (long)gridDim.x * blockDim.x;
+    const long OS = (long)S * S;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gs) {
+        const long b = e / OS;
+        const long pix = e - b * OS;
+        const int f = fim[e];
+        float tx = -2.f, ty = -2.f;
+        if (f >= 0 && f < NF) {
+            const float* v = src_faces + (b * NF + f) * 9;
+            const float w0 = wim[e * 3], w1 = wim[e * 3 + 1], w2 = wim[e * 3 + 2];
+            tx = (v[0] * w0 + v[3] * w1) + v[6] * w2;
+            ty = ((-v[1]) * w0 + (-v[4]) * w1) + (-v[7]) * w2;
+        }
+        float ix = gs_unnormalize(tx, W, align);
+        float iy = gs_unnormalize(ty, H, align);
+        ix = fminf((float)(W - 1), fmaxf(ix, 0.f));
+        iy = fminf((float)(H - 1), fmaxf(iy, 0.f));
+        const WarpTap t = make_tap(ix, iy);
+        const bool xw = t.x0 >= 0 && t.x0 < W, xe = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+        const bool yn = t.y0 >= 0 && t.y0 < H, ys = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+        const long o = (long)t.y0 * W + t.x0;
+        for (int c = 0; c < C; ++c) {
+            const float* sp = src + (b * C + c) * (long)H * W;
+            float r = 0.f;
+            if (yn && xw) r += sp[o] * t.wnw;
+            if (yn && xe) r += sp[o + 1] * t.wne;
+            if (ys && xw) r += sp[o + W] * t.wsw;
+            if (ys && xe) r += sp[o + W + 1] * t.wse;
+            if (mask) r = r * mask[(b * mask_c + (mask_c == 1 ? 0 : c)) * OS + pix];
+            out[(b * C + c) * OS + pix] = r;
+        }
+    }
+}
+
+extern "C" int jaf_flow_warp_fwd(jaf_stream_t s, const float* src, const float* src_faces, const int32_t* fim, const float* wim,
+                                 const float* mask, float* out, int32_t B, int32_t C, int32_t H, int32_t W, int32_t NF, int32_t S,
+                                 int32_t mask_c, int align_corners) {
+    JAF_REQUIRE(src && src_faces && fim && wim && out && B >= 1 && C >= 1 && H >= 1 && W >= 1 && NF >= 1 && S >= 1);
+    JAF_REQUIRE(!mask || mask_c == 1 || mask_c == C);
+    hipLaunchKernelGGL(flow_warp_fwd_kernel, dim3(jaf_ew_grid((long)B * S * S)), dim3(256), 0, (hipStream_t)s, src, src_faces, fim, wim,
+                       mask, out, B, C, H, W, NF, S, mask_c, align_corners);
+    return jaf_launch_status();
+}

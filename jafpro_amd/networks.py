@@ -72,9 +72,9 @@ class _GroupedStateDict(nn.Module):
                 state_dict[prefix + name] = torch.cat([state_dict.pop(k) for k in keys], 0)
 
 
-def _lrelu_conv(x_srcs, w, b, stride=1, pad=1, shared=None, prepacked=None, dst=None):
+def _lrelu_conv(x_srcs, w, b, stride=1, pad=1, shared=None, prepacked=None, dst=None, keep_f32=True):
     return ops.conv2d(x_srcs, w, b, stride=stride, pad=pad, act=ACT_LRELU, slope=0.2, groups=NPARTS, shared=shared,
-                      prepacked=prepacked, dst=dst)
+                      prepacked=prepacked, dst=dst, keep_f32=keep_f32)
 
 
 class _PartEncoderMixin:
@@ -114,8 +114,11 @@ class _PartEncoderMixin:
                     # before anything writes it
                     img_out.images(0, N // tap.T).buf.zero_()
                 dst = img_out.slot(0, 0, pad_tail=not lstm_img)
+            # fp32 copy of the output only where something still reads it: a stride-2 consumer wider than 16 channels (its
+            # weight gradient runs on the fp32-input kernel) or, in the inpainter, the decoder's skip / resize inputs
+            keep = (i < 8 and ENC_S[i + 1] == 2 and c > 16) or (tap is None and i % 2 == 0)
             x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2,
-                            prepacked=img_in, dst=dst)
+                            prepacked=img_in, dst=dst, keep_f32=keep)
             if i % 2 == 0:
                 feats.append(x if tap is None else tap(i // 2, x, img_out))
             img_in = img_out

@@ -207,14 +207,14 @@ def _packed_path(d: ConvDesc) -> bool:
     return _USE_PACKED and d.precision == PREC_BF16
 
 
-def _plan(key, d: ConvDesc, lstm: int) -> ConvPlan:
+def _plan(key, d: ConvDesc, lstm: int, flags: int = 0) -> ConvPlan:
     packed = _packed_path(d)
-    k = (key, lstm, d.precision, packed)
+    k = (key, lstm, d.precision, packed, flags if packed else 0)
     pl = _PLAN_CACHE.get(k)
     if pl is None:
         pl = ConvPlan()
         if packed:
-            check(lib().jaf_conv2d_plan_packed(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan_packed")
+            check(lib().jaf_conv2d_plan_packed_ex(ctypes.byref(d), lstm, flags, ctypes.byref(pl)), "jaf_conv2d_plan_packed_ex")
         else:
             check(lib().jaf_conv2d_plan(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan")
         _PLAN_CACHE[k] = pl
@@ -475,15 +475,21 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
               bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
               xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
-              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None):
+              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False):
+    skip_f32 = skip_f32 and dst is not None and ln_stats is None
     if out is None:
         out_ctot = G * Cout
-        out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
+        if skip_f32:
+            # nothing reads this tensor in fp32: it exists only as the autograd edge (shape / dtype / device), its one
+            # element is never written.  Any op that is not packed-aware rejects it (not contiguous).
+            out = torch.empty_strided((N, out_ctot, OH, OW), (0, 0, 0, 0), device=srcs[0].device, dtype=torch.float32)
+        else:
+            out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
     key = (N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, tuple(specs), w_cin_tot, w_cin_off,
            out_ctot, out_coff, act, float(slope))
     d = _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, specs, w_cin_tot, w_cin_off,
                    out_ctot, out_coff, act, slope)
-    pl = _plan(key, d, 0)
+    pl = _plan(key, d, 0, 1 if skip_f32 else 0)           # JAF_PLAN_NO_INTERLEAVE for packed-only outputs
     wpk = _packed(weight, w_rows_tot, d, pl, mode, key[:17])
     if _packed_path(d):
         if prepacked is not None:           # the producers already wrote this layer's input image
@@ -495,14 +501,15 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
             if dst.img_off + N > dst.image.N:
                 raise RuntimeError("conv2d destination: images %d..%d outside the packed image (%d)" % (dst.img_off, dst.img_off + N, dst.image.N))
-        io = _io_struct(prepacked, dst)
+        io = _io_struct(prepacked, dst, skip_f32)
         sums = None
         if ln_stats is not None:
             ln_stats.filled = False
             if act == ACT_NONE and G == 1:
                 sums = ln_stats.buffer(N, out.device)
         ev = _PROF.begin() if _PROF is not None else None
-        check(lib().jaf_conv2d_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias), _p(out),
+        check(lib().jaf_conv2d_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
+                                             None if skip_f32 else _p(out),
                                              _p(sums), ln_stats.slots if sums is not None else 1,
                                              ctypes.byref(io) if io is not None else None),
               "jaf_conv2d_fwd_packed_io")
@@ -533,7 +540,7 @@ def _grad_inplace(p: torch.Tensor) -> bool:
 
 class _ConvMeta:
     __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
-                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst")
+                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst", "keep_f32")
 
 
 def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
@@ -570,7 +577,11 @@ class _ConvFn(Function):
         use_img = packed_active()
         y, xp = _conv_raw(srcs, m.specs, weight, m.Cout, PACK_FWD, bias, m.N, m.G, m.Cin, m.Cout, m.H, m.W, m.OH, m.OW,
                           m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True,
-                          ln_stats=m.ln_stats, prepacked=m.prepacked if use_img else None, dst=m.dst if use_img else None)
+                          ln_stats=m.ln_stats, prepacked=m.prepacked if use_img else None, dst=m.dst if use_img else None,
+                          skip_f32=use_img and not m.keep_f32 and m.dst is not None and m.dst.coff % 8 == 0
+                          and m.act in (ACT_LRELU, ACT_RELU))
+        # y only as bf16 inside the consumer's image: the activation backward reads it from there
+        ctx.y_img = (m.dst.image, m.dst.coff, m.dst.img_off) if (y.stride(0) == 0 and y.numel() > 1) else None
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
         ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.xp_ng8 = m.prepacked.ng8 if (use_img and m.prepacked is not None) else 0
@@ -612,9 +623,18 @@ class _ConvFn(Function):
                 db_done = True
             ng8 = (m.Cout + 7) // 8
             dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16, device=dy.device, dtype=torch.uint8)
-            with _hbm("conv_pack_dz_kernel", dy.numel() * (4.0 + (4.0 if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
+            yimg = getattr(ctx, "y_img", None)
+            with _hbm("conv_pack_dz_kernel", dy.numel() * (4.0 + ((2.0 if yimg else 4.0) if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
                 per = dzp.numel() // m.N
                 for n0, n1 in _n_chunks(m.N, m.G * ng8):
+                    if yimg is not None:
+                        img, ycoff, yoff = yimg
+                        yper = img.G * img.ng8 * img.H * img.W * 16
+                        check(L.jaf_conv2d_pack_dz_ex(_s(), _p(dy[n0:n1]), None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
+                                                      img.ng8, ycoff, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
+                                                      _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
+                                                      _p(dbt)), "jaf_conv2d_pack_dz_ex")
+                        continue
                     check(L.jaf_conv2d_pack_dz(_s(), _p(dy[n0:n1]), _p(y[n0:n1]) if m.act != ACT_NONE else None, n1 - n0, m.G, m.Cout,
                                                m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
                                                _p(dz[n0:n1]) if dz is not None else None, _p(dbt)), "jaf_conv2d_pack_dz")
@@ -667,19 +687,23 @@ class _ConvFn(Function):
 
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0,
            act: int = ACT_NONE, slope: float = 0.0, groups: int = 1, shared: Optional[Sequence[bool]] = None,
-           ln_stats: Optional[LNStats] = None, prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None):
+           ln_stats: Optional[LNStats] = None, prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None,
+           keep_f32: bool = True):
     """Grouped convolution over the channel concatenation of `srcs` with fused bias + activation.
     `ln_stats`: see LNStats (filled only on the packed bf16 path with act NONE and groups 1).
     `prepacked`: the packed bf16 image of exactly this concatenation, already written by the producers of `srcs`
     (then `srcs` are only the autograd edges); `dst`: the consumer's image slot the outputs are also written to.
-    Both are honoured on the packed bf16 path only (see PackedImage).
+    keep_f32=False with a `dst` (ReLU / LeakyReLU layers): every consumer reads the packed image, so the fp32 result
+    is not written at all and the returned tensor is a storage-less autograd handle.  All three are honoured on the packed
+    bf16 path only (see PackedImage).
 
     srcs[i]: [N, groups*c_i, H, W] (or [N, c_i, H, W] when shared[i]: every group reads the same
     channels).  weight: [groups*Cout, sum(c_i), KH, KW] or [groups, Cout, sum(c_i), KH, KW].
     """
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
-    srcs = [_chk(t, "conv2d source") for t in srcs]
+    if not (prepacked is not None and packed_active()):       # with their packed image given, the sources are only autograd edges
+        srcs = [_chk(t, "conv2d source") for t in srcs]
     _chk(weight, "conv2d weight")
     if bias is not None:
         _chk(bias, "conv2d bias")
@@ -709,7 +733,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     m.specs, m.N, m.Cin, m.Cout, m.H, m.W = specs, int(N), Cin, Cout, int(H), int(W)
     m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
     m.ln_stats = ln_stats
-    m.prepacked, m.dst = prepacked, dst
+    m.prepacked, m.dst, m.keep_f32 = prepacked, dst, keep_f32
     return _ConvFn.apply(weight, bias, m, *srcs)
 
 
@@ -831,7 +855,7 @@ class _ConvLSTMFn(Function):
         if dh_out is None:          # only c_T was used downstream
             dh_out = torch.zeros_like(hs) if ctx.need_all else torch.zeros_like(hs[0])
         dh_out = _c(dh_out)
-        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         bias = ctx.bias_ref
         w_inplace, b_inplace = _grad_inplace(weight), _grad_inplace(bias)
         dw = weight.grad if w_inplace else torch.empty_like(weight)
@@ -921,7 +945,9 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
     """x: [T, N, G*C, H, W] -> (h_T [N, G*C, H, W] or all h_t, c_T).  `state` = (h0, c0), default the zero
     state of src/convLSTM.py:58-63,119-120; gate order i,f,o,g (:46).  Differentiable w.r.t. x, the parameters,
     the initial state, and through both h and c_T (T = 1 with a state is ConvLSTMCell.forward, :41-56)."""
-    _chk(x, "convlstm x"); _chk(weight, "convlstm weight"); _chk(bias, "convlstm bias")
+    if not (seq_image is not None and packed_active() and state is None):     # x is then only the autograd edge
+        _chk(x, "convlstm x")
+    _chk(weight, "convlstm weight"); _chk(bias, "convlstm bias")
     h0 = c0 = None
     if state is not None:
         h0, c0 = _chk(state[0], "convlstm h0"), _chk(state[1], "convlstm c0")
@@ -1524,6 +1550,21 @@ def rasterize_fim_wim(faces, image_size: int, near: float = 0.1, far: float = 10
     check(L.jaf_rasterize_fim_wim(_s(), _p(faces), _p(fim), _p(wim), _p(ws), B, NF, image_size, near, far),
           "jaf_rasterize_fim_wim")
     return fim, wim
+
+
+def flow_warp(src, src_faces, fim, wim, mask=None, align_corners: bool = False):
+    """grid_sample(src, cal_bc_transform(src_faces, fim, wim), border) [* mask] in one kernel, forward only
+    (src/cal_flow.py:28-39, src/flow_net.py:91); bit-identical to bc_transform -> grid_sample -> mul_bcast."""
+    _chk(src, "flow_warp src"); _chk(src_faces, "src_faces"); _chk(fim, "fim", torch.int32); _chk(wim, "wim")
+    if mask is not None:
+        _chk(mask, "mask")
+    B, C, H, W = src.shape
+    S, NF = fim.shape[1], src_faces.shape[1]
+    out = torch.empty((B, C, S, S), device=src.device, dtype=torch.float32)
+    with _hbm("flow_warp_fwd_kernel", 4.0 * B * (C * H * W + 4 * S * S + C * S * S + (mask.shape[1] * S * S if mask is not None else 0))):
+        check(lib().jaf_flow_warp_fwd(_s(), _p(src), _p(src_faces), _p(fim), _p(wim), _p(mask), _p(out), B, C, H, W, NF, S,
+                                      mask.shape[1] if mask is not None else 1, 1 if align_corners else 0), "jaf_flow_warp_fwd")
+    return out
 
 
 class _BcTransformFn(Function):

@@ -171,3 +171,23 @@ def test_smpl_renderer_silhouette_and_depth():
     d = r2.render_depth(torch.from_numpy(cam).cuda(), torch.from_numpy(v).cuda())
     dref = RA.rasterize_depth(O.project_faces(torch.from_numpy(v), torch.from_numpy(cam), fidx), 64)
     assert torch.equal(d.cpu(), dref)
+
+
+def test_fused_flow_warp_is_bit_identical():
+    """jaf_flow_warp_fwd == jaf_bc_transform -> jaf_grid_sample_fwd(border) -> jaf_mul_bcast, bit for bit, both align modes."""
+    from oracle import raster_oracle
+    from jafpro_amd import synth
+    ops = _ops()
+    B, S = 2, 128
+    _, _, _, fs = _mesh_faces(B, 96)
+    _, _, _, ft = _mesh_faces(B, 97)
+    fim, wim = raster_oracle.rasterize_fim_wim(ft.numpy(), S)
+    fim, wim, fs = torch.from_numpy(fim).cuda(), torch.from_numpy(wim).cuda(), fs.cuda()
+    img = torch.from_numpy(synth.uniform(98, "img", (B, 3, 96, 80))).cuda()
+    m3 = torch.from_numpy(synth.uniform(98, "m3", (B, 3, S, S), 0, 1)).cuda()
+    for ac in (False, True):
+        T = ops.bc_transform(fs, fim, wim)
+        ref = ops.grid_sample(img, T, True, ac)
+        assert torch.equal(ops.flow_warp(img, fs, fim, wim, None, ac), ref)
+        assert torch.equal(ops.flow_warp(img, fs, fim, wim, m3, ac), ops.mul_bcast(ref, m3))
+        assert torch.equal(ops.flow_warp(img, fs, fim, wim, m3[:, :1].contiguous(), ac), ops.mul_bcast(ref, m3[:, :1].contiguous()))
