@@ -211,7 +211,7 @@ def main():
         "metric": "train-step frames/sec, %dx%d 30-frame clips, stage-4" % (args.size, args.size),
         "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "median_ms_per_step": float(np.median(step_ms)),
-        "step_ms_min_max": [float(np.min(step_ms)), float(np.max(step_ms))],
+        "step_ms": [round(float(t), 2) for t in step_ms],
         "frames_per_s_at_median": world * B / (float(np.median(step_ms)) * 1e-3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",

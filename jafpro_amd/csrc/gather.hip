@@ -221,6 +221,9 @@ __global__ void flow_warp_fwd_kernel(const float* __restrict__ src, const float*
         const int f = fim[e];
         float tx = -2.f, ty = -2.f;
         if (f >= 0 && f < NF) {
+            // products then sums, no fused multiply-add: the expression tree of bc_transform_kernel (raster.hip is built
+            // with -ffp-contract=off) and of the reference's `(pts * w).sum(1)`, so the sample position is the same to the bit
+#pragma clang fp contract(off)
             const float* v = src_faces + (b * NF + f) * 9;
             const float w0 = wim[e * 3], w1 = wim[e * 3 + 1], w2 = wim[e * 3 + 2];
             tx = (v[0] * w0 + v[3] * w1) + v[6] * w2;
