@@ -17,7 +17,11 @@
 //   ds_read_b64_tr_b16 (cdna_hip_programming.md T10), whose four row addresses per 16-lane group
 //   are free -- so every tap is just a shifted row address and no im2col copy exists anywhere;
 // * accumulators (MTW x 9 tiles) leave through an LDS transpose so that the fp32 atomics that
-//   combine the pixel splits run along the memory order of dW (co rows of [ci][tap]).
+//   combine the pixel splits run along the memory order of dW (co rows of [ci][tap]);
+// * SPLIT (JAF_PREC_BF16X3, the parity-grade mode): both operands are staged as a bf16 head and a bf16 residual
+//   (v = hi + lo up to 2^-17 relative) in two LDS images each, and every product is three MFMAs
+//   dz_hi*x_hi + dz_lo*x_hi + dz_hi*x_lo -- fp32-grade weight gradients at a third of the bf16 matrix-core rate instead
+//   of the 33 TFLOP/s of the fp32 MFMA kernel (wgrad.hip) that mode used before.
 #include "conv_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -48,6 +52,7 @@ struct WgBArgs {
     int PH, PW, PWp, npos;   // PWp: row pitch in positions, multiple of 8 (row = whole 256-byte lines)
     int xplane;
     int off_dz, off_cptr;
+    int lo_x, lo_dz;         // SPLIT: byte distance from the head image to the residual image (patch / dz)
     int nitems_x;
     int vec4;
     float inv_pw, inv_npos;
@@ -59,8 +64,16 @@ __device__ __forceinline__ unsigned int wb_pack2(float a, float b) {
     return __builtin_bit_cast(unsigned int, r);
 }
 
-template <int MTW>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBArgs a) {
+// residual of the bf16 head: v - float(bf16(v)), itself rounded to bf16 by wb_pack2
+__device__ __forceinline__ unsigned int wb_pack2_lo(float a, float b) {
+    f32x2 v = {a, b};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    return wb_pack2(a - hf[0], b - hf[1]);
+}
+
+template <int MTW, bool SPLIT>
+__global__ __launch_bounds__(256, SPLIT ? 1 : 2) void conv_wgrad_bf16_kernel(const WgBArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -195,6 +208,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBArgs a
                 w[2] = wb_pack2(v1[it][0], v1[it][1]);
                 w[3] = wb_pack2(v1[it][2], v1[it][3]);
                 *(u32x4*)(s_dz + ldso[it]) = w;
+                if (SPLIT) {
+                    u32x4 l;
+                    l[0] = wb_pack2_lo(v0[it][0], v0[it][1]);
+                    l[1] = wb_pack2_lo(v0[it][2], v0[it][3]);
+                    l[2] = wb_pack2_lo(v1[it][0], v1[it][1]);
+                    l[3] = wb_pack2_lo(v1[it][2], v1[it][3]);
+                    *(u32x4*)(s_dz + a.lo_dz + ldso[it]) = l;
+                }
             }
         }
 
@@ -233,6 +254,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBArgs a
                     w[2] = wb_pack2(v[it][4], v[it][5]);
                     w[3] = wb_pack2(v[it][6], v[it][7]);
                     *(u32x4*)(s_x + ldso[it]) = w;
+                    if (SPLIT) {
+                        u32x4 l;
+                        l[0] = wb_pack2_lo(v[it][0], v[it][1]);
+                        l[1] = wb_pack2_lo(v[it][2], v[it][3]);
+                        l[2] = wb_pack2_lo(v[it][4], v[it][5]);
+                        l[3] = wb_pack2_lo(v[it][6], v[it][7]);
+                        *(u32x4*)(s_x + a.lo_x + ldso[it]) = l;
+                    }
                 }
             }
         }
@@ -240,10 +269,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBArgs a
 
         // ---- MFMA: this wave's k-steps (32 pixels = 2 tile rows each) ----
         for (int ks = wk; ks < 4; ks += WK) {
-            bf16x8 af[MTW];
+            bf16x8 af[MTW], afl[MTW];
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+            for (int mt = 0; mt < MTW; ++mt) {
                 af[mt] = *(const bf16x8*)(s_dz + (mt * 16 + li) * WB_DZP + ks * 64 + q * 16);
+                if (SPLIT) afl[mt] = *(const bf16x8*)(s_dz + a.lo_dz + (mt * 16 + li) * WB_DZP + ks * 64 + q * 16);
+            }
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int rowoff = ((2 * ks * s + ky) * PWp) * 32;
@@ -255,9 +286,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_bf16_kernel(const WgBArgs a
                     const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a1));
                     const s16x8 bb = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, bb);
+                    bf16x8 bfl;
+                    if (SPLIT) {
+                        const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a.lo_x + a0));
+                        const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a.lo_x + a1));
+                        bfl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
-                        acc[mt][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][ky * 3 + kx], 0, 0, 0);
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        f32x4 c = acc[mt][ky * 3 + kx];
+                        if (SPLIT) {        // small terms first
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[mt], bf, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bfl, c, 0, 0, 0);
+                        }
+                        acc[mt][ky * 3 + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, c, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -323,9 +366,13 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
     a.PW = (WB_TW - 1) * d->stride + 3;
     a.npos = a.PH * a.PW;
     a.PWp = rup_i(a.PW, 8);                              // the bit-7 swizzle stays inside a row
+    const bool split = d->precision == JAF_PREC_BF16X3;
+    const int nimg = split ? 2 : 1;
     a.xplane = a.PH * a.PWp * 32;
-    a.off_dz = a.WC * a.xplane;
-    a.off_cptr = a.off_dz + 16 * MTW * WB_DZP;
+    a.lo_x = a.WC * a.xplane;
+    a.lo_dz = 16 * MTW * WB_DZP;
+    a.off_dz = nimg * a.WC * a.xplane;
+    a.off_cptr = a.off_dz + nimg * 16 * MTW * WB_DZP;
     a.nitems_x = a.npos * 2 * a.WC;
     a.vec4 = (d->OW % 4 == 0) ? 1 : 0;
     a.inv_pw = 1.0f / (float)a.PW;
@@ -340,9 +387,9 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
     a.nsplit = (int)nsplit;
     const long nblk = outblocks * nsplit;
     JAF_REQUIRE(nblk <= 0x7fffffffL);
-#define JAF_WGB(MT_)                                                                                   \
+#define JAF_WGB(MT_, SP_)                                                                              \
     do {                                                                                               \
-        auto k = conv_wgrad_bf16_kernel<MT_>;                                                          \
+        auto k = conv_wgrad_bf16_kernel<MT_, SP_>;                                                     \
         static int optin[JAF_MAX_DEVICES];                                                             \
         if (lds > 48 * 1024) {                                                                         \
             const int e = jaf_lds_optin((const void*)k, optin);                                        \
@@ -350,11 +397,17 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
         }                                                                                              \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)
-    switch (MTW) {
-        case 1: JAF_WGB(1); break;
-        case 2: JAF_WGB(2); break;
-        case 3: JAF_WGB(3); break;
-        default: JAF_WGB(4); break;
+    if (split) switch (MTW) {
+        case 1: JAF_WGB(1, true); break;
+        case 2: JAF_WGB(2, true); break;
+        case 3: JAF_WGB(3, true); break;
+        default: JAF_WGB(4, true); break;
+    }
+    else switch (MTW) {
+        case 1: JAF_WGB(1, false); break;
+        case 2: JAF_WGB(2, false); break;
+        case 3: JAF_WGB(3, false); break;
+        default: JAF_WGB(4, false); break;
     }
 #undef JAF_WGB
     return jaf_launch_status();

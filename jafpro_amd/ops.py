@@ -123,7 +123,7 @@ def _wgrad_dma_name(Cout: int, KS: int) -> str:
 
 
 def _wgrad_name(KH, KW) -> str:
-    return "conv_wgrad_bf16_kernel" if (_PRECISION == PREC_BF16 and KH == 3 and KW == 3) else "conv_wgrad_kernel"
+    return "conv_wgrad_bf16_kernel" if (_PRECISION in (PREC_BF16, PREC_BF16X3) and KH == 3 and KW == 3) else "conv_wgrad_kernel"
 
 
 def _kname(lstm: bool, KH, KW, pl) -> str:
