@@ -357,6 +357,11 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
         if (pad < bestPad) { bestPad = pad; MTW = mt; }
     }
     a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
+    {   // the split mode keeps two images of everything in LDS: narrower input-channel blocks where 160 KB would not hold them
+        const int ph = (WB_TH - 1) * d->stride + 3, pwp = rup_i((WB_TW - 1) * d->stride + 3, 8);
+        const int nimg_ = d->precision == JAF_PREC_BF16X3 ? 2 : 1;
+        while (a.WC > 1 && nimg_ * (a.WC * ph * pwp * 32 + 16 * MTW * WB_DZP) + 16 * a.WC * 12 + 16 > 160 * 1024) a.WC >>= 1;
+    }
     a.WK = 4 / a.WC;
     a.coblocks = jaf_cdiv(d->Cout, 16 * MTW);
     a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);
