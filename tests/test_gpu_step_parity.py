@@ -118,6 +118,27 @@ def test_train_step_bf16_gradients():
         assert bn_buffers_err(mods[n], orc.sd[n]) <= 5e-2, n
 
 
+def test_train_step_bf16x3_is_parity_grade():
+    """The split-bf16 mode (three bf16 MFMAs per product, forward, data AND weight gradients on the matrix cores) held to
+    the fp32 bars of the full step: frame <= 1e-3 L-inf, losses 2e-3, per-module gradients at the B=1 bars above."""
+    from jafpro_amd import ops
+    M, tr, orc, batch, dbatch, mods = build(1, seed=330)
+    prev = ops.set_precision("bf16x3")
+    try:
+        out = tr.train_step(dbatch)
+    finally:
+        ops.set_precision(prev)
+    ref = orc.train_step(host(batch))
+    err = (out["final_output"].cpu() - ref["final_output"]).abs().max().item()
+    print("bf16x3 frame max|diff| %.3e" % err)
+    assert err <= 1e-3
+    check_losses(out, ref, 2e-3, "bf16x3")
+    for n in TRAINABLE:
+        rel = module_grad_rel(mods[n], orc.sd[n])
+        print("bf16x3 grad rel-L2 %-8s %.3e (bar %.0e)" % (n, rel, SUBSET_GRAD_BARS[n]))
+        assert rel <= SUBSET_GRAD_BARS[n], (n, rel)
+
+
 def test_bf16_second_step_uses_refreshed_weight_images():
     """Two bf16 steps; the packed weight images were re-made IN PLACE on a side stream after each Adam
     (ops.refresh_packed_weights).  A forward that uses those cached images must equal, bit for bit, a forward that
