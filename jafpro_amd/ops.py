@@ -961,7 +961,7 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
 # --------------------------------------------------------------------------------------------
 class _LayerNormLReLUFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats], dst=None):
+    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats], dst=None, keep_f32=True):
         N, C, H, W = x.shape
         L = lib()
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
@@ -971,14 +971,18 @@ class _LayerNormLReLUFn(Function):
         else:
             ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
             check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")
-        y = torch.empty_like(x)
         if dst is not None and packed_active():
             _check_image(dst.image, N, 1, 0, H, W, "layernorm destination")
             if dst.img_off or dst.coff % 8 or dst.coff + C > dst.image.ng8 * 8:
                 raise RuntimeError("layernorm destination: slot does not fit")
-            check(L.jaf_layernorm_lrelu_fwd_packed(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), _p(dst.image.buf),
+            # keep_f32=False: only the convolution behind `dst` reads the result -> no fp32 tensor is written, the
+            # returned tensor is a storage-less autograd handle (the backward pass needs x and the statistics, not y)
+            y = (torch.empty_like(x) if keep_f32 else
+                 torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=torch.float32))
+            check(L.jaf_layernorm_lrelu_fwd_packed(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y) if keep_f32 else None, _p(dst.image.buf),
                                                    dst.image.ng8, dst.coff, N, C, H * W, slope), "jaf_layernorm_lrelu_fwd_packed")
         else:
+            y = torch.empty_like(x)
             check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
                   "jaf_layernorm_lrelu_fwd")
         ctx.eps, ctx.slope = eps, slope
@@ -999,14 +1003,15 @@ class _LayerNormLReLUFn(Function):
         check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
                                             _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
               "jaf_layernorm_lrelu_bwd")
-        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None
+        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None, None
 
 
 def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01, pre: Optional[LNStats] = None,
-                    dst: Optional[PackedDst] = None):
-    """`dst`: the consumer convolution's packed image slot (packed bf16 path only, see PackedImage)."""
+                    dst: Optional[PackedDst] = None, keep_f32: bool = True):
+    """`dst`: the consumer convolution's packed image slot; keep_f32=False: that convolution is the only reader, so no
+    fp32 result is written (both on the packed bf16 path only, see PackedImage)."""
     _chk(x, "layernorm x"); _chk(gamma, "gamma"); _chk(beta, "beta")
-    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre, dst)
+    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre, dst, keep_f32)
 
 
 class _BatchNormActFn(Function):

@@ -101,6 +101,9 @@ _FLAG_CACHE = {}
 
 
 WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradients on a second side stream
+# where the next clip's preparation is issued: "bwd" = right before the generator loss backward (north star), "d" = at
+# the start of the discriminator phase (experiment: that phase is a chain of 5-40 us launches that leaves the chip idle)
+PREP_AT = os.environ.get("JAF_PREP_AT", "bwd")
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -314,6 +317,8 @@ class Stage4Trainer:
         else:
             raise RuntimeError("train_step supports image_size 256 (reference) and 512 (config 5), got %d" % M.image_size)
         target_d, src0_d = dview(target), dview(src0)
+        if next_batch is not None and PREP_AT == "d":
+            self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True)
         # ---- face discriminator, one update (:362-374)
         if face_pred is not None:
             F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
@@ -341,7 +346,7 @@ class Stage4Trainer:
         F_errG = (ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0) if face_pred is not None
                   else torch.zeros(1, device=final.device))
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
-        if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
+        if next_batch is not None and PREP_AT != "d":      # overlaps with the VGG + GAN loss backward below
             self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True)
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
