@@ -127,6 +127,13 @@ int jaf_conv2d_fwd_direct(jaf_stream_t s, const jaf_conv_desc* d,
 int64_t jaf_conv2d_packed_input_bytes(const jaf_conv_desc* d);
 int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
                           const float* src2, void* packed);
+/* jaf_conv2d_pack_input with bilinear up-sampling fused in: source i with src_h[i] > 0 is given at its low resolution
+ * [N][ctot][src_h[i]][src_w[i]] and sampled at the layer's H x W on the fly (ATen upsample_bilinear2d rules,
+ * align_corners[i]); src_h[i] == 0: a plain source.  The decoders' `cat[up(x), skip]` (src/networks.py:896-909) and the
+ * CRN's `cat[label, pool, up(net)]` (src/crn_model.py:276-299) then never exist at full resolution in fp32. */
+int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
+                                  const float* src2, const int32_t* src_h, const int32_t* src_w,
+                                  const int32_t* align_corners, void* packed);
 /* Backward-pass companion of jaf_conv2d_pack_input for a conv output gradient dy [N, G*C, H, W]:
  * dz = dy * act'(y) (y = the activation output, nullable for JAF_ACT_NONE), written as the packed bf16
  * image; dbias[G*C] += per-channel sum of dz (nullable); dz (nullable) receives the fp32 dz for the

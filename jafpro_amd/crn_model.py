@@ -105,7 +105,7 @@ class CRN_smaller(nn.Module):
         label = label.contiguous()
         pool = lambda t: ops.avg_pool(t, 3, 2, 1)
         down = lambda s: ops.resize(label, (s, s), align_corners=True)
-        up = lambda t, s: ops.resize(t, (s, s), align_corners=True)
+        up = lambda t, s: ops.resize(t, (s, s), align_corners=True, lazy=True)      # only ever a source of the next decoder conv
         pool1 = pool(self.conv1_encoder(label))
         pool2 = pool(self.conv2_encoder(pool1))
         pool3 = pool(self.conv3_encoder(pool2))

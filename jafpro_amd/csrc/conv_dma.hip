@@ -168,6 +168,113 @@ extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, con
     return jaf_launch_status();
 }
 
+// Packing with bilinear up-sampling fused in: a source flagged lazy is given at its LOW resolution [N][ctot][sh][sw] and
+// is sampled at the layer's H x W on the fly (ATen upsample_bilinear2d index rules, as resample.hip) -- the up-sampled
+// fp32 tensor of the decoders (`cat[up(x), skip]`, src/networks.py:896-909; the CRN's `cat[label, pool, up(net)]`,
+// src/crn_model.py:276-299) is neither written nor read back.  One lane = one pixel x 8 channels.
+struct PackLazyArgs {
+    PackInArgs b;
+    int lazy[3], sh[3], sw[3], align[3];
+    float sy[3], sx[3];
+};
+
+__device__ __forceinline__ void cd_resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
+    float src = align ? scale * (float)o : fmaxf(scale * ((float)o + 0.5f) - 0.5f, 0.f);
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void conv_pack_input_lazy_kernel(const PackLazyArgs a) {
+    const jaf_conv_desc& d = a.b.d;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= d.W || y >= d.H) return;
+    int z = blockIdx.z;
+    const int cg = z % a.b.ngroups8;
+    z /= a.b.ngroups8;
+    const int g = z % d.G;
+    const int n = z / d.G;
+    const int c0 = d.src_c[0];
+    const int c01 = c0 + (d.nsrc > 1 ? d.src_c[1] : 0);
+    const long HW = (long)d.H * d.W;
+    int o00[3], o01[3], o10[3], o11[3];
+    float ly[3], lx[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        o00[s] = o01[s] = o10[s] = o11[s] = 0;
+        ly[s] = lx[s] = 0.f;
+        if (s < d.nsrc && a.lazy[s]) {
+            int y0, y1, x0, x1;
+            cd_resize_src(y, a.sy[s], a.sh[s], a.align[s], y0, y1, ly[s]);
+            cd_resize_src(x, a.sx[s], a.sw[s], a.align[s], x0, x1, lx[s]);
+            o00[s] = y0 * a.sw[s] + x0; o01[s] = y0 * a.sw[s] + x1;
+            o10[s] = y1 * a.sw[s] + x0; o11[s] = y1 * a.sw[s] + x1;
+        }
+    }
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        v[j] = 0.f;
+        if (c < d.Cin) {
+            const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
+            const int cl = (s == 0) ? c : ((s == 1) ? c - c0 : c - c01);
+            const float* sp = (s == 0) ? a.b.src[0] : ((s == 1) ? a.b.src[1] : a.b.src[2]);
+            const long ch = (long)n * d.src_ctot[s] + d.src_coff[s] + g * d.src_gstride[s] + cl;
+            if (a.lazy[s]) {
+                const float* p = sp + ch * (long)(a.sh[s] * a.sw[s]);
+                const float hy = 1.f - ly[s], hx = 1.f - lx[s];
+                v[j] = hy * (hx * p[o00[s]] + lx[s] * p[o01[s]]) + ly[s] * (hx * p[o10[s]] + lx[s] * p[o11[s]]);
+            } else {
+                v[j] = sp[ch * HW + (long)y * d.W + x];
+            }
+        }
+    }
+    u32x4 w;
+    w[0] = cd_pack2(v[0], v[1]);
+    w[1] = cd_pack2(v[2], v[3]);
+    w[2] = cd_pack2(v[4], v[5]);
+    w[3] = cd_pack2(v[6], v[7]);
+    *(u32x4*)(a.b.out + ((((long)n * d.G + g) * a.b.ngroups8 + cg) * HW + (long)y * d.W + x) * 16) = w;
+}
+
+extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
+                                             const float* src2, const int32_t* src_h, const int32_t* src_w,
+                                             const int32_t* align_corners, void* packed) {
+    JAF_REQUIRE(pack_desc_ok(d) && src0 && packed && src_h && src_w && align_corners);
+    JAF_REQUIRE(d->nsrc < 2 || src1);
+    JAF_REQUIRE(d->nsrc < 3 || src2);
+    PackLazyArgs a;
+    a.b.src[0] = src0; a.b.src[1] = src1; a.b.src[2] = src2;
+    a.b.out = (unsigned char*)packed;
+    a.b.d = *d;
+    a.b.ngroups8 = jaf_cdiv(d->Cin, 8);
+    for (int i = 0; i < 3; ++i) {
+        a.lazy[i] = (i < d->nsrc && src_h[i] > 0) ? 1 : 0;
+        a.sh[i] = a.lazy[i] ? src_h[i] : 1;
+        a.sw[i] = a.lazy[i] ? src_w[i] : 1;
+        a.align[i] = a.lazy[i] ? (align_corners[i] ? 1 : 0) : 0;
+        JAF_REQUIRE(!a.lazy[i] || (src_w[i] > 0 && (long)src_h[i] * src_w[i] < (1L << 30)));
+        if (a.align[i]) {
+            a.sy[i] = d->H > 1 ? (float)(a.sh[i] - 1) / (float)(d->H - 1) : 0.f;
+            a.sx[i] = d->W > 1 ? (float)(a.sw[i] - 1) / (float)(d->W - 1) : 0.f;
+        } else {
+            a.sy[i] = (float)a.sh[i] / (float)d->H;
+            a.sx[i] = (float)a.sw[i] / (float)d->W;
+        }
+    }
+    const long nz = (long)d->N * d->G * a.b.ngroups8;
+    if (nz > 65535 || d->H > 65535) return JAF_EUNSUPPORTED;
+    int tx = 64;
+    while (tx > 8 && (tx >> 1) >= d->W) tx >>= 1;
+    const int ty = 256 / tx;
+    hipLaunchKernelGGL(conv_pack_input_lazy_kernel, dim3(jaf_cdiv(d->W, tx), jaf_cdiv(d->H, ty), (unsigned)nz), dim3(tx, ty), 0,
+                       (hipStream_t)s, a);
+    return jaf_launch_status();
+}
+
 // ---------------------------------------------------------------------------------------------
 // dz packing for the backward pass: dz = dy * act'(y) (activation backward), its packed bf16 image for
 // the data / weight gradient kernels, the bias gradient (per-channel sum of dz) and -- only when a

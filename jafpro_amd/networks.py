@@ -186,7 +186,7 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
         x = hs[4]
         for i in range(4):            # Upsampler_SE: bilinear(AC=True) to a fixed size, cat skip, conv+lrelu
             skip = hs[3 - i]
-            up = ops.resize(x, (skip.shape[2], skip.shape[3]), align_corners=True)
+            up = ops.resize(x, (skip.shape[2], skip.shape[3]), align_corners=True, lazy=True)    # sampled while dec packs its input
             x = _lrelu_conv([up, skip], getattr(self, "dec%d_w" % (i + 1)), getattr(self, "dec%d_b" % (i + 1)))
         return ops.conv2d(x, self.out_w, self.out_b, stride=1, pad=1, act=ACT_NONE, groups=NPARTS)
 
@@ -268,12 +268,12 @@ class UNet_inpainter(_GroupedStateDict, _PartEncoderMixin):
         # dec1 input = up(cat[x9, global_embed]) ++ x7 ; bilinear is per channel so the cat is never built
         skip = feats[3]
         size = (skip.shape[2], skip.shape[3])
-        up9 = ops.resize(feats[4], size, align_corners=True)
-        upe = ops.resize(embed, size, align_corners=True)
+        up9 = ops.resize(feats[4], size, align_corners=True, lazy=True)
+        upe = ops.resize(embed, size, align_corners=True, lazy=True)
         x = _lrelu_conv([up9, upe, skip], self.dec1_w, self.dec1_b, shared=[False, True, False])
         for i in range(1, 4):
             skip = feats[3 - i]
-            up = ops.resize(x, (skip.shape[2], skip.shape[3]), align_corners=True)
+            up = ops.resize(x, (skip.shape[2], skip.shape[3]), align_corners=True, lazy=True)
             x = _lrelu_conv([up, skip], getattr(self, "dec%d_w" % (i + 1)), getattr(self, "dec%d_b" % (i + 1)))
         return ops.conv2d(x, self.out_w, self.out_b, stride=1, pad=1, act=ACT_NONE, groups=NPARTS)
 

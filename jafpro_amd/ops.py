@@ -221,7 +221,7 @@ def _plan(key, d: ConvDesc, lstm: int, flags: int = 0) -> ConvPlan:
     return pl
 
 
-def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc) -> torch.Tensor:
+def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc, lazy=None) -> torch.Tensor:
     """bf16 [N][G][ceil(Cin/8)][H][W][8] image of a descriptor's (concatenated, grouped) input: converted
     once, consumed by the forward conv and the weight gradient (or by dgrad and wgrad for a dz)."""
     nbytes = int(lib().jaf_conv2d_packed_input_bytes(ctypes.byref(d)))
@@ -230,6 +230,28 @@ def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc) -> torch.Tensor:
     xp = torch.empty(nbytes, device=srcs[0].device, dtype=torch.uint8)
     ng8 = (d.Cin + 7) // 8
     chunks = _n_chunks(d.N, d.G * ng8)
+    if lazy is None:
+        lazy = [getattr(t, "_jaf_lazy", None) for t in srcs]
+    if any(l is not None for l in lazy):
+        # up-sampled sources given at their low resolution: sampled while packing (jaf_conv2d_pack_input_resized)
+        I3 = ctypes.c_int32 * 3
+        sh, sw, al = I3(0, 0, 0), I3(0, 0, 0), I3(0, 0, 0)
+        real = []
+        for i, (t, l) in enumerate(zip(srcs, lazy)):
+            if l is None:
+                real.append(t)
+            else:
+                real.append(l[0])
+                sh[i], sw[i], al[i] = int(l[0].shape[2]), int(l[0].shape[3]), 1 if l[1] else 0
+        with _hbm("conv_pack_input_lazy_kernel", sum(4.0 * r.numel() * (1 if l is not None else 1) for r, l in zip(real, lazy)) + nbytes):
+            per = nbytes // d.N
+            for n0, n1 in chunks:
+                dc = type(d).from_buffer_copy(d)
+                dc.N = n1 - n0
+                ps = [_p(t[n0:n1]) for t in real] + [None] * (3 - len(real))
+                check(lib().jaf_conv2d_pack_input_resized(_s(), ctypes.byref(dc), ps[0], ps[1], ps[2], sh, sw, al,
+                                                          _p(xp[n0 * per:n1 * per])), "jaf_conv2d_pack_input_resized")
+        return xp
     with _hbm("conv_pack_input_kernel", 4.0 * d.N * d.G * d.Cin * d.H * d.W + nbytes):
         if len(chunks) == 1:
             ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
@@ -475,7 +497,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
               bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
               xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
-              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False):
+              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False, lazy=None):
     skip_f32 = skip_f32 and dst is not None and ln_stats is None
     if out is None:
         out_ctot = G * Cout
@@ -496,7 +518,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             _check_image(prepacked, N, G, Cin, H, W, "conv2d")
             xp = prepacked.buf
         elif xp is None:
-            xp = pack_input(srcs, d)
+            xp = pack_input(srcs, d, lazy)
         if dst is not None:
             _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
             if dst.img_off + N > dst.image.N:
@@ -540,7 +562,7 @@ def _grad_inplace(p: torch.Tensor) -> bool:
 
 class _ConvMeta:
     __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
-                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst", "keep_f32")
+                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst", "keep_f32", "lazy")
 
 
 def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
@@ -579,7 +601,9 @@ class _ConvFn(Function):
                           m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True,
                           ln_stats=m.ln_stats, prepacked=m.prepacked if use_img else None, dst=m.dst if use_img else None,
                           skip_f32=use_img and not m.keep_f32 and m.dst is not None and m.dst.coff % 8 == 0
-                          and m.act in (ACT_LRELU, ACT_RELU))
+                          and m.act in (ACT_LRELU, ACT_RELU), lazy=m.lazy)
+        if m.lazy is not None and xp is None:
+            raise RuntimeError("conv2d: a lazily resized source reached a convolution outside the packed bf16 path")
         # y only as bf16 inside the consumer's image: the activation backward reads it from there
         ctx.y_img = (m.dst.image, m.dst.coff, m.dst.img_off) if (y.stride(0) == 0 and y.numel() > 1) else None
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
@@ -703,7 +727,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     if not (prepacked is not None and packed_active()):       # with their packed image given, the sources are only autograd edges
-        srcs = [_chk(t, "conv2d source") for t in srcs]
+        srcs = [t if getattr(t, "_jaf_lazy", None) is not None and packed_active() else _chk(t, "conv2d source") for t in srcs]
     _chk(weight, "conv2d weight")
     if bias is not None:
         _chk(bias, "conv2d bias")
@@ -734,6 +758,11 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
     m.ln_stats = ln_stats
     m.prepacked, m.dst, m.keep_f32 = prepacked, dst, keep_f32
+    m.lazy = [getattr(t, "_jaf_lazy", None) for t in srcs]
+    if not any(l is not None for l in m.lazy):
+        m.lazy = None
+    elif not _wgrad_packed_ok(m):
+        raise RuntimeError("conv2d: lazily resized sources need a layer whose weight gradient runs on the packed kernel")
     return _ConvFn.apply(weight, bias, m, *srcs)
 
 
@@ -1113,9 +1142,38 @@ class _ResizeFn(Function):
         return dx, None, None, None, None, None
 
 
-def resize(x, size: Tuple[int, int], align_corners: bool, nearest: bool = False, crop=None):
-    """Bilinear (or nearest) resize of x (optionally of the crop window (y0, x0, h, w))."""
-    return _ResizeFn.apply(_chk(x, "resize x"), int(size[0]), int(size[1]), bool(align_corners), bool(nearest), crop)
+class _LazyResizeFn(Function):
+    """Bilinear resize whose result is only ever read by a convolution of the packed bf16 path: nothing is computed here,
+    the consumer samples `x` while it packs its input image (pack_input -> jaf_conv2d_pack_input_resized).  The returned
+    tensor is a storage-less autograd handle; the adjoint is the ordinary resize backward."""
+
+    @staticmethod
+    def forward(ctx, x, OH, OW, align):
+        N, C, H, W = x.shape
+        ctx.cfg = (N, C, H, W, OH, OW, align)
+        return torch.empty_strided((N, C, OH, OW), (0, 0, 0, 0), device=x.device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, OH, OW, align = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
+        for n0, n1 in _n_chunks(N, C):
+            check(lib().jaf_resize_bwd(_s(), _p(dy[n0:n1]), _p(dx[n0:n1]), n1 - n0, C, H, W, 0, 0, H, W, OH, OW, 1 if align else 0),
+                  "jaf_resize_bwd")
+        return dx, None, None, None
+
+
+def resize(x, size: Tuple[int, int], align_corners: bool, nearest: bool = False, crop=None, lazy: bool = False):
+    """Bilinear (or nearest) resize of x (optionally of the crop window (y0, x0, h, w)).
+    lazy=True (honoured on the packed bf16 path, bilinear, no crop): the caller guarantees that the result is consumed
+    only as a source of ops.conv2d, which then samples `x` itself while packing (see _LazyResizeFn)."""
+    _chk(x, "resize x")
+    if lazy and packed_active() and not nearest and crop is None:
+        y = _LazyResizeFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
+        y._jaf_lazy = (x, bool(align_corners))
+        return y
+    return _ResizeFn.apply(x, int(size[0]), int(size[1]), bool(align_corners), bool(nearest), crop)
 
 
 class _ReflectPadFn(Function):

@@ -360,3 +360,38 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                 assert d <= 1e-5 * max(1.0, p0[k].abs().max().item()), (cls.__name__, k, d)
     finally:
         ops.set_precision(prev)
+
+
+def test_lazy_resize_matches_resize_then_pack():
+    """bf16 path: a decoder's `cat[up(x), skip]` with the up-sampling fused into the packing pass
+    (ops.resize(lazy=True) -> jaf_conv2d_pack_input_resized) against the materialised resize: same bilinear taps, so the
+    conv output and all gradients agree to bf16 rounding noise of isolated elements (the two kernels may contract the
+    interpolation's multiply-adds differently: one fp32 ulp, occasionally one bf16 ulp after rounding)."""
+    from jafpro_amd import ops
+    G = 3
+    for ac, (h, w, OH, OW) in ((True, (13, 13, 25, 25)), (False, (16, 20, 32, 40)), (True, (25, 25, 50, 50))):
+        res = []
+        for lazy in (True, False):
+            g = torch.Generator().manual_seed(5)
+            x = (torch.rand(2, G * 8, h, w, generator=g) * 2 - 1).cuda().requires_grad_(True)
+            e = (torch.rand(2, 5, h, w, generator=g) * 2 - 1).cuda().requires_grad_(True)       # shared by all groups
+            skip = (torch.rand(2, G * 4, OH, OW, generator=g) * 2 - 1).cuda().requires_grad_(True)
+            wt = ((torch.rand(G * 6, 17, 3, 3, generator=g) - 0.5) * 0.4).cuda().requires_grad_(True)
+            b = (torch.rand(G * 6, generator=g) - 0.5).cuda().requires_grad_(True)
+            proj = torch.rand(2, G * 6, OH, OW, generator=g).cuda()
+            prev = ops.set_precision("bf16")
+            try:
+                up = ops.resize(x, (OH, OW), ac, lazy=lazy)
+                upe = ops.resize(e, (OH, OW), ac, lazy=lazy)
+                assert (getattr(up, "_jaf_lazy", None) is not None) == lazy
+                y = ops.conv2d([up, upe, skip], wt, b, stride=1, pad=1, act=ops.ACT_LRELU, slope=0.2, groups=G, shared=[False, True, False])
+                (y * proj).sum().backward()
+            finally:
+                ops.set_precision(prev)
+            res.append([t.detach().clone() for t in (y, x.grad, e.grad, skip.grad, wt.grad, b.grad)])
+        for a, r, name in zip(res[0], res[1], ("y", "dx", "de", "dskip", "dw", "db")):
+            rel = ((a - r).double().norm() / r.double().norm()).item()
+            assert rel <= 2e-3, (ac, name, rel)
+    # outside the packed path `lazy` is ignored
+    t = torch.rand(1, 2, 4, 4).cuda()
+    assert getattr(ops.resize(t, (8, 8), True, lazy=True), "_jaf_lazy", None) is None
