@@ -203,6 +203,10 @@ def _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
     return d
 
 
+def _packed_path_now() -> bool:
+    return _USE_PACKED and _PRECISION == PREC_BF16
+
+
 def _packed_path(d: ConvDesc) -> bool:
     return _USE_PACKED and d.precision == PREC_BF16
 
@@ -312,6 +316,20 @@ def set_packed_images(flag: bool) -> bool:
     global _PACKED_IMAGES
     prev, _PACKED_IMAGES = _PACKED_IMAGES, bool(flag)
     return prev
+
+
+_LAZY_RESIZE = os.environ.get("JAF_NO_LAZY_RESIZE") is None
+
+
+def set_lazy_resize(flag: bool) -> bool:
+    """A/B switch of ops.resize(lazy=True): False materialises every resize (jaf_resize_fwd) again."""
+    global _LAZY_RESIZE
+    prev, _LAZY_RESIZE = _LAZY_RESIZE, bool(flag)
+    return prev
+
+
+def lazy_resize_active() -> bool:
+    return _LAZY_RESIZE and _USE_PACKED and _PRECISION == PREC_BF16
 
 
 def packed_active() -> bool:
@@ -727,7 +745,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     if not (prepacked is not None and packed_active()):       # with their packed image given, the sources are only autograd edges
-        srcs = [t if getattr(t, "_jaf_lazy", None) is not None and packed_active() else _chk(t, "conv2d source") for t in srcs]
+        srcs = [t if getattr(t, "_jaf_lazy", None) is not None and _packed_path_now() else _chk(t, "conv2d source") for t in srcs]
     _chk(weight, "conv2d weight")
     if bias is not None:
         _chk(bias, "conv2d bias")
@@ -1169,7 +1187,7 @@ def resize(x, size: Tuple[int, int], align_corners: bool, nearest: bool = False,
     lazy=True (honoured on the packed bf16 path, bilinear, no crop): the caller guarantees that the result is consumed
     only as a source of ops.conv2d, which then samples `x` itself while packing (see _LazyResizeFn)."""
     _chk(x, "resize x")
-    if lazy and packed_active() and not nearest and crop is None:
+    if lazy and lazy_resize_active() and not nearest and crop is None:
         y = _LazyResizeFn.apply(x, int(size[0]), int(size[1]), bool(align_corners))
         y._jaf_lazy = (x, bool(align_corners))
         return y

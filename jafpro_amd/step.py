@@ -101,9 +101,13 @@ _FLAG_CACHE = {}
 
 
 WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradients on a second side stream
-# where the next clip's preparation is issued: "bwd" = right before the generator loss backward (north star), "d" = at
-# the start of the discriminator phase (experiment: that phase is a chain of 5-40 us launches that leaves the chip idle)
-PREP_AT = os.environ.get("JAF_PREP_AT", "bwd")
+# Where the next clip's preparation (side stream 0) is issued.  "d" (default): its matrix-core part -- the frozen
+# background CRN (2.4 TFLOP at B=8) and the frozen VGG's target features -- at the start of the discriminator phase, which is
+# ~330 launches of 5-40 us in one dependent chain and leaves most of the chip idle; its renderer part (SMPL projection,
+# rasteriser, barycentric flow, flow warp) right before the VGG + GAN loss backward, which it overlaps (north star).
+# "bwd": everything right before the loss backward, where the CRN competes with the backward's own kernels.
+# Measured at B=8: 68.6 vs 70.4 ms/step.
+PREP_AT = os.environ.get("JAF_PREP_AT", "d")
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -151,32 +155,42 @@ def _source_pose(b: Dict[str, torch.Tensor], prosrc: int):
     return b["src_cam"], b["src_verts"]
 
 
-def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int, with_loss_target: bool = False) -> PreparedClip:
+def prepare_clip(M: Stage4Models, b: Dict[str, torch.Tensor], prosrc: int, with_loss_target: bool = False,
+                 part: str = "all", into: Optional[PreparedClip] = None) -> PreparedClip:
+    """Issues a clip's parameter-independent preparation on side stream 0.  `part`: "networks" = the frozen background
+    CRN and the frozen VGG's target features (matrix-core work), "renderer" = SMPL projection -> rasteriser -> barycentric
+    flow -> flow warp (the neural_renderer part the north star names), "all" = both.  The two parts may be issued at
+    different points of the previous step (`into` = the PreparedClip the first part returned); `event` always marks the
+    end of everything issued so far."""
     main = torch.cuda.current_stream()
     side = _side_stream(main.device)
     side.wait_stream(main)          # the batch tensors were produced on the main stream
-    p = PreparedClip()
-    p.batch, p.prosrc, p.key = b, prosrc, _clip_key(b, prosrc)
+    p = into
+    if p is None:
+        p = PreparedClip()
+        p.batch, p.prosrc, p.key = b, prosrc, _clip_key(b, prosrc)
+        p.src0 = p.bg_output = p.tsf = p.event = p.vgg_target = p.vgg_event = None
     with torch.cuda.stream(side), torch.no_grad():
         if side != main:
             for k in _PREP_KEYS:    # read on the side stream: a batch freed early must not be reallocated under it
                 if k in b:
                     b[k].record_stream(side)
-        p.src0 = b["src_img"][:, 0].contiguous()
-        bg_mask = 1.0 - b["src_mask_in_image0"]                                 # :230-231 (input prep)
-        bg_incomplete = (bg_mask * p.src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
-        p.bg_output = M.bg_model(bg_incomplete, M.image_size)                   # :319-320
-        prev_img = b["src_img"][:, prosrc].contiguous()
-        src_cam, src_verts = _source_pose(b, prosrc)
-        p.tsf = M.flow_calculator(prev_img, [src_cam, None, src_verts, None],
-                                  [b["tgt_cam"], None, b["tgt_verts"], None])    # :325
+        if part in ("all", "networks"):
+            p.src0 = b["src_img"][:, 0].contiguous()
+            bg_mask = 1.0 - b["src_mask_in_image0"]                                 # :230-231 (input prep)
+            bg_incomplete = (bg_mask * p.src0 + (1.0 - bg_mask) * b["bg_noise"]).contiguous()
+            p.bg_output = M.bg_model(bg_incomplete, M.image_size)                   # :319-320
+            if with_loss_target and "tgt_img" in b:
+                p.vgg_target = M.loss_criterion.target_features(b["tgt_img"])
+                p.vgg_event = torch.cuda.Event()
+                p.vgg_event.record(side)
+        if part in ("all", "renderer"):
+            prev_img = b["src_img"][:, prosrc].contiguous()
+            src_cam, src_verts = _source_pose(b, prosrc)
+            p.tsf = M.flow_calculator(prev_img, [src_cam, None, src_verts, None],
+                                      [b["tgt_cam"], None, b["tgt_verts"], None])    # :325
         p.event = torch.cuda.Event()
         p.event.record(side)
-        p.vgg_target, p.vgg_event = None, None
-        if with_loss_target and "tgt_img" in b:
-            p.vgg_target = M.loss_criterion.target_features(b["tgt_img"])
-            p.vgg_event = torch.cuda.Event()
-            p.vgg_event.record(side)
     return p
 
 
@@ -193,6 +207,8 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     main = torch.cuda.current_stream()
     if prepared is None or prepared.key != _clip_key(b, prosrc) or (with_loss_target and "tgt_img" in b and prepared.vgg_target is None):
         prepared = prepare_clip(M, b, prosrc, with_loss_target)
+    elif prepared.tsf is None or prepared.bg_output is None:        # only one part was issued ahead: issue the other now
+        prepared = prepare_clip(M, b, prosrc, with_loss_target, part="renderer" if prepared.tsf is None else "networks", into=prepared)
     bg_output, tsf = prepared.bg_output, prepared.tsf
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
     x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
@@ -318,7 +334,7 @@ class Stage4Trainer:
             raise RuntimeError("train_step supports image_size 256 (reference) and 512 (config 5), got %d" % M.image_size)
         target_d, src0_d = dview(target), dview(src0)
         if next_batch is not None and PREP_AT == "d":
-            self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True)
+            self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True, part="networks")
         # ---- face discriminator, one update (:362-374)
         if face_pred is not None:
             F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
@@ -346,8 +362,9 @@ class Stage4Trainer:
         F_errG = (ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0) if face_pred is not None
                   else torch.zeros(1, device=final.device))
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
-        if next_batch is not None and PREP_AT != "d":      # overlaps with the VGG + GAN loss backward below
-            self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True)
+        if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
+            self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True,
+                                          part="renderer" if PREP_AT == "d" else "all", into=self._prepared if PREP_AT == "d" else None)
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
             # input (reverse graph order), beside the differentiation of the modules upstream of it

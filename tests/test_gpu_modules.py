@@ -321,6 +321,7 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
     from jafpro_amd.crn_model import CRN_smaller
     from jafpro_amd.networks import Accumulate_LSTM_no_loss, UNet_inpainter, VGG19_CRN
     prev = ops.set_precision("bf16")
+    prev_lazy = ops.set_lazy_resize(False)      # (the fused up-sampling has its own test; it is not bit-identical by design)
     try:
         for cls, seed, T_ in ((Accumulate_LSTM_no_loss, 21, 3), (UNet_inpainter, 31, 1), (CRN_smaller, 41, 0), (VGG19_CRN, 71, 0)):
             res = []
@@ -360,6 +361,7 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                 assert d <= 1e-5 * max(1.0, p0[k].abs().max().item()), (cls.__name__, k, d)
     finally:
         ops.set_precision(prev)
+        ops.set_lazy_resize(prev_lazy)
 
 
 def test_lazy_resize_matches_resize_then_pack():
@@ -392,6 +394,6 @@ def test_lazy_resize_matches_resize_then_pack():
         for a, r, name in zip(res[0], res[1], ("y", "dx", "de", "dskip", "dw", "db")):
             rel = ((a - r).double().norm() / r.double().norm()).item()
             assert rel <= 2e-3, (ac, name, rel)
-    # outside the packed path `lazy` is ignored
+    # outside the packed bf16 path `lazy` is ignored
     t = torch.rand(1, 2, 4, 4).cuda()
     assert getattr(ops.resize(t, (8, 8), True, lazy=True), "_jaf_lazy", None) is None
