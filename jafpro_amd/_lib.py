@@ -10,7 +10,8 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libjafpro_hip.so")
+# JAFPRO_HIP_LIB: another build of the same library (A/B runs of compiler flags); still no fallback of any kind
+LIB_PATH = os.environ.get("JAFPRO_HIP_LIB") or os.path.join(HERE, "libjafpro_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "jafpro_hip.h")
 
 _PROTO = re.compile(r"^(int|int64_t)\s+(jaf_\w+)\s*\(([^;]*?)\)\s*;", re.S | re.M)

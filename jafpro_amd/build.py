@@ -21,7 +21,13 @@ SOURCES = ["conv.hip", "conv_bf16.hip", "conv_dma.hip", "wgrad.hip", "wgrad_bf16
            "raster.hip", "linear.hip", "ubench.hip", "input_pipeline.hip", "metrics.hip"]
 # raster.hip must keep the reference's fp32 expression trees (no FMA contraction): see its header.
 EXTRA = {"raster.hip": ["-ffp-contract=off"]}
-COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# No packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in device code.  Measured on MI355X: with them,
+# flow_warp_fwd_kernel (`v_pk_mul_f32 ... op_sel` straight after 4-byte-aligned dwordx2 gathers) lost one product in 16 adjacent
+# lanes in 2-8 % of its launches while bf16 MFMA kernels of another stream shared the CUs; without them 0 of 720, and the step
+# is 1 ms faster (tests/test_gpu_overlap.py; tests/test_host_logic.py checks the built code objects).
+# The x86 pass of hipcc ignores the feature with a warning.
+NO_PACKED_F32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + NO_PACKED_F32
 
 
 def _digest(path: str, flags) -> str:

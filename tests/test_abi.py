@@ -18,6 +18,29 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().jaf_version() == 100
 
 
+def test_device_code_has_no_packed_fp32_instructions(tmp_path):
+    """build.py NO_PACKED_F32: v_pk_mul/add/fma_f32 gave wrong lanes beside bf16 MFMA kernels of another
+    stream; the shipped code objects must not contain one.  Disassembles the gfx950 code of the built library."""
+    import re
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump in this image")
+    so = str(tmp_path / "lib.so")
+    shutil.copy(_lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", so], check=True, capture_output=True, cwd=str(tmp_path))
+    cos = [f for f in os.listdir(str(tmp_path)) if "gfx950" in f]
+    assert cos, "no gfx950 code object in %s" % _lib.LIB_PATH
+    n_inst, packed = 0, []
+    for co in cos:
+        txt = subprocess.run([objdump, "-d", str(tmp_path / co)], check=True, capture_output=True, text=True).stdout
+        n_inst += len(re.findall(r"\bv_mfma_", txt))
+        packed += re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b", txt)
+    assert n_inst > 100                      # the disassembly is the real thing
+    assert not packed, "%d packed-fp32 instructions in the library" % len(packed)
+
+
 def test_header_cites_reference_interfaces():
     text = open(_lib.HEADER).read()
     for cite in ("rasterize_cuda.cpp:70-95", "src/convLSTM.py:41-56", "src/crn_model.py:78-87", "src/cal_flow.py:38",
