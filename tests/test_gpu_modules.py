@@ -371,7 +371,9 @@ def test_lazy_resize_matches_resize_then_pack():
     interpolation's multiply-adds differently: one fp32 ulp, occasionally one bf16 ulp after rounding)."""
     from jafpro_amd import ops
     G = 3
-    for ac, (h, w, OH, OW) in ((True, (13, 13, 25, 25)), (False, (16, 20, 32, 40)), (True, (25, 25, 50, 50))):
+    # widths below 48 take the gather kernel, the rest the LDS-staged one (ragged tiles, non-integer ratios included)
+    for ac, (h, w, OH, OW) in ((True, (13, 13, 25, 25)), (False, (16, 20, 32, 40)), (True, (25, 25, 50, 50)),
+                               (False, (50, 50, 100, 100)), (True, (50, 60, 100, 119)), (False, (37, 41, 100, 130))):
         res = []
         for lazy in (True, False):
             g = torch.Generator().manual_seed(5)
