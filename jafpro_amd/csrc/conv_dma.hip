@@ -89,6 +89,13 @@ __global__ void conv_pack_input_kernel(const PackInArgs a) {
     const int c0 = d.src_c[0];
     const int c01 = c0 + (d.nsrc > 1 ? d.src_c[1] : 0);
     const long HW = (long)d.H * d.W;
+    // base of this (image, group) in each source, with constant indices: a descriptor array indexed by a run-time source
+    // number is re-read from the kernel arguments (scalar load + wait) at every use
+    const float* sb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+        sb[s] = (s < d.nsrc) ? a.src[s] + ((long)n * d.src_ctot[s] + d.src_coff[s] + (long)g * d.src_gstride[s]) * HW : nullptr;
+    const unsigned pix = (unsigned)(y * d.W + x);
     float v[8][V];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -98,8 +105,7 @@ __global__ void conv_pack_input_kernel(const PackInArgs a) {
         if (c < d.Cin) {
             const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
             const int cl = (s == 0) ? c : ((s == 1) ? c - c0 : c - c01);
-            const float* sp = (s == 0) ? a.src[0] : ((s == 1) ? a.src[1] : a.src[2]);
-            const float* p = sp + ((long)n * d.src_ctot[s] + d.src_coff[s] + g * d.src_gstride[s] + cl) * HW + (long)y * d.W + x;
+            const float* p = ((s == 0) ? sb[0] : ((s == 1) ? sb[1] : sb[2])) + cl * HW + pix;
             if (V == 4) {
                 const f32x4 t = *(const f32x4*)p;
                 v[j][0] = t[0]; v[j][1] = t[1]; v[j][2] = t[2]; v[j][3] = t[3];
@@ -176,6 +182,7 @@ struct PackLazyArgs {
     PackInArgs b;
     int lazy[3], sh[3], sw[3], align[3];
     float sy[3], sx[3];
+    int cap;               // LDS-staged form: floats per channel of the staged source tile
 };
 
 __device__ __forceinline__ void cd_resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
@@ -242,16 +249,21 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_kernel(const PackLaz
 
 // The same packing with the low-resolution source tiles staged through LDS: a 64 x 16 output tile of an up-sampled source
 // needs about (64 sx + 2) x (16 sy + 2) source pixels per channel, which the workgroup loads once, coalesced, instead of
-// four gathers per output value (the gather form is texture-address bound: 32 gathers per lane).  Lane (tx, ty) owns column
-// tx of rows ty, ty + 4, ty + 8, ty + 12 of the tile.  Same expression tree as the gather kernel: results are identical.
+// four gathers per output value.  V = 4 (W % 4 == 0): a lane owns 4 consecutive pixels of one row -- the sources that are
+// not resized arrive by 16-byte loads and the lane writes 64 contiguous bytes; V = 1: lane = column, 4 rows per lane.
+// Same expression tree as the gather kernel: results are identical.
 #define PL_TW 64
 #define PL_TH 16
 #define PL_CAP 1280        // floats per channel of the staged source tile (host checks the bound)
+template <int V>
 __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const PackLazyArgs a) {
-    __shared__ float s_t[8][PL_CAP];
+    extern __shared__ float s_dyn[];       // [8][a.cap]
+    constexpr int LX = PL_TW / V;          // lanes along x
+    constexpr int RP = 256 / LX;           // rows in flight
     const jaf_conv_desc& d = a.b.d;
-    const int tid = threadIdx.y * 64 + threadIdx.x;
-    const int x = blockIdx.x * PL_TW + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int tx = tid % LX, ty = tid / LX;
+    const int x = blockIdx.x * PL_TW + tx * V;
     const int yb = blockIdx.y * PL_TH;
     int z = blockIdx.z;
     const int cg = z % a.b.ngroups8;
@@ -261,12 +273,23 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const Pac
     const int c0 = d.src_c[0];
     const int c01 = c0 + (d.nsrc > 1 ? d.src_c[1] : 0);
     const long HW = (long)d.H * d.W;
+    // per-source scalars with constant indices (a descriptor array indexed by a run-time source number is re-read from
+    // the kernel arguments, with a wait, at every use): plane size, lazy flag, base of this (image, group)
+    int lz[3];
+    long pl[3];
+    const float* sb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        lz[s] = (s < d.nsrc) ? a.lazy[s] : 0;
+        pl[s] = lz[s] ? (long)a.sh[s] * a.sw[s] : HW;
+        sb[s] = (s < d.nsrc) ? a.b.src[s] + ((long)n * d.src_ctot[s] + d.src_coff[s] + (long)g * d.src_gstride[s]) * pl[s] : nullptr;
+    }
     const int xl = min(blockIdx.x * PL_TW + PL_TW - 1, d.W - 1), yl = min(yb + PL_TH - 1, d.H - 1);     // last column / row of the tile
     int ys0[3], xs0[3], tw[3];
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         ys0[s] = xs0[s] = 0; tw[s] = 1;
-        if (s < d.nsrc && a.lazy[s]) {
+        if (lz[s]) {
             int i0, i1; float l;
             cd_resize_src(yb, a.sy[s], a.sh[s], a.align[s], ys0[s], i1, l);
             cd_resize_src(blockIdx.x * PL_TW, a.sx[s], a.sw[s], a.align[s], xs0[s], i1, l);
@@ -274,79 +297,155 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const Pac
             tw[s] = i1 - xs0[s] + 1;
         }
     }
-    // stage: channel j of this group of 8, rows ys0 .. y1(last row), columns xs0 .. x1(last column)
+    // stage: channel j of this group of 8, rows ys0 .. y1(last row), columns xs0 .. x1(last column).  All of a lane's loads
+    // (two per channel cover tiles of up to 512 source pixels) are issued before the first LDS store.
+    int cnt[3], soff[3][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        cnt[s] = 0; soff[s][0] = soff[s][1] = 0;
+        if (lz[s]) {
+            int i0, i1; float l;
+            cd_resize_src(yl, a.sy[s], a.sh[s], a.align[s], i0, i1, l);
+            cnt[s] = (i1 - ys0[s] + 1) * tw[s];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int e = tid + 256 * u;
+                const int r = e / tw[s], q = e - r * tw[s];
+                soff[s][u] = (ys0[s] + r) * a.sw[s] + xs0[s] + q;
+            }
+        }
+    }
+    float st[8][2];
+    const float* sbase[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = cg * 8 + j;
+        sbase[j] = nullptr;
+        st[j][0] = st[j][1] = 0.f;
         if (c >= d.Cin) continue;
         const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
-        if (!a.lazy[s]) continue;
+        if (!((s == 0) ? lz[0] : ((s == 1) ? lz[1] : lz[2]))) continue;
         const int cl = (s == 0) ? c : ((s == 1) ? c - c0 : c - c01);
-        const float* sp = (s == 0) ? a.b.src[0] : ((s == 1) ? a.b.src[1] : a.b.src[2]);
-        const long ch = (long)n * d.src_ctot[s] + d.src_coff[s] + g * d.src_gstride[s] + cl;
-        const float* p = sp + ch * (long)(a.sh[s] * a.sw[s]);
-        int i0, i1; float l;
-        cd_resize_src(yl, a.sy[s], a.sh[s], a.align[s], i0, i1, l);
-        const int th = i1 - ys0[s] + 1, w_ = tw[s];
-        const int cnt = th * w_;
-        for (int e = tid; e < cnt; e += 256) {
-            const int r = e / w_, q = e - r * w_;
-            s_t[j][e] = p[(ys0[s] + r) * a.sw[s] + xs0[s] + q];
+        sbase[j] = ((s == 0) ? sb[0] : ((s == 1) ? sb[1] : sb[2])) + cl * ((s == 0) ? pl[0] : ((s == 1) ? pl[1] : pl[2]));
+        const int cn = (s == 0) ? cnt[0] : ((s == 1) ? cnt[1] : cnt[2]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + 256 * u < cn) st[j][u] = sbase[j][(s == 0) ? soff[0][u] : ((s == 1) ? soff[1][u] : soff[2][u])];
+    }
+    // the sources that are not resized do not depend on the staged tiles: their loads go out with the staging loads
+    constexpr int ITER = PL_TH / RP;
+    float nv[ITER][8][V];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int y = yb + ty + RP * it;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cg * 8 + j;
+#pragma unroll
+            for (int i = 0; i < V; ++i) nv[it][j][i] = 0.f;
+            if (c < d.Cin && x < d.W && y < d.H) {
+                const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
+                if (!((s == 0) ? lz[0] : ((s == 1) ? lz[1] : lz[2]))) {
+                    const int cl = (s == 0) ? c : ((s == 1) ? c - c0 : c - c01);
+                    const float* q = ((s == 0) ? sb[0] : ((s == 1) ? sb[1] : sb[2])) + cl * HW + (unsigned)(y * d.W + x);
+                    if (V == 4) {
+                        const f32x4 tq = *(const f32x4*)q;
+                        nv[it][j][0] = tq[0]; nv[it][j][V > 1 ? 1 : 0] = tq[1]; nv[it][j][V > 2 ? 2 : 0] = tq[2]; nv[it][j][V > 3 ? 3 : 0] = tq[3];
+                    } else {
+                        nv[it][j][0] = q[0];
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (!sbase[j]) continue;
+        const int c = cg * 8 + j;
+        const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
+        const int cn = (s == 0) ? cnt[0] : ((s == 1) ? cnt[1] : cnt[2]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (tid + 256 * u < cn) s_dyn[j * a.cap + tid + 256 * u] = st[j][u];
+        if (cn > 512) {                                           // tiles beyond 512 source pixels (ratios near 1)
+            const int tws = (s == 0) ? tw[0] : ((s == 1) ? tw[1] : tw[2]);
+            const int y0s = (s == 0) ? ys0[0] : ((s == 1) ? ys0[1] : ys0[2]);
+            const int x0s = (s == 0) ? xs0[0] : ((s == 1) ? xs0[1] : xs0[2]);
+            const int sws = (s == 0) ? a.sw[0] : ((s == 1) ? a.sw[1] : a.sw[2]);
+            for (int e = tid + 512; e < cn; e += 256) {
+                const int r = e / tws, q = e - r * tws;
+                s_dyn[j * a.cap + e] = sbase[j][(y0s + r) * sws + x0s + q];
+            }
         }
     }
     __syncthreads();
     if (x >= d.W) return;
-    int ox0[3], ox1[3];
-    float lx[3];
+    int ox0[3][V], ox1[3][V];
+    float lx[3][V];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        ox0[s] = ox1[s] = 0; lx[s] = 0.f;
-        if (s < d.nsrc && a.lazy[s]) {
-            int x0, x1;
-            cd_resize_src(x, a.sx[s], a.sw[s], a.align[s], x0, x1, lx[s]);
-            ox0[s] = x0 - xs0[s]; ox1[s] = x1 - xs0[s];
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            ox0[s][i] = ox1[s][i] = 0; lx[s][i] = 0.f;
+            if (lz[s]) {
+                int x0, x1;
+                cd_resize_src(x + i, a.sx[s], a.sw[s], a.align[s], x0, x1, lx[s][i]);
+                ox0[s][i] = x0 - xs0[s]; ox1[s][i] = x1 - xs0[s];
+            }
         }
-    }
 #pragma unroll
-    for (int i = 0; i < PL_TH / 4; ++i) {
-        const int y = yb + threadIdx.y + 4 * i;
+    for (int it = 0; it < ITER; ++it) {
+        const int y = yb + ty + RP * it;
         if (y >= d.H) break;
         int r0[3], r1[3];
         float ly[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
             r0[s] = r1[s] = 0; ly[s] = 0.f;
-            if (s < d.nsrc && a.lazy[s]) {
+            if (lz[s]) {
                 int y0, y1;
                 cd_resize_src(y, a.sy[s], a.sh[s], a.align[s], y0, y1, ly[s]);
                 r0[s] = (y0 - ys0[s]) * tw[s]; r1[s] = (y1 - ys0[s]) * tw[s];
             }
         }
-        float v[8];
+        float v[8][V];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = cg * 8 + j;
-            v[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) v[j][i] = 0.f;
             if (c < d.Cin) {
                 const int s = (c < c0) ? 0 : ((c < c01) ? 1 : 2);
-                if (a.lazy[s]) {
-                    const float* t = s_t[j];
-                    const float hy = 1.f - ly[s], hx = 1.f - lx[s];
-                    v[j] = hy * (hx * t[r0[s] + ox0[s]] + lx[s] * t[r0[s] + ox1[s]]) + ly[s] * (hx * t[r1[s] + ox0[s]] + lx[s] * t[r1[s] + ox1[s]]);
+                if ((s == 0) ? lz[0] : ((s == 1) ? lz[1] : lz[2])) {
+                    const float* t = s_dyn + j * a.cap;
+                    const float lys = (s == 0) ? ly[0] : ((s == 1) ? ly[1] : ly[2]);
+                    const int r0s = (s == 0) ? r0[0] : ((s == 1) ? r0[1] : r0[2]);
+                    const int r1s = (s == 0) ? r1[0] : ((s == 1) ? r1[1] : r1[2]);
+                    const float hy = 1.f - lys;
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const float lxs = (s == 0) ? lx[0][i] : ((s == 1) ? lx[1][i] : lx[2][i]);
+                        const int o0 = (s == 0) ? ox0[0][i] : ((s == 1) ? ox0[1][i] : ox0[2][i]);
+                        const int o1 = (s == 0) ? ox1[0][i] : ((s == 1) ? ox1[1][i] : ox1[2][i]);
+                        const float hx = 1.f - lxs;
+                        v[j][i] = hy * (hx * t[r0s + o0] + lxs * t[r0s + o1]) + lys * (hx * t[r1s + o0] + lxs * t[r1s + o1]);
+                    }
                 } else {
-                    const int cl = (s == 0) ? c : ((s == 1) ? c - c0 : c - c01);
-                    const float* sp = (s == 0) ? a.b.src[0] : ((s == 1) ? a.b.src[1] : a.b.src[2]);
-                    const long ch = (long)n * d.src_ctot[s] + d.src_coff[s] + g * d.src_gstride[s] + cl;
-                    v[j] = sp[ch * HW + (long)y * d.W + x];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) v[j][i] = nv[it][j][i];
                 }
             }
         }
-        u32x4 w;
-        w[0] = cd_pack2(v[0], v[1]);
-        w[1] = cd_pack2(v[2], v[3]);
-        w[2] = cd_pack2(v[4], v[5]);
-        w[3] = cd_pack2(v[6], v[7]);
-        *(u32x4*)(a.b.out + ((((long)n * d.G + g) * a.b.ngroups8 + cg) * HW + (long)y * d.W + x) * 16) = w;
+        unsigned char* o = a.b.out + ((((long)n * d.G + g) * a.b.ngroups8 + cg) * HW + (long)y * d.W + x) * 16;
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            u32x4 w;
+            w[0] = cd_pack2(v[0][i], v[1][i]);
+            w[1] = cd_pack2(v[2][i], v[3][i]);
+            w[2] = cd_pack2(v[4][i], v[5][i]);
+            w[3] = cd_pack2(v[6][i], v[7][i]);
+            *(u32x4*)(o + i * 16) = w;
+        }
     }
 }
 
@@ -379,16 +478,23 @@ extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc
     if (nz > 65535 || d->H > 65535) return JAF_EUNSUPPORTED;
     // the LDS-staged form when the image is at least a tile wide and every lazy source tile fits (up-sampling: it always does)
     bool staged = d->W >= 48;
+    long cap = 32;
     for (int i = 0; i < 3; ++i)
         if (a.lazy[i]) {
             const long th = (long)ceilf(a.sy[i] * PL_TH) + 3, tw = (long)ceilf(a.sx[i] * PL_TW) + 3;
-            if (th * tw > PL_CAP) staged = false;
+            if (th * tw > cap) cap = th * tw;
         }
+    if (cap > PL_CAP) staged = false;
     if (staged) {
-        hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel, dim3(jaf_cdiv(d->W, PL_TW), jaf_cdiv(d->H, PL_TH), (unsigned)nz), dim3(64, 4), 0,
-                           (hipStream_t)s, a);
+        a.cap = (int)((cap + 31) / 32 * 32);
+        const size_t lds = (size_t)8 * a.cap * sizeof(float);       // <= 40 KB
+        const dim3 grid(jaf_cdiv(d->W, PL_TW), jaf_cdiv(d->H, PL_TH), (unsigned)nz);
+        const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
+        if (al && d->W % 4 == 0) hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<4>, grid, dim3(256), lds, (hipStream_t)s, a);
+        else hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, a);
         return jaf_launch_status();
     }
+    a.cap = 0;
     int tx = 64;
     while (tx > 8 && (tx >> 1) >= d->W) tx >>= 1;
     const int ty = 256 / tx;
