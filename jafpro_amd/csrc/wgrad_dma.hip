@@ -45,9 +45,13 @@ struct WgDArgs {
     float inv_pwp;
 };
 
-template <int MTW, int KS>
+// PAIR (Cin <= 8, i.e. one packed item per position): the 16 columns of an MFMA are TWO taps x 8 channels instead of one
+// tap x 16 channels of which 8 are padding -- lanes p = 2, 3 of the transposed read point at the next tap's position --
+// so a 5x5 layer issues 13 MFMAs per k-step instead of 25 and keeps 13 accumulators.
+template <int MTW, int KS, bool PAIR>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
     constexpr int NTAP = KS * KS;
+    constexpr int NACC = PAIR ? (NTAP + 1) / 2 : NTAP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -134,11 +138,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         abase[h] = ((k * 32) ^ ((k & 8) << 4)) + pp * 8;
     }
 
-    f32x4 acc[MTW][NTAP];
+    f32x4 acc[MTW][NACC];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-        for (int t = 0; t < NTAP; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NACC; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
@@ -199,6 +203,26 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[1]));
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
+            if constexpr (PAIR) {
+                const int hb = pp >> 1;                  // which tap of the pair this lane's address belongs to
+#pragma unroll
+                for (int pr = 0; pr < NACC; ++pr) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int tA = 2 * pr, tB = (2 * pr + 1 < NTAP) ? 2 * pr + 1 : 2 * pr;
+                    const int ky = hb ? tB / KS : tA / KS, kx = hb ? tB % KS : tA % KS;
+                    s16x4 bb[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int c0h = (8 * (q & 1) + 4 * h + qp) * s + kx;
+                        const int ad = ((((q >> 1) + 2 * ks) * s + ky) * PWp + c0h) * 32 + (pp & 1) * 8;
+                        bb[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + (ad ^ ((c0h & 8) << 4))));
+                    }
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bb[0], bb[1], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        acc[mt][pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][pr], 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int ky = 0; ky < KS; ++ky) {
                 const int rowoff = ((2 * ks * s + ky) * PWp) * 32;
@@ -220,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     // ---- epilogue.  3x3: transpose through LDS, then atomics along dW's memory order.  5x5 / 7x7 (a few
     // tiny first/last layers): the gradient tensor is a few KB, direct atomics. ----
     const int cit = ci0 + wc * 16;
-    if (KS == 3) {
+    if constexpr (KS == 3) {
         float* s_ep = (float*)smem + wave * (16 * WD_EP);
         const int nrem = (d.Cin - cit) * 9;
 #pragma unroll
@@ -238,6 +262,23 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 if (co < d.Cout && rem < nrem) {
                     float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
                     atomicAdd(p, s_ep[row * WD_EP + rem]);
+                }
+            }
+        }
+    } else if constexpr (PAIR) {
+        const int ci = li & 7, hb = li >> 3;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = co0 + mt * 16 + q * 4 + j;
+                if (co < d.Cout && ci < d.Cin) {
+                    float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + ci) * NTAP;
+#pragma unroll
+                    for (int pr = 0; pr < NACC; ++pr) {
+                        const int t = 2 * pr + hb;
+                        if (t < NTAP) atomicAdd(p + t, acc[mt][pr][j]);
+                    }
                 }
             }
         }
@@ -318,9 +359,10 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     a.nsplit = (int)nsplit;
     const long nblk = outblocks * nsplit;
     JAF_REQUIRE(nblk <= 0x7fffffffL);
-#define JAF_WGD(MT_, KS_)                                                                              \
+#define JAF_WGD(MT_, KS_) JAF_WGDP(MT_, KS_, false)
+#define JAF_WGDP(MT_, KS_, PAIR_)                                                                      \
     do {                                                                                               \
-        auto k = conv_wgrad_dma_kernel<MT_, KS_>;                                                      \
+        auto k = conv_wgrad_dma_kernel<MT_, KS_, PAIR_>;                                               \
         static int optin[JAF_MAX_DEVICES];                                                             \
         if (lds > 48 * 1024) {                                                                         \
             const int e = jaf_lds_optin((const void*)k, optin);                                        \
@@ -328,7 +370,8 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
         }                                                                                              \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)
-    if (KS == 5) JAF_WGD(1, 5);
+    if (KS == 5 && d->Cin <= 8) JAF_WGDP(1, 5, true);
+    else if (KS == 5) JAF_WGD(1, 5);
     else if (KS == 1) switch (MTW) {
         case 1: JAF_WGD(1, 1); break;
         case 2: JAF_WGD(2, 1); break;
@@ -342,5 +385,6 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
         default: JAF_WGD(4, 3); break;
     }
 #undef JAF_WGD
+#undef JAF_WGDP
     return jaf_launch_status();
 }

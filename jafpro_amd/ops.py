@@ -111,7 +111,7 @@ class _arith:
         return False
 
 
-def _wgrad_dma_name(Cout: int, KS: int) -> str:
+def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16) -> str:
     """Template instantiation jaf_conv2d_wgrad_packed launches (same rule as csrc/wgrad_dma.hip), so that the
     bench's per-kernel rows carry the names rocprofv3 reports."""
     mt_best, pad_best = 1, None
@@ -119,7 +119,7 @@ def _wgrad_dma_name(Cout: int, KS: int) -> str:
         pad = -(-Cout // (16 * mt)) * 16 * mt
         if pad_best is None or pad < pad_best:
             mt_best, pad_best = mt, pad
-    return "conv_wgrad_dma_kernel<%d, %d>" % (mt_best, KS)
+    return "conv_wgrad_dma_kernel<%d, %d, %s>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false")
 
 
 def _wgrad_name(KH, KW) -> str:
@@ -600,7 +600,7 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
             dzp = pack_input([dz], dzd)
         check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
                                            1 if inplace else 0), "jaf_conv2d_wgrad_packed_ex")
-        wname = _wgrad_dma_name(m.Cout, m.KH)
+        wname = _wgrad_dma_name(m.Cout, m.KH, m.Cin)
     else:
         check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
               "jaf_conv2d_wgrad")

@@ -43,6 +43,8 @@ CONV_CASES = [
     (1, 1, [64], 64, 100, 100, 3, 1, 1, 2),
     (2, 3, [24], 24, 50, 50, 3, 2, 1, 1),              # stride 2, wide (two ci tiles): part-network enc2/4/6/8
     (1, 1, [128], 72, 33, 31, 3, 2, 1, 1),             # stride 2, >32 input channels, odd sizes
+    (2, 3, [3], 12, 40, 44, 5, 1, 2, 1),               # 5x5 with <= 8 input channels: paired-tap weight gradient (enc_0)
+    (1, 2, [8], 12, 30, 30, 5, 1, 2, 0),
 ]
 
 
