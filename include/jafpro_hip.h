@@ -187,6 +187,9 @@ typedef struct jaf_packed_io {
     int32_t dst_img_off;     /* destination image index = n + dst_img_off */
     int32_t dst_pad_tail;    /* also write zeros to the channels up to the next multiple of 8 (last source of the image) */
     int32_t skip_f32;        /* do not write the fp32 output tensor (its pointer may be NULL) */
+    int32_t accumulate_f32;  /* out += result instead of out = result (plain convolution launches only): the second data
+                              * gradient of a tensor with two consumers lands in the first one's buffer, replacing the
+                              * separate three-pass add of the autograd engine */
 } jaf_packed_io;
 int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                              const void* packed_in, const void* packed_w, const float* bias, float* out,

@@ -50,6 +50,7 @@ struct ConvDArgs {
     unsigned char* dst;    // destination packed image (nullable)
     int dst_ng8, dst_coff, dst_img_off, dst_pad_tail;
     int skip_f32;          // the fp32 output tensor is not written (nobody reads it)
+    int acc_out;           // out += result (jaf_packed_io.accumulate_f32)
 };
 
 // Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
@@ -958,6 +959,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                             fvec o;                                                                   \
                             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
                                 o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
+                            if (a.acc_out) o += *(const fvec*)(op + opix[0]);                         \
                             *(fvec*)(op + opix[0]) = o;                                               \
                             if (ST_) {                                                                \
                                 _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { st1 += o[nt]; st2 += o[nt] * o[nt]; } \
@@ -966,7 +968,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     } else {                                                                          \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
                             if (opix[nt] >= 0) {                                                      \
-                                const float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);           \
+                                float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                 \
+                                if (a.acc_out) v += op[opix[nt]];                                     \
                                 op[opix[nt]] = v;                                                     \
                                 if (ST_) { st1 += v; st2 += v * v; }                                  \
                             }                                                                         \
@@ -1488,6 +1491,7 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.dst = nullptr;
     a.dst_ng8 = a.dst_coff = a.dst_img_off = a.dst_pad_tail = 0;
     a.skip_f32 = 0;
+    a.acc_out = 0;
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1502,6 +1506,7 @@ static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm)
     } else if (io->skip_f32 && !lstm) {
         return false;                                         // a launch that writes nothing
     }
+    if (io->accumulate_f32 && (lstm || io->skip_f32)) return false;
     return true;
 }
 
@@ -1514,6 +1519,7 @@ static void cd_apply_io(ConvDArgs& a, const jaf_packed_io* io) {
     a.dst_img_off = io->dst_img_off;
     a.dst_pad_tail = io->dst_pad_tail ? 1 : 0;
     a.skip_f32 = io->skip_f32 ? 1 : 0;
+    a.acc_out = io->accumulate_f32 ? 1 : 0;
 }
 
 extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,

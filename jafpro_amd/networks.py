@@ -120,6 +120,8 @@ class _PartEncoderMixin:
             x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2,
                             prepacked=img_in, dst=dst, keep_f32=keep)
             if i % 2 == 0:
+                if tap is not None and i < 8:
+                    ops.mark_two_consumers(x)      # read by this level's ConvLSTM and by enc_{i+1}, and by nothing else
                 feats.append(x if tap is None else tap(i // 2, x, img_out))
             img_in = img_out
         return feats     # x1, x3, x5, x7, x9 (or what `tap` made of them)
@@ -177,7 +179,7 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
         def lstm(level, f, image):
             # runs right after the encoder layer that made f: the ConvLSTM only needs that level, and on the packed path it
             # completes the [x, h] image before enc_{i+1} reads x out of it
-            seq = f.view(T, B, f.shape[1], f.shape[2], f.shape[3])
+            seq = ops.share_gradslot(f, f.view(T, B, f.shape[1], f.shape[2], f.shape[3]))
             h, _ = ops.convlstm(seq, getattr(self, "lstm%d_w" % (level + 1)), getattr(self, "lstm%d_b" % (level + 1)),
                                 groups=NPARTS, return_all=False, seq_image=image)
             return h

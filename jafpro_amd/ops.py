@@ -8,6 +8,7 @@ CHECK_CONTIGUOUS, rasterize_cuda.cpp:66-68).
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import weakref
 from typing import List, Optional, Sequence, Tuple
@@ -337,10 +338,12 @@ def packed_active() -> bool:
     return _PACKED_IMAGES and _USE_PACKED and _PRECISION == PREC_BF16
 
 
-def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False) -> Optional[PackedIO]:
-    if prepacked is None and dst is None:
+def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False,
+               accumulate: bool = False) -> Optional[PackedIO]:
+    if prepacked is None and dst is None and not accumulate:
         return None
     io = PackedIO()
+    io.accumulate_f32 = 1 if accumulate else 0
     io.in_ng8_tot = prepacked.ng8 if prepacked is not None else 0
     if dst is not None:
         io.dst = dst.image.buf.data_ptr()
@@ -515,8 +518,12 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
               bias: Optional[torch.Tensor], N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
               xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
-              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False, lazy=None):
+              prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False, lazy=None,
+              accumulate: bool = False):
+    """`accumulate`: out += result (packed bf16 path only; `out` must be given): see GradSlot."""
     skip_f32 = skip_f32 and dst is not None and ln_stats is None
+    if accumulate and (out is None or skip_f32):
+        raise RuntimeError("conv: accumulate needs an existing fp32 output")
     if out is None:
         out_ctot = G * Cout
         if skip_f32:
@@ -541,7 +548,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
             if dst.img_off + N > dst.image.N:
                 raise RuntimeError("conv2d destination: images %d..%d outside the packed image (%d)" % (dst.img_off, dst.img_off + N, dst.image.N))
-        io = _io_struct(prepacked, dst, skip_f32)
+        io = _io_struct(prepacked, dst, skip_f32, accumulate)
         sums = None
         if ln_stats is not None:
             ln_stats.filled = False
@@ -558,6 +565,8 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if ev is not None:
             _PROF.end("conv_dma_kernel<%d, %d, false>" % (pl.MT, pl.NT), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
+    if accumulate:
+        raise RuntimeError("conv: accumulate is a feature of the packed bf16 path")
     ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
     ev = _PROF.begin() if _PROF is not None else None
     check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
@@ -576,6 +585,47 @@ def _grad_inplace(p: torch.Tensor) -> bool:
         return False
     g = p.grad
     return g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape
+
+
+class GradSlot:
+    """Where the data gradients of a tensor with exactly TWO consumers meet -- both of them convolutions / ConvLSTMs of
+    this module (the accumulate network's skip features: the level's ConvLSTM and enc_{i+1}, src/networks.py:1290-1357).
+    The consumer whose backward runs first returns its gradient tensor as usual and leaves it here; the second one lets
+    its data-gradient kernel add into that buffer (jaf_packed_io.accumulate_f32) and returns no gradient, so the autograd
+    engine's separate three-pass add (900 us for the 200 x 200 level at B = 8) disappears.  Attach with `mark_two_consumers`
+    ONLY when every consumer of the tensor honours the slot: a third consumer would make the engine replace the buffer."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+    def take(self, shape):
+        """The first gradient, viewed as `shape`, if the second consumer may add into it (bf16 packed path); clears the slot."""
+        b, self.buf = self.buf, None
+        if b is None or not _packed_path_now() or not b.is_contiguous() or b.dtype != torch.float32 or b.numel() != math.prod(shape):
+            return None
+        return b.view(shape)
+
+
+def mark_two_consumers(t: torch.Tensor) -> torch.Tensor:
+    if t.requires_grad and packed_active():
+        t._jaf_gradslot = GradSlot()
+    return t
+
+
+def share_gradslot(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
+    """`view` (a reshape of `src` handed to the other consumer) meets `src`'s gradients in the same slot."""
+    slot = getattr(src, "_jaf_gradslot", None)
+    if slot is not None:
+        view._jaf_gradslot = slot
+    return view
+
+
+SLOT_STATS = {"first": 0, "added": 0}        # how often a slot received a first gradient / an in-place second one (tests)
+
+
+def _slot_of(t) -> Optional["GradSlot"]:
+    return getattr(t, "_jaf_gradslot", None)
 
 
 class _ConvMeta:
@@ -631,6 +681,7 @@ class _ConvFn(Function):
         ctx.mode = (_PRECISION, _USE_PACKED)
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
+        ctx.slots = [_slot_of(t) for t in srcs]
         ctx.save_for_backward(weight, y if m.act != ACT_NONE else None, *srcs)
         return y
 
@@ -705,11 +756,20 @@ class _ConvFn(Function):
             if ctx.needs_input_grad[3 + i]:
                 # transposed convolution: rows = this source's channels, reduction = Cout
                 spec = [(m.Cout, m.G * m.Cout, 0, m.Cout)]
+                slot = ctx.slots[i] if gs != 0 else None
+                first = slot.take((m.N, m.G * c, m.H, m.W)) if slot is not None else None
                 g, dzp = _conv_raw([dz] if dz is not None else [dy], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
                                    m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0, xp=dzp,
-                                   want_xp=True)
+                                   want_xp=True, out=first, out_ctot=(m.G * c) if first is not None else None,
+                                   accumulate=first is not None)
                 if gs == 0:      # source shared by all groups: sum the per-group gradients
                     g = g.view(m.N, m.G, c, m.H, m.W).sum(1)
+                if first is not None:
+                    g = None     # added into the other consumer's gradient (GradSlot)
+                    SLOT_STATS["added"] += 1
+                elif slot is not None:
+                    slot.buf = g
+                    SLOT_STATS["first"] += 1
                 dsrcs.append(g)
             else:
                 dsrcs.append(None)
@@ -882,6 +942,7 @@ class _ConvLSTMFn(Function):
         ctx.mode = (_PRECISION, _USE_PACKED)        # backward uses the arithmetic the forward ran in
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
+        ctx.slot = _slot_of(x)
         c_last = cs[T - 1].clone()
         if need_all:
             return hs, c_last
@@ -903,6 +964,13 @@ class _ConvLSTMFn(Function):
             dh_out = torch.zeros_like(hs) if ctx.need_all else torch.zeros_like(hs[0])
         dh_out = _c(dh_out)
         dx = torch.empty(x.shape, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        # x has a second consumer (enc_{i+1}) whose data gradient may already exist: add into it (GradSlot)
+        slot = getattr(ctx, "slot", None)
+        dx_first = None
+        if dx is not None and slot is not None and ctx.xps is not None and _packed_path_now():
+            dx_first = slot.take(tuple(x.shape))
+            if dx_first is not None:
+                dx = dx_first
         bias = ctx.bias_ref
         w_inplace, b_inplace = _grad_inplace(weight), _grad_inplace(bias)
         dw = weight.grad if w_inplace else torch.empty_like(weight)
@@ -976,13 +1044,20 @@ class _ConvLSTMFn(Function):
                       "jaf_channel_sum")
             if dx is not None:
                 _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
-                                   1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True)
+                                   1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True,
+                                   accumulate=dx_first is not None)
             if not first:
                 dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
             dc = dc_prev
         dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None
         dc0 = dc if (ctx.has_state and ctx.needs_input_grad[6]) else None
+        if dx_first is not None:
+            dx = None            # added into the other consumer's gradient
+            SLOT_STATS["added"] += 1
+        elif dx is not None and slot is not None:
+            slot.buf = dx
+            SLOT_STATS["first"] += 1
         return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0, None, None
 
 
