@@ -90,7 +90,7 @@ class _PartEncoderMixin:
             self._add("enc%d_b" % (i + 1), "Downsampler_list.{p}.enc%d.enconv.0.bias" % (i + 1), b)
             cin = c
 
-    def _encode(self, x, tap=None):
+    def _encode(self, x, tap=None, skips_feed_one_conv=False):
         """enc1..enc9 -> [x1, x3, x5, x7, x9].  On the packed bf16 path every layer writes its output straight into the
         next layer's packed input image (ops.PackedImage): no separate packing pass between the convolutions.
         `tap(level, x_level, image)` (accumulate: the ConvLSTM of that level) is called as soon as a skip feature exists;
@@ -120,8 +120,10 @@ class _PartEncoderMixin:
             x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2,
                             prepacked=img_in, dst=dst, keep_f32=keep)
             if i % 2 == 0:
-                if tap is not None and i < 8:
-                    ops.mark_two_consumers(x)      # read by this level's ConvLSTM and by enc_{i+1}, and by nothing else
+                if (tap is not None or skips_feed_one_conv) and i < 8:
+                    # read by enc_{i+1} and by exactly one more convolution / ConvLSTM (the level's ConvLSTM; the
+                    # inpainter's decoder): their two data gradients meet inside the second kernel (ops.GradSlot)
+                    ops.mark_two_consumers(x)
                 feats.append(x if tap is None else tap(i // 2, x, img_out))
             img_in = img_out
         return feats     # x1, x3, x5, x7, x9 (or what `tap` made of them)
@@ -181,7 +183,7 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
             # completes the [x, h] image before enc_{i+1} reads x out of it
             seq = ops.share_gradslot(f, f.view(T, B, f.shape[1], f.shape[2], f.shape[3]))
             h, _ = ops.convlstm(seq, getattr(self, "lstm%d_w" % (level + 1)), getattr(self, "lstm%d_b" % (level + 1)),
-                                groups=NPARTS, return_all=False, seq_image=image)
+                                groups=NPARTS, return_all=False, seq_image=image, return_state=False)
             return h
         lstm.T = T
         hs = self._encode(x, tap=lstm)
@@ -265,7 +267,7 @@ class UNet_inpainter(_GroupedStateDict, _PartEncoderMixin):
 
     def forward_grouped(self, x: torch.Tensor) -> torch.Tensor:
         """x: [B, 72, 200, 200] -> [B, 72, 200, 200]."""
-        feats = self._encode(x)
+        feats = self._encode(x, skips_feed_one_conv=True)     # x1..x7: enc_{i+1} and the decoder's skip input below
         embed = _lrelu_conv(feats[4], self.cmp_w, self.cmp_b)          # [B, 72, 13, 13] == cat of the 24 embeds (:1824)
         # dec1 input = up(cat[x9, global_embed]) ++ x7 ; bilinear is per channel so the cat is never built
         skip = feats[3]

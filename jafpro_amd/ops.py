@@ -869,7 +869,7 @@ def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=
 # --------------------------------------------------------------------------------------------
 class _ConvLSTMFn(Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0, seq_image=None, final_dst=None):
+    def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0, seq_image=None, final_dst=None, want_c: bool = True):
         # x: [T, N, G*C, H, W]; weight: [G*4C, 2C, 3, 3]; bias [G*4C]; h0/c0: [N, G*C, H, W] or None (zero state)
         # seq_image (packed bf16 path only): PackedImage of T*N images x 2C channels whose x halves the producer of `x`
         # already wrote; step t reads image block t and its epilogue writes h_t into block t+1 (final_dst: where h_T goes)
@@ -943,7 +943,7 @@ class _ConvLSTMFn(Function):
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
         ctx.slot = _slot_of(x)
-        c_last = cs[T - 1].clone()
+        c_last = cs[T - 1].clone() if want_c else None          # (a copy: cs is saved for backward)
         if need_all:
             return hs, c_last
         return hs[T - 1], c_last
@@ -1058,15 +1058,16 @@ class _ConvLSTMFn(Function):
         elif dx is not None and slot is not None:
             slot.buf = dx
             SLOT_STATS["first"] += 1
-        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0, None, None
+        return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0, None, None, None
 
 
 def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int = 1, return_all: bool = False,
              state: Optional[Tuple[torch.Tensor, torch.Tensor]] = None, seq_image: Optional[PackedImage] = None,
-             final_dst: Optional[PackedDst] = None):
+             final_dst: Optional[PackedDst] = None, return_state: bool = True):
     """x: [T, N, G*C, H, W] -> (h_T [N, G*C, H, W] or all h_t, c_T).  `state` = (h0, c0), default the zero
     state of src/convLSTM.py:58-63,119-120; gate order i,f,o,g (:46).  Differentiable w.r.t. x, the parameters,
-    the initial state, and through both h and c_T (T = 1 with a state is ConvLSTMCell.forward, :41-56)."""
+    the initial state, and through both h and c_T (T = 1 with a state is ConvLSTMCell.forward, :41-56).
+    `return_state=False`: c_T is not wanted (-> None), which saves its copy."""
     if not (seq_image is not None and packed_active() and state is None):     # x is then only the autograd edge
         _chk(x, "convlstm x")
     _chk(weight, "convlstm weight"); _chk(bias, "convlstm bias")
@@ -1075,7 +1076,7 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
         h0, c0 = _chk(state[0], "convlstm h0"), _chk(state[1], "convlstm c0")
         if h0.shape != x.shape[1:] or c0.shape != x.shape[1:]:
             raise RuntimeError("convlstm: state shape %s / %s does not match the input %s" % (tuple(h0.shape), tuple(c0.shape), tuple(x.shape[1:])))
-    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all, h0, c0, seq_image, final_dst)
+    return _ConvLSTMFn.apply(x, weight, bias, groups, return_all, h0, c0, seq_image, final_dst, return_state)
 
 
 # --------------------------------------------------------------------------------------------
