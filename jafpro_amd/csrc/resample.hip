@@ -86,6 +86,7 @@ struct ResizeArgs {
     int rw, rh;        // LDS kernels: pitch and rows of the staged region (floats)
     float inv_sy, inv_sx;
     int vec;           // LDS kernels: 16-byte staging allowed
+    int rows;          // resize_bwd_lds_kernel: input rows per lane (tile height = blockDim.y * rows)
 };
 
 __device__ __forceinline__ void resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
@@ -317,12 +318,15 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
 // the tile's first and last pixel (candidate ranges are monotonic in the pixel index).
 __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a) {
     extern __shared__ float s_reg[];
-    const int gx0 = blockIdx.x * blockDim.x, gy0 = blockIdx.y * blockDim.y;
-    const int gx = gx0 + threadIdx.x, gy = gy0 + threadIdx.y;
+    // a.rows input rows per lane: the tile is blockDim.x x (blockDim.y * a.rows) input pixels, so one staging round trip
+    // (all of a lane's 16-byte loads in flight before the first LDS store) serves a.rows times the outputs
+    const int TH = (int)blockDim.y * a.rows;
+    const int gx0 = blockIdx.x * blockDim.x, gy0 = blockIdx.y * TH;
+    const int gx = gx0 + threadIdx.x;
     const long nc = blockIdx.z;
     // tile -> crop-window coordinates, clipped (uniform)
     int ixf = gx0 - a.x0, ixl = gx0 + (int)blockDim.x - 1 - a.x0;
-    int iyf = gy0 - a.y0, iyl = gy0 + (int)blockDim.y - 1 - a.y0;
+    int iyf = gy0 - a.y0, iyl = gy0 + TH - 1 - a.y0;
     if (ixf < 0) ixf = 0;
     if (iyf < 0) iyf = 0;
     if (ixl > a.cw - 1) ixl = a.cw - 1;
@@ -342,18 +346,28 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
             rx0 &= ~3;
             if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;  // never taken: a.rw / a.rh bound the region (host)
             if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
-            const int w4 = (rx1 - rx0 + 4) >> 2, nr = ry1 - ry0 + 1, sy3 = blockDim.y;
-            for (int c4 = threadIdx.x; c4 < w4; c4 += blockDim.x) {
-                for (int r = threadIdx.y; r < nr; r += 3 * sy3) {
-                    const f32x4r z = {0.f, 0.f, 0.f, 0.f};
-                    const float* q = p + (long)(ry0 + r) * a.OW + rx0 + 4 * c4;
-                    const f32x4r v0 = *(const f32x4r*)q;
-                    const f32x4r v1 = (r + sy3 < nr) ? *(const f32x4r*)(q + (long)sy3 * a.OW) : z;
-                    const f32x4r v2 = (r + 2 * sy3 < nr) ? *(const f32x4r*)(q + 2L * sy3 * a.OW) : z;
-                    *(f32x4r*)(s_reg + r * a.rw + 4 * c4) = v0;
-                    if (r + sy3 < nr) *(f32x4r*)(s_reg + (r + sy3) * a.rw + 4 * c4) = v1;
-                    if (r + 2 * sy3 < nr) *(f32x4r*)(s_reg + (r + 2 * sy3) * a.rw + 4 * c4) = v2;
+            const int w4 = (rx1 - rx0 + 4) >> 2, nr = ry1 - ry0 + 1;
+            const int total4 = w4 * nr, tid = threadIdx.y * blockDim.x + threadIdx.x, nth = blockDim.x * blockDim.y;
+            const float inv_w4 = 1.0f / (float)w4;
+            for (int base = tid; base < total4; base += nth * 8) {
+                f32x4r v[8];
+                int so[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int idx = base + nth * u;
+                    so[u] = -1;
+                    if (idx < total4) {
+                        int r = (int)(((float)idx + 0.5f) * inv_w4);
+                        int c4 = idx - r * w4;
+                        if (c4 < 0) { --r; c4 += w4; }
+                        if (c4 >= w4) { ++r; c4 -= w4; }
+                        v[u] = *(const f32x4r*)(p + (long)(ry0 + r) * a.OW + rx0 + 4 * c4);
+                        so[u] = r * a.rw + 4 * c4;
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (so[u] >= 0) *(f32x4r*)(s_reg + so[u]) = v[u];
             }
         } else {
             if (rx1 > rx0 + a.rw - 1) rx1 = rx0 + a.rw - 1;
@@ -364,7 +378,10 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
         }
     }
     __syncthreads();
-    if (gx >= a.W || gy >= a.H) return;
+    if (gx >= a.W) return;
+    for (int rr = 0; rr < a.rows; ++rr) {
+    const int gy = gy0 + threadIdx.y + (int)blockDim.y * rr;
+    if (gy >= a.H) return;
     const int ix = gx - a.x0, iy = gy - a.y0;
     float acc = 0.f;
     if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
@@ -392,7 +409,7 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
                 acc += wy * ((wx[0] * row[cx[0]] + wx[1] * row[cx[1]]) + (wx[2] * row[cx[2]] + wx[3] * row[cx[3]]) + wx[4] * row[cx[4]]);
             }
             dx[(nc * a.H + gy) * a.W + gx] = acc;
-            return;
+            continue;
         }
         resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
         resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
@@ -426,6 +443,7 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
         }
     }
     dx[(nc * a.H + gy) * a.W + gx] = acc;
+    }
 }
 
 extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
@@ -437,20 +455,28 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
     resize_scales(a);
     JAF_REQUIRE(H <= 65535 && (long)N * C <= 65535);
     const dim3 b = block2d(W);      // (squarer 32x8 / 64x4 tiles stage fewer halo rows but measured 6-8 % slower)
-    // candidate region of one (b.x, b.y) tile: (pixels + 1) / scale + 4 per axis (resize_cand), capped by the image
-    long rw = a.sx > 0.f ? (long)ceilf(((float)b.x + 1.f) / a.sx) + 4 : OW;
-    long rh = a.sy > 0.f ? (long)ceilf(((float)b.y + 1.f) / a.sy) + 4 : OH;
-    if (rw > OW) rw = OW;
-    if (rh > OH) rh = OH;
     const bool vec = (OW % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
-    if (vec) rw = (rw + 3 + 3) / 4 * 4;        // start rounded down to a multiple of 4, pitch a multiple of 4
+    // candidate region of one (b.x, b.y * rows) tile: (pixels + 1) / scale + 4 per axis (resize_cand), capped by the image.
+    // rows per lane: as many (<= 4) as keep the region within 40 KB and leave the launch >= 2048 workgroups
+    long rw = 0, rh = 0;
+    int rows = 4;
+    for (;; rows >>= 1) {
+        rw = a.sx > 0.f ? (long)ceilf(((float)b.x + 1.f) / a.sx) + 4 : OW;
+        rh = a.sy > 0.f ? (long)ceilf(((float)(b.y * rows) + 1.f) / a.sy) + 4 : OH;
+        if (rw > OW) rw = OW;
+        if (rh > OH) rh = OH;
+        if (vec) rw = (rw + 3 + 3) / 4 * 4;        // start rounded down to a multiple of 4, pitch a multiple of 4
+        const long blocks = (long)jaf_cdiv(W, b.x) * jaf_cdiv(H, b.y * rows) * N * C;
+        if (rows == 1 || (rw * rh * 4 <= 40 * 1024 && blocks >= 2048)) break;
+    }
     if (rw * rh * 4 <= 48 * 1024) {
         a.rw = (int)rw;
         a.rh = (int)rh;
         a.vec = vec ? 1 : 0;
+        a.rows = rows;
         a.inv_sx = a.sx > 0.f ? 1.0f / a.sx : 0.f;
         a.inv_sy = a.sy > 0.f ? 1.0f / a.sy : 0.f;
-        hipLaunchKernelGGL(resize_bwd_lds_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C), b, (size_t)(rw * rh * 4),
+        hipLaunchKernelGGL(resize_bwd_lds_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y * rows), N * C), b, (size_t)(rw * rh * 4),
                            (hipStream_t)s, dy, dx, a);
     } else {
         hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C), b, 0, (hipStream_t)s, dy, dx, a);

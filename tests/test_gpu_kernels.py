@@ -304,6 +304,20 @@ def test_resize_bilinear(H, W, OH, OW, ac):
     assert maxerr(xd.grad, xr.grad) <= 1e-5
 
 
+@pytest.mark.parametrize("C,H,W,OH,OW,ac", [(2400, 50, 50, 100, 100, True), (2400, 37, 41, 74, 82, False), (1200, 64, 48, 100, 100, True)])
+def test_resize_adjoint_many_planes(C, H, W, OH, OW, ac):
+    """Launches with >= 2048 workgroups take the tall-tile form of the adjoint kernel (several input rows per lane, all of a
+    lane's staging loads in flight at once): against ATen's bilinear backward."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(1, C, H, W, generator=g) - 0.5).cuda().requires_grad_(True)
+    proj = (torch.rand(1, C, OH, OW, generator=g) - 0.5).cuda()
+    ops.resize(x, (OH, OW), ac).mul(proj).sum().backward()
+    xr = x.detach().cpu().double().requires_grad_(True)
+    (F.interpolate(xr, size=(OH, OW), mode="bilinear", align_corners=ac) * proj.cpu().double()).sum().backward()
+    assert maxerr(x.grad, xr.grad) <= 1e-5
+
+
 def test_resize_crop_and_nearest():
     """face crops, train/4...py:342-350: bilinear (AC=False) and nearest to 64x64 of a box."""
     ops = _ops()
