@@ -190,6 +190,11 @@ typedef struct jaf_packed_io {
     int32_t accumulate_f32;  /* out += result instead of out = result (plain convolution launches only): the second data
                               * gradient of a tensor with two consumers lands in the first one's buffer, replacing the
                               * separate three-pass add of the autograd engine */
+    float* out2;             /* second fp32 output (NULL: none): rows >= split_rows of every group go to out2 [N, G*(Cout-split_rows),
+                              * OH, OW], rows below it to `out` taken as [N, G*split_rows, OH, OW] (the descriptor's out_ctot /
+                              * out_coff then only have to be valid for Cout rows; they are not used).  The ConvLSTM's
+                              * data gradient w.r.t. [x_t, h_{t-1}] in ONE launch: the gate gradients are read once */
+    int32_t split_rows;
 } jaf_packed_io;
 int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                              const void* packed_in, const void* packed_w, const float* bias, float* out,

@@ -80,7 +80,8 @@ class PackedIO(ctypes.Structure):
     """jaf_packed_io (include/jafpro_hip.h)."""
     _fields_ = [("in_ng8_tot", ctypes.c_int32), ("dst", ctypes.c_void_p), ("dst_ng8_tot", ctypes.c_int32),
                 ("dst_coff", ctypes.c_int32), ("dst_img_off", ctypes.c_int32), ("dst_pad_tail", ctypes.c_int32),
-                ("skip_f32", ctypes.c_int32), ("accumulate_f32", ctypes.c_int32)]
+                ("skip_f32", ctypes.c_int32), ("accumulate_f32", ctypes.c_int32),
+                ("out2", ctypes.c_void_p), ("split_rows", ctypes.c_int32)]
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4

@@ -51,6 +51,8 @@ struct ConvDArgs {
     int dst_ng8, dst_coff, dst_img_off, dst_pad_tail;
     int skip_f32;          // the fp32 output tensor is not written (nobody reads it)
     int acc_out;           // out += result (jaf_packed_io.accumulate_f32)
+    float* out2;           // rows >= split of every group go here (jaf_packed_io.out2); nullptr: everything to `out`
+    int split;
 };
 
 // Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
@@ -953,13 +955,17 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
                 if (co < d.Cout) {                                                                    \
                     const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
-                    float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;  \
+                    const bool second = a.out2 && co >= a.split;                                      \
+                    float* op = second ? a.out2 + (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW \
+                                       : (a.out2 ? a.out + (((long)n * d.G + g) * a.split + co) * OHW        \
+                                                 : a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW);  \
+                    const bool accp = a.acc_out && !second;                                           \
                     if (vec) {                                                                        \
                         if (opix[0] >= 0) {                                                           \
                             fvec o;                                                                   \
                             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
                                 o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
-                            if (a.acc_out) o += *(const fvec*)(op + opix[0]);                         \
+                            if (accp) o += *(const fvec*)(op + opix[0]);                              \
                             *(fvec*)(op + opix[0]) = o;                                               \
                             if (ST_) {                                                                \
                                 _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { st1 += o[nt]; st2 += o[nt] * o[nt]; } \
@@ -969,7 +975,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
                             if (opix[nt] >= 0) {                                                      \
                                 float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                 \
-                                if (a.acc_out) v += op[opix[nt]];                                     \
+                                if (accp) v += op[opix[nt]];                                          \
                                 op[opix[nt]] = v;                                                     \
                                 if (ST_) { st1 += v; st2 += v * v; }                                  \
                             }                                                                         \
@@ -1492,6 +1498,8 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.dst_ng8 = a.dst_coff = a.dst_img_off = a.dst_pad_tail = 0;
     a.skip_f32 = 0;
     a.acc_out = 0;
+    a.out2 = nullptr;
+    a.split = 0;
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1507,6 +1515,7 @@ static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm)
         return false;                                         // a launch that writes nothing
     }
     if (io->accumulate_f32 && (lstm || io->skip_f32)) return false;
+    if (io->out2 && (lstm || io->skip_f32 || io->dst || io->split_rows < 1 || io->split_rows >= d->Cout)) return false;
     return true;
 }
 
@@ -1520,6 +1529,8 @@ static void cd_apply_io(ConvDArgs& a, const jaf_packed_io* io) {
     a.dst_pad_tail = io->dst_pad_tail ? 1 : 0;
     a.skip_f32 = io->skip_f32 ? 1 : 0;
     a.acc_out = io->accumulate_f32 ? 1 : 0;
+    a.out2 = io->out2;
+    a.split = io->out2 ? io->split_rows : 0;
 }
 
 extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
@@ -1527,7 +1538,7 @@ extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, 
                                         double* stats, int32_t stat_slots, const jaf_packed_io* io) {
     JAF_REQUIRE(cd_desc_ok(d) && cd_plan_ok(d, plan) && packed_in && packed_w && cd_io_ok(d, io, false));
     JAF_REQUIRE(out || (io && io->skip_f32));
-    JAF_REQUIRE(!stats || (d->act == JAF_ACT_NONE && d->G == 1 && stat_slots >= 1 && stat_slots <= 64 && !(io && io->skip_f32)));
+    JAF_REQUIRE(!stats || (d->act == JAF_ACT_NONE && d->G == 1 && stat_slots >= 1 && stat_slots <= 64 && !(io && (io->skip_f32 || io->out2))));
     ConvDArgs a;
     cd_fill(a, d, plan);
     cd_apply_io(a, io);

@@ -339,11 +339,13 @@ def packed_active() -> bool:
 
 
 def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False,
-               accumulate: bool = False) -> Optional[PackedIO]:
-    if prepacked is None and dst is None and not accumulate:
+               accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0) -> Optional[PackedIO]:
+    if prepacked is None and dst is None and not accumulate and out2 is None:
         return None
     io = PackedIO()
     io.accumulate_f32 = 1 if accumulate else 0
+    if out2 is not None:
+        io.out2, io.split_rows = out2.data_ptr(), split
     io.in_ng8_tot = prepacked.ng8 if prepacked is not None else 0
     if dst is not None:
         io.dst = dst.image.buf.data_ptr()
@@ -519,8 +521,10 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
               xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
               prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False, lazy=None,
-              accumulate: bool = False):
-    """`accumulate`: out += result (packed bf16 path only; `out` must be given): see GradSlot."""
+              accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0):
+    """`accumulate`: out += result (packed bf16 path only; `out` must be given): see GradSlot.
+    `out2`, `split`: rows >= split of every group go to out2 [N, G*(Cout-split), OH, OW], the others to `out` taken as
+    [N, G*split, OH, OW] (pass out_ctot = G*Cout): jaf_packed_io.out2."""
     skip_f32 = skip_f32 and dst is not None and ln_stats is None
     if accumulate and (out is None or skip_f32):
         raise RuntimeError("conv: accumulate needs an existing fp32 output")
@@ -548,7 +552,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
             if dst.img_off + N > dst.image.N:
                 raise RuntimeError("conv2d destination: images %d..%d outside the packed image (%d)" % (dst.img_off, dst.img_off + N, dst.image.N))
-        io = _io_struct(prepacked, dst, skip_f32, accumulate)
+        io = _io_struct(prepacked, dst, skip_f32, accumulate, out2, split)
         sums = None
         if ln_stats is not None:
             ln_stats.filled = False
@@ -565,8 +569,8 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if ev is not None:
             _PROF.end("conv_dma_kernel<%d, %d, false>" % (pl.MT, pl.NT), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
-    if accumulate:
-        raise RuntimeError("conv: accumulate is a feature of the packed bf16 path")
+    if accumulate or out2 is not None:
+        raise RuntimeError("conv: accumulate / out2 are features of the packed bf16 path")
     ps = [_p(t) for t in srcs] + [None] * (3 - len(srcs))
     ev = _PROF.begin() if _PROF is not None else None
     check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
@@ -867,6 +871,10 @@ def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=
 # --------------------------------------------------------------------------------------------
 # ConvLSTM (whole sequence, one autograd node; BPTT in backward)
 # --------------------------------------------------------------------------------------------
+# widest [x, h] data gradient taken in one launch (see _ConvLSTMFn._backward); measured: a gain up to 48 rows (levels with 12 and 24 hidden channels), none above
+_LSTM_FUSED_DGRAD_MAX_ROWS = int(os.environ.get("JAF_LSTM_FUSED_DGRAD_MAX_ROWS", "48"))
+
+
 class _ConvLSTMFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0, seq_image=None, final_dst=None, want_c: bool = True):
@@ -1042,13 +1050,21 @@ class _ConvLSTMFn(Function):
                     _PROF.end(wname, 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
                       "jaf_channel_sum")
-            if dx is not None:
-                _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
-                                   1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True,
-                                   accumulate=dx_first is not None)
-            if not first:
-                dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
-                               1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
+            if dx is not None and not first and fused and 2 * C <= _LSTM_FUSED_DGRAD_MAX_ROWS:
+                # d[x_t, h_{t-1}] in one launch: 2C rows per group, the x rows into dx[t], the h rows into dh -- the packed gate
+                # gradients (4C channels) are read once instead of twice
+                dh = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
+                _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, 2 * C, H, W, H, W, 3, 3, 1, 1, 1,
+                                   1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=2 * GC, out_coff=0, xp=gtp, want_xp=True,
+                                   accumulate=dx_first is not None, out2=dh, split=C)
+            else:
+                if dx is not None:
+                    _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
+                                       1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True,
+                                       accumulate=dx_first is not None)
+                if not first:
+                    dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
+                                   1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
             dc = dc_prev
         dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None
         dc0 = dc if (ctx.has_state and ctx.needs_input_grad[6]) else None
