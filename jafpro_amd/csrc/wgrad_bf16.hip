@@ -362,6 +362,16 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
         const int nimg_ = d->precision == JAF_PREC_BF16X3 ? 2 : 1;
         while (a.WC > 1 && nimg_ * (a.WC * ph * pwp * 32 + 16 * MTW * WB_DZP) + 16 * a.WC * 12 + 16 > 160 * 1024) a.WC >>= 1;
     }
+    {   // a launch that cannot fill the chip (the discriminators' 8x8 ... 64x64 layers: 8-64 pixel tiles in all) is one long
+        // serial chain per workgroup -- 25 us whatever the size; smaller output blocks give more, shorter workgroups
+        const long items0 = (long)d->N * jaf_cdiv(d->OW, WB_TW) * jaf_cdiv(d->OH, WB_TH);
+        const long sp = items0 < JAF_WGRAD_MAX_SPLIT ? items0 : JAF_WGRAD_MAX_SPLIT;
+        while ((long)d->G * jaf_cdiv(d->Cout, 16 * MTW) * jaf_cdiv(d->Cin, 16 * a.WC) * sp < 512) {
+            if (MTW > 1) MTW = (MTW == 4) ? 2 : 1;
+            else if (a.WC > 1) a.WC >>= 1;
+            else break;
+        }
+    }
     a.WK = 4 / a.WC;
     a.coblocks = jaf_cdiv(d->Cout, 16 * MTW);
     a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);

@@ -330,6 +330,15 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
         if (pad < bestPad) { bestPad = pad; MTW = mt; }
     }
     a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
+    {   // launches that cannot fill the chip: smaller output blocks = more, shorter workgroups (see jafb_wgrad)
+        const long items0 = (long)d->N * jaf_cdiv(d->OW, WD_TW) * jaf_cdiv(d->OH, WD_TH);
+        const long sp = items0 < JAF_WGRAD_MAX_SPLIT ? items0 : JAF_WGRAD_MAX_SPLIT;
+        while (KS != 5 && (long)d->G * jaf_cdiv(d->Cout, 16 * MTW) * jaf_cdiv(d->Cin, 16 * a.WC) * sp < 512) {
+            if (MTW > 1) MTW = (MTW == 4) ? 2 : 1;
+            else if (a.WC > 1) a.WC >>= 1;
+            else break;
+        }
+    }
     a.WK = 4 / a.WC;
     a.coblocks = jaf_cdiv(d->Cout, 16 * MTW);
     a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);

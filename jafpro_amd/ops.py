@@ -112,7 +112,7 @@ class _arith:
         return False
 
 
-def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16) -> str:
+def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, OH: int = 1 << 20, OW: int = 1 << 20) -> str:
     """Template instantiation jaf_conv2d_wgrad_packed launches (same rule as csrc/wgrad_dma.hip), so that the
     bench's per-kernel rows carry the names rocprofv3 reports."""
     mt_best, pad_best = 1, None
@@ -120,6 +120,16 @@ def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16) -> str:
         pad = -(-Cout // (16 * mt)) * 16 * mt
         if pad_best is None or pad < pad_best:
             mt_best, pad_best = mt, pad
+    if KS != 5:        # launches that cannot fill the chip use smaller output blocks
+        wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
+        sp = min(N * -(-OW // 16) * -(-OH // 8), 96)
+        while G * -(-Cout // (16 * mt_best)) * -(-Cin // (16 * wc)) * sp < 512:
+            if mt_best > 1:
+                mt_best = 2 if mt_best == 4 else 1
+            elif wc > 1:
+                wc >>= 1
+            else:
+                break
     return "conv_wgrad_dma_kernel<%d, %d, %s>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false")
 
 
@@ -654,7 +664,7 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool):
             dzp = pack_input([dz], dzd)
         check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
                                            1 if inplace else 0), "jaf_conv2d_wgrad_packed_ex")
-        wname = _wgrad_dma_name(m.Cout, m.KH, m.Cin)
+        wname = _wgrad_dma_name(m.Cout, m.KH, m.Cin, m.G, m.N, m.OH, m.OW)
     else:
         check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
               "jaf_conv2d_wgrad")
@@ -1026,7 +1036,7 @@ class _ConvLSTMFn(Function):
                     check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
                                                        1 if w_inplace else acc), "jaf_conv2d_wgrad_packed_ex")
                     if ev is not None:
-                        _PROF.end(_wgrad_dma_name(4 * C, 3), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                        _PROF.end(_wgrad_dma_name(4 * C, 3, Cin, G, N, H, W), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:
                     gtp.record_stream(wst)
                     ctx.xps[t].record_stream(wst)
@@ -1041,7 +1051,7 @@ class _ConvLSTMFn(Function):
                     gtp = pack_input([gt], gd)
                     check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
                                                        1 if w_inplace else acc), "jaf_conv2d_wgrad_packed_ex")
-                    wname = _wgrad_dma_name(4 * C, 3)
+                    wname = _wgrad_dma_name(4 * C, 3, Cin, G, N, H, W)
                 else:
                     check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hprev), None,
                                              _p(gt), _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
