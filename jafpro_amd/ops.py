@@ -264,6 +264,19 @@ def _plan(key, d: ConvDesc, lstm: int, flags: int = 0) -> ConvPlan:
     return pl
 
 
+def _lazy_pack_name(H: int, W: int, lazies) -> str:
+    """Kernel jaf_conv2d_pack_input_resized launches (same rule as csrc/conv_dma.hip), for the bench's per-kernel rows."""
+    staged = W >= 48
+    for sh, sw, al in lazies:
+        sy = ((sh - 1) / (H - 1) if H > 1 else 0.0) if al else sh / H
+        sx = ((sw - 1) / (W - 1) if W > 1 else 0.0) if al else sw / W
+        if (math.ceil(sy * 16) + 3) * (math.ceil(sx * 64) + 3) > 1280:
+            staged = False
+    if not staged:
+        return "conv_pack_input_lazy_kernel"
+    return "conv_pack_input_lazy_lds_kernel<%d>" % (4 if W % 4 == 0 else 1)
+
+
 def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc, lazy=None) -> torch.Tensor:
     """bf16 [N][G][ceil(Cin/8)][H][W][8] image of a descriptor's (concatenated, grouped) input: converted
     once, consumed by the forward conv and the weight gradient (or by dgrad and wgrad for a dz)."""
@@ -286,7 +299,8 @@ def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc, lazy=None) -> torch.Te
             else:
                 real.append(l[0])
                 sh[i], sw[i], al[i] = int(l[0].shape[2]), int(l[0].shape[3]), 1 if l[1] else 0
-        with _hbm("conv_pack_input_lazy_kernel", sum(4.0 * r.numel() * (1 if l is not None else 1) for r, l in zip(real, lazy)) + nbytes):
+        name = _lazy_pack_name(d.H, d.W, [(sh[i], sw[i], al[i]) for i, l in enumerate(lazy) if l is not None]) if _PROF is not None else ""
+        with _hbm(name, sum(4.0 * r.numel() for r in real) + nbytes):
             per = nbytes // d.N
             for n0, n1 in chunks:
                 dc = type(d).from_buffer_copy(d)
