@@ -393,6 +393,52 @@ int jaf_rasterize_bwd_pixel_map(jaf_stream_t s, const float* faces, const int32_
 int jaf_rasterize_bwd_depth_map(jaf_stream_t s, const float* faces, const float* depth_map,
                                 const int32_t* face_index_map, const float* face_inv_map, const float* weight_map,
                                 const float* grad_depth_map, float* grad_faces, int32_t B, int32_t NF, int32_t S);
+/* forward_texture_sampling of the reference FFI (rasterize_cuda.cpp:97-122, kernel rasterize_cuda_kernel.cu:171-243)
+ * fused with forward_background (rasterize.py:194-202): rgb_map [B,S,S,3] = trilinear sample of the hit face's texture
+ * block textures[B,NF,ts,ts,ts,3] at (weight_k * (ts-1) * depth / z_k), `background` ([3], or [B,3] when bg_per_image)
+ * where no face is hit.  Maps UNFLIPPED.  sampling_index_map int32 [B,S,S,8] / sampling_weight_map [B,S,S,8] are the
+ * reference's saved-for-backward maps; both NULLABLE here -- jaf_rasterize_texture_bwd_rebuild re-derives them. */
+int jaf_rasterize_texture_fwd(jaf_stream_t s, const float* faces, const float* textures, const int32_t* face_index_map,
+                              const float* weight_map, const float* depth_map, float* rgb_map,
+                              int32_t* sampling_index_map, float* sampling_weight_map, const float* background,
+                              int bg_per_image, int32_t B, int32_t NF, int32_t S, int32_t ts, float eps);
+/* backward_textures (rasterize_cuda.cpp:149-167, kernel :506-541): grad_textures[B,NF,ts,ts,ts,3] += w * grad_rgb. */
+int jaf_rasterize_texture_bwd(jaf_stream_t s, const int32_t* face_index_map, const float* sampling_weight_map,
+                              const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures,
+                              int32_t B, int32_t NF, int32_t S, int32_t ts);
+/* The same adjoint without the two sampling maps: taps rebuilt from the face / weight / depth maps (saves 128 B/pixel). */
+int jaf_rasterize_texture_bwd_rebuild(jaf_stream_t s, const float* faces, const int32_t* face_index_map,
+                                      const float* weight_map, const float* depth_map, const float* grad_rgb_map,
+                                      float* grad_textures, int32_t B, int32_t NF, int32_t S, int32_t ts, float eps);
+/* neural_renderer.lighting (lighting.py:6-58; src/nmr.py:219-229): textures_out = textures_in * light with
+ * light[b,f,c] = ia*ca[c] + id*cd[c]*relu(normal_f . direction), normal_f = normalize((v0-v1) x (v2-v1), eps 1e-5) of
+ * faces[B,NF,3,3].  The three colour / direction arguments are HOST float[3]; in == out is allowed (the reference
+ * multiplies in place); light_out [B,NF,3] nullable. */
+int jaf_lighting_fwd(jaf_stream_t s, const float* faces, const float* textures_in, float* textures_out, float* light_out,
+                     float intensity_ambient, float intensity_directional, const float* color_ambient,
+                     const float* color_directional, const float* direction, int32_t B, int32_t NF, int32_t ts);
+/* Its adjoint: grad_textures_in = grad_out * light (nullable), grad_faces[B,NF,3,3] (nullable; zero unless id != 0). */
+int jaf_lighting_bwd(jaf_stream_t s, const float* faces, const float* textures_in, const float* grad_out,
+                     float* grad_textures_in, float* grad_faces, float intensity_ambient, float intensity_directional,
+                     const float* color_ambient, const float* color_directional, const float* direction, int32_t B,
+                     int32_t NF, int32_t ts);
+/* SMPLRenderer.dynamic_sampler (src/nmr.py:388-395, :445-477): sampler[B,NF,TT,2] = clamp(p2 + (p0-p2)*coords[0,j] +
+ * (p1-p2)*coords[1,j], -1, 1), p_k = cam_s * (verts[faces_idx[f,k]].xy + cam_t); coords [2,TT] (create_coords, :479-495). */
+int jaf_face_sampler_fwd(jaf_stream_t s, const float* verts, const float* cam, const int32_t* faces_idx,
+                         const float* coords, float* sampler, int32_t B, int32_t NV, int32_t NF, int32_t TT);
+/* Its adjoint: dverts[B,NV,3] += (x, y), dcam[B,3] += (nullable). */
+int jaf_face_sampler_bwd(jaf_stream_t s, const float* verts, const float* cam, const int32_t* faces_idx,
+                         const float* coords, const float* grad_sampler, float* dverts, float* dcam, int32_t B, int32_t NV,
+                         int32_t NF, int32_t TT);
+/* The layout half of SMPLRenderer.extract_tex (src/nmr.py:379-384): sampled[B,3,NF,T*T] -> tex[B,NF,T,T,T,3]. */
+int jaf_tex_expand_fwd(jaf_stream_t s, const float* sampled, float* tex, int32_t B, int32_t NF, int32_t T);
+int jaf_tex_expand_bwd(jaf_stream_t s, const float* grad_tex, float* grad_sampled, int32_t B, int32_t NF, int32_t T);
+/* neural_renderer.vertices_to_faces (vertices_to_faces.py:4-22): faces[B,NF,3,3] = verts[b, faces_idx[f,k]]; the adjoint
+ * adds into dverts[B,NV,3]. */
+int jaf_vertices_to_faces(jaf_stream_t s, const float* verts, const int32_t* faces_idx, float* faces, int32_t B, int32_t NV,
+                          int32_t NF);
+int jaf_vertices_to_faces_bwd(jaf_stream_t s, const float* dfaces, const int32_t* faces_idx, float* dverts, int32_t B,
+                              int32_t NV, int32_t NF);
 /* Adjoint of jaf_project_faces (autograd of src/nmr.py:269-276 in the reference): dverts[B,NV,3] += , dcam[B,3] +=
  * (nullable). */
 int jaf_project_faces_bwd(jaf_stream_t s, const float* dfaces, const float* verts, const float* cam,

@@ -18,9 +18,9 @@ LIB = os.path.join(HERE, "libjafpro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 SOURCES = ["conv.hip", "conv_bf16.hip", "conv_dma.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_dma.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
-           "raster.hip", "linear.hip", "ubench.hip", "input_pipeline.hip", "metrics.hip"]
+           "raster.hip", "raster_bwd.hip", "raster_texture.hip", "linear.hip", "ubench.hip", "input_pipeline.hip", "metrics.hip"]
 # raster.hip must keep the reference's fp32 expression trees (no FMA contraction): see its header.
-EXTRA = {"raster.hip": ["-ffp-contract=off"]}
+EXTRA = {"raster.hip": ["-ffp-contract=off"], "raster_bwd.hip": ["-ffp-contract=off"], "raster_texture.hip": ["-ffp-contract=off"]}
 # No packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in device code.  Measured on MI355X: with them,
 # flow_warp_fwd_kernel (`v_pk_mul_f32 ... op_sel` straight after 4-byte-aligned dwordx2 gathers) lost one product in 16 adjacent
 # lanes in 2-8 % of its launches while bf16 MFMA kernels of another stream shared the CUs; without them 0 of 720, and the step

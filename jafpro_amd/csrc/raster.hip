@@ -223,168 +223,7 @@ extern "C" int jaf_rasterize_maps(jaf_stream_t s_, const float* faces, int32_t* 
     return jaf_launch_status();
 }
 
-// ---------------------------------------------------------------------------------------------
-// backward_pixel_map (rasterize_cuda_kernel.cu:245-491): the silhouette / colour gradient w.r.t. the face
-// vertices.  A face's work is a walk along its three edges (a few dozen pixels), so one LANE per face as in the
-// reference; each lane owns its 9 outputs (no atomics) and the expression trees are kept (this file is built
-// with -ffp-contract=off) so the result is bit-identical to oracle/raster_oracle.c.
-// ---------------------------------------------------------------------------------------------
-__global__ void raster_bwd_pixel_map_kernel(const float* faces, const int* face_index_map, const float* rgb_map,
-                                            const float* alpha_map, const float* grad_rgb_map, const float* grad_alpha_map,
-                                            float* grad_faces, int total, int NF, int is, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const bool return_rgb = rgb_map && grad_rgb_map, return_alpha = alpha_map && grad_alpha_map;
-    const int bn = i / NF;
-    const int fn = i % NF;
-    const float* face = faces + (long)i * 9;
-    float grad_face[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if ((face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0])) return;
-    for (int edge_num = 0; edge_num < 3; edge_num++) {
-        int pi[3];
-        float pp[3][2];
-        for (int num = 0; num < 3; num++) pi[num] = (edge_num + num) % 3;
-        for (int num = 0; num < 3; num++)
-            for (int dim = 0; dim < 2; dim++) pp[num][dim] = (float)(0.5 * (double)(face[3 * pi[num] + dim] * is + is - 1));
-        for (int axis = 0; axis < 2; axis++) {
-            float p[3][2];
-            for (int num = 0; num < 3; num++)
-                for (int dim = 0; dim < 2; dim++) p[num][dim] = pp[num][(dim + axis) % 2];
-            int direction;
-            if (axis == 0) direction = (p[0][0] < p[1][0]) ? -1 : 1;
-            else direction = (p[0][0] < p[1][0]) ? 1 : -1;
-            const int d0_from = (int)fmax((double)ceilf(fminf(p[0][0], p[1][0])), 0.);
-            const int d0_to = (int)fmin((double)fmaxf(p[0][0], p[1][0]), is - 1.);
-            for (int d0 = d0_from; d0 <= d0_to; d0++) {
-                int d1_in, d1_out;
-                const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
-                if (0 < direction) d1_in = (int)floorf(d1_cross);
-                else d1_in = (int)ceilf(d1_cross);
-                d1_out = d1_in + direction;
-                if (d1_in < 0 || is <= d1_in) continue;
-                if (d1_out < 0 || is <= d1_out) continue;
-                float alpha_in = 0.f, alpha_out = 0.f;
-                const float *rgb_in = nullptr, *rgb_out = nullptr;
-                int map_index_in, map_index_out;
-                if (axis == 0) {
-                    map_index_in = bn * is * is + d1_in * is + d0;
-                    map_index_out = bn * is * is + d1_out * is + d0;
-                } else {
-                    map_index_in = bn * is * is + d0 * is + d1_in;
-                    map_index_out = bn * is * is + d0 * is + d1_out;
-                }
-                if (return_alpha) { alpha_in = alpha_map[map_index_in]; alpha_out = alpha_map[map_index_out]; }
-                if (return_rgb) { rgb_in = &rgb_map[(long)map_index_in * 3]; rgb_out = &rgb_map[(long)map_index_out * 3]; }
-                const int map_offset = (axis == 0) ? is : 1;
-                if (face_index_map[map_index_in] == fn) {     // "out": pixels beyond the edge
-                    const int d1_limit = (0 < direction) ? is - 1 : 0;
-                    const int d1_from = max(min(d1_out, d1_limit), 0);
-                    const int d1_to = min(max(d1_out, d1_limit), is - 1);
-                    long mp = (axis == 0) ? bn * is * is + d1_from * is + d0 : bn * is * is + d0 * is + d1_from;
-                    for (int d1 = d1_from; d1 <= d1_to; d1++, mp += map_offset) {
-                        float diff_grad = 0;
-                        if (return_alpha) diff_grad += (alpha_map[mp] - alpha_in) * grad_alpha_map[mp];
-                        if (return_rgb)
-                            for (int k = 0; k < 3; k++) diff_grad += (rgb_map[mp * 3 + k] - rgb_in[k]) * grad_rgb_map[mp * 3 + k];
-                        if (diff_grad <= 0) continue;
-                        if (p[1][0] != d0) {
-                            float dist = (float)((double)((p[1][0] - p[0][0]) / (p[1][0] - d0) * (d1 - d1_cross)) * 2. / is);
-                            dist = (0 < dist) ? dist + eps : dist - eps;
-                            grad_face[pi[0] * 3 + (1 - axis)] -= diff_grad / dist;
-                        }
-                        if (p[0][0] != d0) {
-                            float dist = (float)((double)((p[1][0] - p[0][0]) / (d0 - p[0][0]) * (d1 - d1_cross)) * 2. / is);
-                            dist = (0 < dist) ? dist + eps : dist - eps;
-                            grad_face[pi[1] * 3 + (1 - axis)] -= diff_grad / dist;
-                        }
-                    }
-                }
-                {                                             // "in": pixels of this face behind the edge
-                    float d0_cross2;
-                    if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0)
-                        d0_cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
-                    else
-                        d0_cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
-                    const int d1_limit = (0 < direction) ? (int)ceilf(d0_cross2) : (int)floorf(d0_cross2);
-                    const int d1_from = max(min(d1_in, d1_limit), 0);
-                    const int d1_to = min(max(d1_in, d1_limit), is - 1);
-                    long mp = (axis == 0) ? bn * is * is + d1_from * is + d0 : bn * is * is + d0 * is + d1_from;
-                    for (int d1 = d1_from; d1 <= d1_to; d1++, mp += map_offset) {
-                        if (face_index_map[mp] != fn) continue;
-                        float diff_grad = 0;
-                        if (return_alpha) diff_grad += (alpha_map[mp] - alpha_out) * grad_alpha_map[mp];
-                        if (return_rgb)
-                            for (int k = 0; k < 3; k++) diff_grad += (rgb_map[mp * 3 + k] - rgb_out[k]) * grad_rgb_map[mp * 3 + k];
-                        if (diff_grad <= 0) continue;
-                        if (p[1][0] != d0) {
-                            float dist = (float)((double)((p[1][0] - p[0][0]) / (p[1][0] - d0) * (d1 - d1_cross)) * 2. / is);
-                            dist = (0 < dist) ? dist + eps : dist - eps;
-                            grad_face[pi[0] * 3 + (1 - axis)] -= diff_grad / dist;
-                        }
-                        if (p[0][0] != d0) {
-                            float dist = (float)((double)((p[1][0] - p[0][0]) / (d0 - p[0][0]) * (d1 - d1_cross)) * 2. / is);
-                            dist = (0 < dist) ? dist + eps : dist - eps;
-                            grad_face[pi[1] * 3 + (1 - axis)] -= diff_grad / dist;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    for (int k = 0; k < 9; k++) grad_faces[(long)i * 9 + k] = grad_face[k];
-}
-
-extern "C" int jaf_rasterize_bwd_pixel_map(jaf_stream_t s, const float* faces, const int32_t* face_index_map,
-                                           const float* rgb_map, const float* alpha_map, const float* grad_rgb_map,
-                                           const float* grad_alpha_map, float* grad_faces, int32_t B, int32_t NF, int32_t S,
-                                           float eps) {
-    JAF_REQUIRE(faces && face_index_map && grad_faces && B >= 1 && NF >= 1 && S >= 1);
-    JAF_REQUIRE((rgb_map && grad_rgb_map) || (alpha_map && grad_alpha_map));
-    JAF_REQUIRE((long)B * NF <= 0x7fffffffL / 9 && (long)B * S * S <= 0x7fffffffL / 3);
-    hipLaunchKernelGGL(raster_bwd_pixel_map_kernel, dim3(jaf_cdiv((long)B * NF, 64)), dim3(64), 0, (hipStream_t)s, faces,
-                       face_index_map, rgb_map, alpha_map, grad_rgb_map, grad_alpha_map, grad_faces, B * NF, NF, S, eps);
-    return jaf_launch_status();
-}
-
-// backward_depth_map (rasterize_cuda_kernel.cu:537-593): per foreground pixel, 9 atomic adds into its face.
-__global__ void raster_bwd_depth_map_kernel(const float* faces, const float* depth_map, const int* face_index_map,
-                                            const float* face_inv_map, const float* weight_map, const float* grad_depth_map,
-                                            float* grad_faces, int B, int NF, int is) {
-    const long total = (long)B * is * is;
-    const long gs = (long)gridDim.x * blockDim.x;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
-        const int fn = face_index_map[i];
-        if (fn < 0) continue;
-        const int bn = (int)(i / ((long)is * is));
-        const float* face = faces + ((long)bn * NF + fn) * 9;
-        const float depth = depth_map[i];
-        const float depth2 = depth * depth;
-        const float* face_inv = face_inv_map + i * 9;
-        const float* weight = weight_map + i * 3;
-        const float grad_depth = grad_depth_map[i];
-        if (grad_depth == 0.f) continue;              // adds exact zeros: skipping them changes nothing
-        float* grad_face = grad_faces + ((long)bn * NF + fn) * 9;
-        for (int k = 0; k < 3; k++) {
-            const float z_k = face[3 * k + 2];
-            atomicAdd(&grad_face[3 * k + 2], grad_depth * weight[k] * depth2 / (z_k * z_k));
-        }
-        float tmp[3] = {0.f, 0.f, 0.f};
-        for (int k = 0; k < 3; k++)
-            for (int l = 0; l < 3; l++) tmp[k] += -face_inv[3 * l + k] / face[3 * l + 2];
-        for (int k = 0; k < 3; k++)
-            for (int l = 0; l < 2; l++) atomicAdd(&grad_face[3 * k + l], -grad_depth * tmp[l] * weight[k] * depth2 * is / 2);
-    }
-}
-
-extern "C" int jaf_rasterize_bwd_depth_map(jaf_stream_t s, const float* faces, const float* depth_map,
-                                           const int32_t* face_index_map, const float* face_inv_map, const float* weight_map,
-                                           const float* grad_depth_map, float* grad_faces, int32_t B, int32_t NF, int32_t S) {
-    JAF_REQUIRE(faces && depth_map && face_index_map && face_inv_map && weight_map && grad_depth_map && grad_faces);
-    JAF_REQUIRE(B >= 1 && NF >= 1 && S >= 1);
-    hipLaunchKernelGGL(raster_bwd_depth_map_kernel, dim3(jaf_ew_grid((long)B * S * S)), dim3(256), 0, (hipStream_t)s, faces,
-                       depth_map, face_index_map, face_inv_map, weight_map, grad_depth_map, grad_faces, B, NF, S);
-    return jaf_launch_status();
-}
+// The rasteriser's backward kernels (silhouette / colour and depth gradients) live in raster_bwd.hip.
 
 // Adjoint of project_faces_kernel: dfaces[B,NF,3,3] -> dverts[B,NV,3] (+=, a vertex belongs to ~6 faces) and
 // dcam[B,3] (+=): x = sc*(vx+tx), y = -sc*(vy+ty), z = vz - eye_z.

@@ -1,7 +1,9 @@
-"""SMPL renderer pieces that float_estimate uses, on the HIP kernels.  Mirrors the live part of
-src/nmr.py: orthographic_proj_withz_idrot (:10-28), SMPLRenderer.render_fim_wim (:263-278) and
-SMPLRenderer.cal_bc_transform (:617-659).  The texture / sampler buffers the reference builds in
-__init__ (:146-159) are never read on this path and are not built.
+"""SMPLRenderer on the HIP kernels.  Mirrors src/nmr.py: orthographic_proj_withz_idrot (:10-28), render_fim_wim (:263-278),
+cal_bc_transform (:617-659) -- what float_estimate uses on the stage-4 path -- and, SURVEY 8(f1), the textured renderer:
+forward / render (:192-244), render_fim (:246-260), extract_tex / dynamic_sampler (:364-395), the sampler helpers
+(:397-495), lighting and background setters (:180-190).  The UV-map buffers the reference builds from `mapper.txt`
+(:146-159: img2uv_sampler, map_fn, front/back_map_fn) need that asset, which is not redistributable: they are
+only built when `uv_map_path` is given, and the methods that read them raise otherwise.
 """
 from __future__ import annotations
 
@@ -42,6 +44,113 @@ class SMPLRenderer(nn.Module):
         self.eye = [0, 0, -(1. / np.tan(np.radians(self.viewing_angle)) + 1)]
         self.rasterizer_eps = 1e-3          # src/nmr.py:170 (only the textured render path passes it on)
         self.anti_aliasing = anti_aliasing
+        self.background_color = background_color
+        self.map_name = map_name
+        self.base_nf = int(faces.shape[0]) // (2 if fill_back else 1)
+        self.register_buffer('coords', self.create_coords(tex_size))
+        # light (src/nmr.py:161-168)
+        self.light_intensity_ambient = 1
+        self.light_intensity_directional = 0
+        self.light_color_ambient = [1, 1, 1]
+        self.light_color_directional = [1, 1, 1]
+        self.light_direction = [0, 1, 0]
+        self.img2uv_sampler = None          # needs mapper.txt (mesh.create_uvsampler, :146): see the module docstring
+        if uv_map_path is not None:
+            raise NotImplementedError("SMPLRenderer: the UV-map buffers (mapper.txt) are not built; use dynamic=True")
+
+    # --- src/nmr.py:180-190 --------------------------------------------------------------------
+    def set_ambient_light(self, int_dir=0.3, int_amb=0.7, direction=(1, 0.5, 1)):
+        self.light_intensity_directional = int_dir
+        self.light_intensity_ambient = int_amb
+        if direction is not None:
+            self.light_direction = direction
+
+    def set_bgcolor(self, color=(-1, -1, -1)):
+        self.background_color = color
+
+    def set_tex_size(self, tex_size):
+        dev = self.coords.device
+        del self.coords
+        self.tex_size = tex_size
+        self.register_buffer('coords', self.create_coords(tex_size).to(dev))
+
+    # --- textured rendering (src/nmr.py:192-260) -------------------------------------------------
+    def _shared_faces(self, faces):
+        """The reference passes `faces` as self.faces.repeat(bs, 1, 1); the kernels take the shared [NF,3] topology."""
+        if faces is None:
+            return self.faces
+        f = faces[0] if faces.dim() == 3 else faces
+        return f.int().contiguous()
+
+    def forward(self, cam, vertices, uv_imgs, dynamic=True, get_fim=False):
+        """(images [B,3,S,S], textures [B,NF,T,T,T,3][, fim]) -- src/nmr.py:192-210."""
+        if not dynamic:
+            raise NotImplementedError("SMPLRenderer.forward(dynamic=False) samples with img2uv_sampler, built from mapper.txt")
+        samplers = self.dynamic_sampler(cam, vertices, None)
+        textures = self.extract_tex(uv_imgs, samplers)
+        images, fim = self.render(cam, vertices, textures, None, get_fim=get_fim)
+        return (images, textures, fim) if get_fim else (images, textures)
+
+    def render(self, cam, vertices, textures, faces=None, get_fim=False):
+        """src/nmr.py:212-244: lighting on the un-projected faces (out of place here), projection + y flip + look_at,
+        rasterize(faces, textures, image_size, anti_aliasing, near, far, rasterizer_eps, background_color)."""
+        fidx = self._shared_faces(faces)
+        vertices = vertices.float().contiguous()
+        faces_lighting = ops.vertices_to_faces(vertices, fidx)
+        textures = ops.lighting(faces_lighting, textures.contiguous(), self.light_intensity_ambient,
+                                self.light_intensity_directional, self.light_color_ambient, self.light_color_directional,
+                                self.light_direction)
+        f = ops.project_faces(vertices, cam.float().contiguous(), fidx, float(np.float32(self.eye[2])))
+        images = ops.rasterize_textured(f, textures, self.image_size, self.anti_aliasing, self.near, self.far,
+                                        self.rasterizer_eps, self.background_color)
+        fim = None
+        if get_fim:     # rasterize_face_index_map(faces, image_size, anti_aliasing=False, near, far) (:239-242)
+            fim = ops.rasterize_fim_wim(f.detach(), self.image_size, self.near, self.far)[0]
+        return images, fim
+
+    def render_fim(self, cam, vertices, faces=None):
+        """src/nmr.py:246-260 (rasterize_face_index_map defaults: near 0.1, far 100)."""
+        return self.render_fim_wim(cam, vertices, faces)[1]
+
+    # --- texture extraction (src/nmr.py:355-395) -------------------------------------------------
+    def extract_tex_from_image(self, images, cam, vertices):
+        return self.extract_tex(images, self.dynamic_sampler(cam, vertices, None))
+
+    def extract_tex(self, uv_img, uv_sampler, align_corners=False):
+        """uv_img [B,3,H,W], uv_sampler [B,NF,T*T,2] -> [B,NF,T,T,T,3]: F.grid_sample (zeros padding; align_corners per
+        SURVEY F7) then the view / permute / repeat of :379-384."""
+        tex = ops.grid_sample(uv_img.contiguous(), uv_sampler.contiguous(), padding_border=False, align_corners=align_corners)
+        return ops.tex_expand(tex, self.tex_size)
+
+    def dynamic_sampler(self, cam, vertices, faces=None):
+        """batch_orth_proj_idrot -> points_to_faces -> points_to_sampler in one kernel: [B,NF,T*T,2]."""
+        return ops.face_sampler(vertices.float().contiguous(), cam.float().contiguous(), self._shared_faces(faces), self.coords)
+
+    def project_to_image(self, cam, vertices):
+        return orthographic_proj_withz_idrot(vertices, cam)[:, :, 0:2]
+
+    def points_to_faces(self, points, faces=None):
+        """[B,NV,2] image points -> [B,NF,3,2] per face (src/nmr.py:397-417)."""
+        fidx = self._shared_faces(faces)
+        p3 = torch.cat((points, torch.zeros_like(points[:, :, :1])), 2).contiguous()
+        return ops.vertices_to_faces(p3, fidx)[..., :2]
+
+    @staticmethod
+    def compute_barycenter(f2vts):
+        v2 = f2vts[:, :, 2]
+        return v2 + 0.5 * (f2vts[:, :, 0] - v2) + 0.5 * (f2vts[:, :, 1] - v2)
+
+    @staticmethod
+    def batch_orth_proj_idrot(camera, X):
+        return camera[:, None, 0:1] * (X[:, :, :2] + camera[:, None, 1:])
+
+    @staticmethod
+    def create_coords(tex_size=3):
+        """[2, T*T] barycentric sample positions (src/nmr.py:479-495), on the host; registered as a buffer."""
+        step = 1 if tex_size == 1 else 1 / (tex_size - 1)
+        alpha_beta = torch.arange(0, 1 + step, step, dtype=torch.float32)
+        xv, yv = torch.meshgrid([alpha_beta, alpha_beta], indexing="ij")
+        return torch.stack([xv.flatten(), yv.flatten()], dim=0).contiguous()
 
     def project(self, cam, vertices, faces=None):
         """Projection + y-flip + look_at + vertices_to_faces (src/nmr.py:269-276) -> faces [B,NF,3,3]."""

@@ -1770,6 +1770,215 @@ def rasterize_depth(faces, image_size: int, near: float = 0.1, far: float = 100.
     return torch.flip(rasterize(faces, image_size, near, far, eps, False, True)[1], dims=(1,))
 
 
+_SMALL_CONSTS = {}
+
+
+def _dev_const(values, device) -> torch.Tensor:
+    """A tiny fp32 constant (background colour ...) resident on the device; made once per (values, device)."""
+    t = torch.as_tensor(values, dtype=torch.float32).reshape(-1) if not isinstance(values, torch.Tensor) else None
+    if t is None:
+        return _c(values.to(device=device, dtype=torch.float32))
+    k = (tuple(float(v) for v in t), str(device))
+    hit = _SMALL_CONSTS.get(k)
+    if hit is None:
+        hit = _SMALL_CONSTS[k] = t.to(device)
+    return hit
+
+
+class _RasterizeRGBFn(Function):
+    """RasterizeFunction with return_rgb (rasterize.py:23-160): face-index map -> texture sampling -> background; backward
+    = backward_pixel_map over (rgb [, alpha]) + backward_textures [+ backward_depth_map].  The two per-pixel sampling maps
+    the reference saves (64 B/pixel each way) are not kept: the texture adjoint rebuilds its taps from the weight / depth
+    maps (jaf_rasterize_texture_bwd_rebuild).  Maps UNFLIPPED; rgb [B,S,S,3]."""
+
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, near, far, eps, background, return_alpha, return_depth):
+        B, NF = faces.shape[0], faces.shape[1]
+        S, ts = image_size, int(textures.shape[2])
+        L, dev = lib(), faces.device
+        ws = torch.empty(int(L.jaf_rasterize_workspace(B, NF, S)), device=dev, dtype=torch.uint8)
+        fim = torch.empty((B, S, S), device=dev, dtype=torch.int32)
+        wim = torch.empty((B, S, S, 3), device=dev, dtype=torch.float32)
+        depth = torch.empty((B, S, S), device=dev, dtype=torch.float32)
+        finv = torch.empty((B, S, S, 3, 3), device=dev, dtype=torch.float32) if return_depth else None
+        alpha = torch.empty((B, S, S), device=dev, dtype=torch.float32)
+        check(L.jaf_rasterize_maps(_s(), _p(faces), _p(fim), _p(wim), _p(depth), _p(finv), _p(alpha), _p(ws), B, NF, S,
+                                   near, far, 0), "jaf_rasterize_maps")
+        rgb = torch.empty((B, S, S, 3), device=dev, dtype=torch.float32)
+        bg = _dev_const(background, dev)
+        if bg.numel() not in (3, 3 * B):
+            raise RuntimeError("background colour must be [3] or [B, 3]")
+        check(L.jaf_rasterize_texture_fwd(_s(), _p(faces), _p(textures), _p(fim), _p(wim), _p(depth), _p(rgb), None, None, _p(bg),
+                                          1 if (bg.numel() == 3 * B and B > 1) else 0, B, NF, S, ts, eps),
+              "jaf_rasterize_texture_fwd")
+        ctx.cfg = (S, ts, eps, return_alpha, return_depth)
+        ctx.save_for_backward(faces, fim, wim, depth, finv, alpha, rgb)
+        ctx.mark_non_differentiable(fim, wim)
+        ctx.set_materialize_grads(False)
+        return rgb.clone(), alpha.clone(), depth.clone(), fim, wim
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_alpha, g_depth, _g_fim, _g_wim):
+        faces, fim, wim, depth, finv, alpha, rgb = ctx.saved_tensors
+        S, ts, eps, return_alpha, return_depth = ctx.cfg
+        B, NF = faces.shape[0], faces.shape[1]
+        L = lib()
+        g = torch.zeros_like(faces)
+        grgb = torch.zeros_like(rgb) if g_rgb is None else _c(g_rgb)
+        ga = None
+        if return_alpha:
+            ga = torch.zeros_like(alpha) if g_alpha is None else _c(g_alpha)
+        check(L.jaf_rasterize_bwd_pixel_map(_s(), _p(faces), _p(fim), _p(rgb), _p(alpha) if return_alpha else None, _p(grgb),
+                                            _p(ga), _p(g), B, NF, S, eps), "jaf_rasterize_bwd_pixel_map")
+        gt = None
+        if ctx.needs_input_grad[1]:
+            gt = torch.zeros((B, NF, ts, ts, ts, 3), device=faces.device, dtype=torch.float32)
+            check(L.jaf_rasterize_texture_bwd_rebuild(_s(), _p(faces), _p(fim), _p(wim), _p(depth), _p(grgb), _p(gt), B, NF, S, ts,
+                                                      eps), "jaf_rasterize_texture_bwd_rebuild")
+        if return_depth and g_depth is not None:
+            check(L.jaf_rasterize_bwd_depth_map(_s(), _p(faces), _p(depth), _p(fim), _p(finv), _p(wim), _p(_c(g_depth)), _p(g),
+                                                B, NF, S), "jaf_rasterize_bwd_depth_map")
+        return g, gt, None, None, None, None, None, None, None
+
+
+def rasterize_rgb(faces, textures, image_size: int, near: float = 0.1, far: float = 100.0, eps: float = 1e-4,
+                  background=(0.0, 0.0, 0.0), return_alpha: bool = False, return_depth: bool = False):
+    """-> (rgb [B,S,S,3], alpha, depth, fim, wim), unflipped; differentiable w.r.t. `faces` and `textures` [B,NF,ts,ts,ts,3]."""
+    _chk(faces, "faces"); _chk(textures, "textures")
+    if textures.dim() != 6 or textures.shape[:2] != faces.shape[:2] or textures.shape[-1] != 3 or not (
+            textures.shape[2] == textures.shape[3] == textures.shape[4]):
+        raise RuntimeError("textures must be [B, NF, ts, ts, ts, 3]")
+    return _RasterizeRGBFn.apply(faces, textures, int(image_size), float(near), float(far), float(eps), background,
+                                 bool(return_alpha), bool(return_depth))
+
+
+def rasterize_textured(faces, textures, image_size: int = 256, anti_aliasing: bool = True, near: float = 0.1, far: float = 100.0,
+                       eps: float = 1e-4, background=(0.0, 0.0, 0.0)):
+    """neural_renderer.rasterize (rasterize.py:361-391 -> rasterize_rgbad :257-358): RGB [B,3,S,S], vertically flipped,
+    rendered at 2x and average-pooled when anti_aliasing."""
+    S = image_size * 2 if anti_aliasing else image_size
+    rgb = rasterize_rgb(faces, textures, S, near, far, eps, background)[0]
+    rgb = torch.flip(rgb.permute(0, 3, 1, 2), dims=(2,)).contiguous()
+    return avg_pool(rgb, 2, 2, 0) if anti_aliasing else rgb
+
+
+def _f3(v):
+    vals = [float(x) for x in (v.reshape(-1).tolist() if isinstance(v, torch.Tensor) else list(v))]
+    if len(vals) != 3:
+        raise RuntimeError("lighting: per-image colours / directions are not supported (expected 3 values)")
+    return (ctypes.c_float * 3)(*vals)
+
+
+class _LightingFn(Function):
+    @staticmethod
+    def forward(ctx, faces, textures, ia, idr, ca, cd, direction):
+        B, NF, ts = faces.shape[0], faces.shape[1], int(textures.shape[2])
+        out = torch.empty_like(textures)
+        ctx.args = (float(ia), float(idr), _f3(ca), _f3(cd), _f3(direction), B, NF, ts)
+        a = ctx.args
+        check(lib().jaf_lighting_fwd(_s(), _p(faces), _p(textures), _p(out), None, a[0], a[1], a[2], a[3], a[4], B, NF, ts),
+              "jaf_lighting_fwd")
+        ctx.save_for_backward(faces, textures)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        faces, textures = ctx.saved_tensors
+        ia, idr, ca, cd, direction, B, NF, ts = ctx.args
+        g = _c(g)
+        gt = torch.empty_like(textures) if ctx.needs_input_grad[1] else None
+        gf = torch.empty_like(faces) if ctx.needs_input_grad[0] else None
+        if gt is None and gf is None:
+            return (None,) * 7
+        check(lib().jaf_lighting_bwd(_s(), _p(faces), _p(textures), _p(g), _p(gt), _p(gf), ia, idr, ca, cd, direction, B, NF, ts),
+              "jaf_lighting_bwd")
+        return gf, gt, None, None, None, None, None
+
+
+def lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1),
+             color_directional=(1, 1, 1), direction=(0, 1, 0)):
+    """neural_renderer.lighting (lighting.py:6-58), out of place: textures [B,NF,ts,ts,ts,3] * light(faces [B,NF,3,3])."""
+    _chk(faces, "faces"); _chk(textures, "textures")
+    return _LightingFn.apply(faces, textures, intensity_ambient, intensity_directional, color_ambient, color_directional, direction)
+
+
+class _VerticesToFacesFn(Function):
+    @staticmethod
+    def forward(ctx, verts, faces_idx):
+        B, NV, NF = verts.shape[0], verts.shape[1], faces_idx.shape[0]
+        out = torch.empty((B, NF, 3, 3), device=verts.device, dtype=torch.float32)
+        check(lib().jaf_vertices_to_faces(_s(), _p(verts), _p(faces_idx), _p(out), B, NV, NF), "jaf_vertices_to_faces")
+        ctx.save_for_backward(faces_idx)
+        ctx.nv = NV
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (faces_idx,) = ctx.saved_tensors
+        B, NF = g.shape[0], g.shape[1]
+        dv = torch.zeros((B, ctx.nv, 3), device=g.device, dtype=torch.float32)
+        check(lib().jaf_vertices_to_faces_bwd(_s(), _p(_c(g)), _p(faces_idx), _p(dv), B, ctx.nv, NF), "jaf_vertices_to_faces_bwd")
+        return dv, None
+
+
+def vertices_to_faces(verts, faces_idx):
+    """neural_renderer.vertices_to_faces for one shared topology: verts [B,NV,3], faces_idx int32 [NF,3] -> [B,NF,3,3]."""
+    _chk(verts, "verts"); _chk(faces_idx, "faces", torch.int32)
+    return _VerticesToFacesFn.apply(verts, faces_idx)
+
+
+class _FaceSamplerFn(Function):
+    @staticmethod
+    def forward(ctx, verts, cam, faces_idx, coords):
+        B, NV, NF, TT = verts.shape[0], verts.shape[1], faces_idx.shape[0], coords.shape[1]
+        out = torch.empty((B, NF, TT, 2), device=verts.device, dtype=torch.float32)
+        check(lib().jaf_face_sampler_fwd(_s(), _p(verts), _p(cam), _p(faces_idx), _p(coords), _p(out), B, NV, NF, TT),
+              "jaf_face_sampler_fwd")
+        ctx.save_for_backward(verts, cam, faces_idx, coords)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        verts, cam, faces_idx, coords = ctx.saved_tensors
+        B, NV, NF, TT = verts.shape[0], verts.shape[1], faces_idx.shape[0], coords.shape[1]
+        dverts = torch.zeros_like(verts)
+        dcam = torch.zeros_like(cam) if ctx.needs_input_grad[1] else None
+        check(lib().jaf_face_sampler_bwd(_s(), _p(verts), _p(cam), _p(faces_idx), _p(coords), _p(_c(g)), _p(dverts), _p(dcam),
+                                         B, NV, NF, TT), "jaf_face_sampler_bwd")
+        return dverts, dcam, None, None
+
+
+def face_sampler(verts, cam, faces_idx, coords):
+    """SMPLRenderer.dynamic_sampler (src/nmr.py:388-395): [B,NF,T*T,2] image positions of every face's texels."""
+    _chk(verts, "verts"); _chk(cam, "cam"); _chk(faces_idx, "faces", torch.int32); _chk(coords, "coords")
+    return _FaceSamplerFn.apply(verts, cam, faces_idx, coords)
+
+
+class _TexExpandFn(Function):
+    @staticmethod
+    def forward(ctx, sampled, T):
+        B, _, NF, TT = sampled.shape
+        out = torch.empty((B, NF, T, T, T, 3), device=sampled.device, dtype=torch.float32)
+        check(lib().jaf_tex_expand_fwd(_s(), _p(sampled), _p(out), B, NF, T), "jaf_tex_expand_fwd")
+        ctx.cfg = (B, NF, T)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, NF, T = ctx.cfg
+        out = torch.empty((B, 3, NF, T * T), device=g.device, dtype=torch.float32)
+        check(lib().jaf_tex_expand_bwd(_s(), _p(_c(g)), _p(out), B, NF, T), "jaf_tex_expand_bwd")
+        return out, None
+
+
+def tex_expand(sampled, T: int):
+    """[B,3,NF,T*T] -> [B,NF,T,T,T,3] (view / permute / unsqueeze / repeat of SMPLRenderer.extract_tex, src/nmr.py:379-384)."""
+    _chk(sampled, "sampled")
+    if sampled.dim() != 4 or sampled.shape[1] != 3 or sampled.shape[3] != T * T:
+        raise RuntimeError("tex_expand: expected [B, 3, NF, T*T]")
+    return _TexExpandFn.apply(sampled, int(T))
+
+
 def rasterize_fim_wim(faces, image_size: int, near: float = 0.1, far: float = 100.0):
     _chk(faces, "faces")
     B, NF = faces.shape[0], faces.shape[1]

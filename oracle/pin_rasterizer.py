@@ -7,6 +7,8 @@ golden vectors for the rasteriser path:
   * tests/test_perspective.py:9-14             perspective known answer
   * tests/test_rasterize_depth.py:37-54        teapot depth map == tests/data/test_depth.png (atol 1e-2)
   * tests/test_rasterize_silhouettes.py:37-99  the two known-answer vertex gradients of the silhouette (rtol 1e-2)
+  * tests/test_rasterize.py:60-82              textured teapot (all-ones textures, ambient light) == teapot_blender.png
+  * tests/test_rasterize.py:84-156             the two known-answer vertex gradients of the RGB path (rtol 1e-2)
 and writes tests/golden/raster_pin.json with the verdicts plus a small fixture of OUR OWN
 (single triangle / tetrahedron-like / procedural body mesh digests) that the CPU and GPU tests
 replay.  No reference file content is copied into the repo.
@@ -97,10 +99,31 @@ def main():
     r2 = np.array([[0.98646867, 1.04628897, 0.], [-1.03415668, -0.10403691, 0.], [3.00094461, -1.55173182, 0.]], np.float32)
     res["silhouette_grad_kat1"] = bool(np.allclose(g1, r1, rtol=1e-2))
     res["silhouette_grad_kat2"] = bool(np.allclose(g2, r2, rtol=1e-2))
+    # texture branch (round 3): Renderer.render with all-ones 4^3 textures, ambient 1.0 / directional 0.0, no anti-aliasing
+    ones = torch.ones(1, faces.shape[0], 4, 4, 4, 3)
+    img = RA.renderer_render(verts[None], faces.numpy(), ones, 256, False, perspective=True, fill_back=True,
+                             light=(1.0, 0.0, (1, 1, 1), (1, 1, 1), (0, 1, 0)))
+    res["teapot_rgb_equals_silhouette"] = bool(np.allclose(ref, img[0].mean(0).numpy()))
+
+    def kat_rgb(verts_, pyi, pxi, minus1):
+        v = torch.zeros(4, 3, 3)
+        v[2] = torch.tensor(verts_)
+        v.requires_grad_(True)
+        tex = torch.zeros(4, 1, 4, 4, 4, 3)
+        tex[2] = 1
+        im = RA.renderer_render(v, np.array([[0, 1, 2]]), tex, 64, False, perspective=False,
+                                light=(1.0, 0.0, (1, 1, 1), (1, 1, 1), (0, 1, 0))).mean(1)
+        torch.sum(torch.abs(im[:, pyi, pxi] - (1 if minus1 else 0))).backward()
+        return v.grad[2].numpy()
+    h1 = kat_rgb([[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]], 25, 35, True)
+    h2 = kat_rgb([[0.8, 0.8, 1.], [-0.5, -0.8, 1.], [0.8, -0.8, 1.]], 40, 50, False)
+    res["rgb_grad_kat1"] = bool(np.allclose(h1, r1, rtol=1e-2))
+    res["rgb_grad_kat2"] = bool(np.allclose(h2, r2, rtol=1e-2))
     json.dump(res, open(OUT, "w"), indent=1)
     print(res)
     assert res["look_at_kat"] and res["perspective_kat"] and res["teapot_silhouette_equal"], res
     assert res["teapot_depth_allclose_1e-2"] and res["silhouette_grad_kat1"] and res["silhouette_grad_kat2"], res
+    assert res["teapot_rgb_equals_silhouette"] and res["rgb_grad_kat1"] and res["rgb_grad_kat2"], res
 
 
 if __name__ == "__main__":

@@ -251,3 +251,78 @@ int raster_oracle_bwd_depth_map(const float* faces, const float* depth_map, cons
     }
     return 0;
 }
+
+/* forward_texture_sampling_cuda_kernel (rasterize_cuda_kernel.cu:171-243) followed by forward_background
+ * (rasterize.py:194-202).  textures [B,NF,ts,ts,ts,3]; maps UNFLIPPED; rgb_map [B,S,S,3]; sampling_index_map int32
+ * [B,S,S,8] and sampling_weight_map [B,S,S,8] keep their fill value 0 where no face is hit (rasterize.py:56-58).
+ * background [3] (bg_per_image == 0) or [B,3]. */
+int raster_oracle_texture_fwd(const float* faces, const float* textures, const int32_t* face_index_map,
+                              const float* weight_map, const float* depth_map, float* rgb_map, int32_t* sampling_index_map,
+                              float* sampling_weight_map, const float* background, int bg_per_image, int B, int NF, int is,
+                              int ts, float eps) {
+    for (long i = 0; i < (long)B * is * is; ++i) {
+        const int face_index = face_index_map[i];
+        const int bn = (int)(i / ((long)is * is));
+        float* pixel = rgb_map + i * 3;
+        int32_t* sampling_indices = sampling_index_map + i * 8;
+        float* sampling_weights = sampling_weight_map + i * 8;
+        for (int k = 0; k < 3; k++) pixel[k] = 0.f;
+        for (int pn = 0; pn < 8; pn++) { sampling_indices[pn] = 0; sampling_weights[pn] = 0.f; }
+        if (face_index >= 0) {
+            const float* face = faces + ((long)bn * NF + face_index) * 9;
+            const float* texture = textures + ((long)bn * NF + face_index) * ts * ts * ts * 3;
+            const float* weight = weight_map + i * 3;
+            const float depth = depth_map[i];
+            float texture_index_float[3];
+            for (int k = 0; k < 3; k++) {
+                float tif = weight[k] * (ts - 1) * (depth / (face[3 * k + 2]));
+                tif = (float)dmax_((double)tif, 0.);                    /* max(tif, 0.) promotes to double in the CUDA source */
+                tif = (float)dmin_((double)tif, (double)(ts - 1 - eps));   /* min(tif, ts - 1 - eps): int - float = float, then double */
+                texture_index_float[k] = tif;
+            }
+            float new_pixel[3] = {0, 0, 0};
+            for (int pn = 0; pn < 8; pn++) {
+                float w = 1;
+                int texture_index_int[3];
+                for (int k = 0; k < 3; k++) {
+                    if ((pn >> k) % 2 == 0) {
+                        w *= 1 - (texture_index_float[k] - (int)texture_index_float[k]);
+                        texture_index_int[k] = (int)texture_index_float[k];
+                    } else {
+                        w *= texture_index_float[k] - (int)texture_index_float[k];
+                        texture_index_int[k] = (int)texture_index_float[k] + 1;
+                    }
+                }
+                const int isc = texture_index_int[0] * ts * ts + texture_index_int[1] * ts + texture_index_int[2];
+                for (int k = 0; k < 3; k++) new_pixel[k] += w * texture[isc * 3 + k];
+                sampling_indices[pn] = isc;
+                sampling_weights[pn] = w;
+            }
+            for (int k = 0; k < 3; k++) pixel[k] = new_pixel[k];
+        }
+        /* rgb_map * mask + (1 - mask) * background_color */
+        const float mask = face_index >= 0 ? 1.f : 0.f;
+        const float* bg = background + (bg_per_image ? bn * 3 : 0);
+        for (int k = 0; k < 3; k++) pixel[k] = pixel[k] * mask + (1 - mask) * bg[k];
+    }
+    return 0;
+}
+
+/* backward_textures_cuda_kernel (rasterize_cuda_kernel.cu:506-541): ADDS into grad_textures (pixel order ascending). */
+int raster_oracle_texture_bwd(const int32_t* face_index_map, const float* sampling_weight_map,
+                              const int32_t* sampling_index_map, const float* grad_rgb_map, float* grad_textures, int B,
+                              int NF, int is, int ts) {
+    for (long i = 0; i < (long)B * is * is; ++i) {
+        const int face_index = face_index_map[i];
+        if (0 <= face_index) {
+            const int bn = (int)(i / ((long)is * is));
+            float* grad_texture = grad_textures + ((long)bn * NF + face_index) * ts * ts * ts * 3;
+            for (int pn = 0; pn < 8; pn++) {
+                const float w = sampling_weight_map[i * 8 + pn];
+                const int isc = sampling_index_map[i * 8 + pn];
+                for (int k = 0; k < 3; k++) grad_texture[isc * 3 + k] += w * grad_rgb_map[i * 3 + k];
+            }
+        }
+    }
+    return 0;
+}

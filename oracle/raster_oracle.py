@@ -37,6 +37,10 @@ def _load():
         _lib.raster_oracle_bwd_pixel_map.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf]
         _lib.raster_oracle_bwd_depth_map.restype = ci
         _lib.raster_oracle_bwd_depth_map.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci]
+        _lib.raster_oracle_texture_fwd.restype = ci
+        _lib.raster_oracle_texture_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, cf]
+        _lib.raster_oracle_texture_bwd.restype = ci
+        _lib.raster_oracle_texture_bwd.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci]
     return _lib
 
 
@@ -99,3 +103,36 @@ def rasterize_fim_wim(faces: np.ndarray, image_size: int = 256, near: float = 0.
     if rc != 0:
         raise RuntimeError("raster oracle failed")
     return fim, wim
+
+
+def texture_sampling(faces, textures, fim, wim, depth, background=(0.0, 0.0, 0.0), eps: float = 1e-4):
+    """forward_texture_sampling + forward_background on UNFLIPPED maps -> (rgb [B,S,S,3], sampling_index_map int32
+    [B,S,S,8], sampling_weight_map [B,S,S,8]).  textures [B,NF,ts,ts,ts,3]; background [3] or [B,3]."""
+    L = _load()
+    faces = np.ascontiguousarray(faces, np.float32)
+    textures = np.ascontiguousarray(textures, np.float32)
+    B, NF, S, ts = faces.shape[0], faces.shape[1], fim.shape[1], textures.shape[2]
+    bg = np.ascontiguousarray(background, np.float32)
+    rgb = np.empty((B, S, S, 3), np.float32)
+    sidx = np.empty((B, S, S, 8), np.int32)
+    sw = np.empty((B, S, S, 8), np.float32)
+    a = [np.ascontiguousarray(fim, np.int32), np.ascontiguousarray(wim, np.float32), np.ascontiguousarray(depth, np.float32)]
+    if L.raster_oracle_texture_fwd(faces.ctypes.data, textures.ctypes.data, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+                                   rgb.ctypes.data, sidx.ctypes.data, sw.ctypes.data, bg.ctypes.data, 1 if bg.ndim == 2 else 0,
+                                   B, NF, S, ts, eps) != 0:
+        raise RuntimeError("raster oracle failed")
+    return rgb, sidx, sw
+
+
+def backward_textures(fim, sampling_weight_map, sampling_index_map, grad_rgb_map, NF: int, ts: int):
+    """-> grad_textures [B,NF,ts,ts,ts,3]."""
+    L = _load()
+    fim = np.ascontiguousarray(fim, np.int32)
+    B, S = fim.shape[0], fim.shape[1]
+    sw = np.ascontiguousarray(sampling_weight_map, np.float32)
+    si = np.ascontiguousarray(sampling_index_map, np.int32)
+    g = np.ascontiguousarray(grad_rgb_map, np.float32)
+    out = np.zeros((B, NF, ts, ts, ts, 3), np.float32)
+    if L.raster_oracle_texture_bwd(fim.ctypes.data, sw.ctypes.data, si.ctypes.data, g.ctypes.data, out.ctypes.data, B, NF, S, ts) != 0:
+        raise RuntimeError("raster oracle failed")
+    return out

@@ -25,9 +25,8 @@ def main():
     from jafpro_amd import ops, synth
     from jafpro_amd.dist import GradReducer, shard_batch
     from jafpro_amd.step import Stage4Trainer, _to_dev
-    from tests._step_util import TRAINABLE, build_models, ref_keyed
-    M, mods, _, _ = build_models()
-    M = M.cuda()
+    from tests._step_util import TRAINABLE, flat_in_reference_order, gpu_models, step_index
+    M, mods = gpu_models()
     full = synth.stage4_batch(seed, world)
     if drop_face_rank >= 0:
         full["face_bbox"][drop_face_rank] = (96, 96, 32, 96)         # x0 == x1: no valid face on that rank
@@ -36,10 +35,20 @@ def main():
     ops.set_precision(precision)
     out = tr.train_step(shard, used=used, prosrc=prosrc)
     torch.cuda.synchronize()
+    # digests in the fixture's form (oracle/step_digest.py): samples of the flat gradient / parameter vectors at the
+    # committed positions, per-tensor sums of squares, and the vectors' float64 sums (rank-equality checks)
+    ix, digest = step_index(), {}
+    for n in TRAINABLE:
+        idx = torch.from_numpy(ix["idx." + n]).cuda()
+        numel = torch.from_numpy(ix["numel." + n]).cuda()
+        g, p = flat_in_reference_order(mods[n], n), flat_in_reference_order(mods[n], n, "data")
+        ends = torch.cumsum(numel, 0)
+        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device="cuda"), torch.cumsum(g.double() ** 2, 0)])
+        digest[n] = {"g": g[idx].cpu(), "p": p[idx].cpu(), "g_sq": (cs[ends] - cs[ends - numel]).cpu(),
+                     "g_sum": float(g.double().sum()), "p_sum": float(p.double().sum())}
     res = {"losses": {k: float(v.reshape(-1)[0]) for k, v in out.items() if k != "final_output"},
            "final_output": out["final_output"].cpu(), "overlap_order": list(getattr(tr, "overlap_order", [])),
-           "grads": {n: {k: v.cpu() for k, v in ref_keyed(mods[n]).items()} for n in TRAINABLE},
-           "params": {n: {k: v.cpu() for k, v in ref_keyed(mods[n], "data").items()} for n in TRAINABLE},
+           "digest": digest,
            "buffers": {n: {k: v.cpu() for k, v in mods[n].state_dict().items() if "running_" in k or k.endswith("num_batches_tracked")}
                        for n in ("flow", "D", "face")}}
     torch.save(res, out_path)

@@ -191,3 +191,167 @@ def test_fused_flow_warp_is_bit_identical():
         assert torch.equal(ops.flow_warp(img, fs, fim, wim, None, ac), ref)
         assert torch.equal(ops.flow_warp(img, fs, fim, wim, m3, ac), ops.mul_bcast(ref, m3))
         assert torch.equal(ops.flow_warp(img, fs, fim, wim, m3[:, :1].contiguous(), ac), ops.mul_bcast(ref, m3[:, :1].contiguous()))
+
+
+# ------------------------------------------------------------------------------------------------
+# SURVEY 8(f1), texture branch: forward_texture_sampling / backward_textures, lighting, SMPLRenderer.forward / render
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ts,S", [(3, 128), (4, 96)])
+def test_texture_sampling_bit_exact_and_texture_gradient(ts, S):
+    """jaf_rasterize_texture_fwd (+ background fill) bit-exact vs the C restatement of rasterize_cuda_kernel.cu:171-243,
+    incl. the reference's two sampling maps; backward_textures (:506-541) from the maps and rebuilt without them."""
+    from oracle import raster_oracle
+    from jafpro_amd import synth
+    from jafpro_amd._lib import lib
+    ops = _ops()
+    B = 2
+    _, _, _, faces = _mesh_faces(B, 61)
+    NF = faces.shape[1]
+    tex = synth.uniform(61, "tex", (B, NF, ts, ts, ts, 3), 0.0, 1.0)
+    bg = np.array([[0.25, -0.5, 1.0], [0.0, 0.125, -1.0]], np.float32)
+    fim_r, wim_r, depth_r, _ = raster_oracle.rasterize_maps(faces.numpy(), S, 0.1, 100.0, flip=False)
+    rgb_r, sidx_r, sw_r = raster_oracle.texture_sampling(faces.numpy(), tex, fim_r, wim_r, depth_r, bg, 1e-3)
+    L = lib()
+    f, t = faces.cuda(), torch.from_numpy(tex).cuda()
+    fim, wim, depth = torch.from_numpy(fim_r).cuda(), torch.from_numpy(wim_r).cuda(), torch.from_numpy(depth_r).cuda()
+    rgb = torch.empty((B, S, S, 3), device="cuda")
+    sidx = torch.full((B, S, S, 8), -7, device="cuda", dtype=torch.int32)
+    sw = torch.full((B, S, S, 8), -7.0, device="cuda")
+    ops.check(L.jaf_rasterize_texture_fwd(ops._s(), ops._p(f), ops._p(t), ops._p(fim), ops._p(wim), ops._p(depth), ops._p(rgb),
+                                          ops._p(sidx), ops._p(sw), ops._p(torch.from_numpy(bg).cuda()), 1, B, NF, S, ts, 1e-3),
+              "jaf_rasterize_texture_fwd")
+    assert np.array_equal(rgb.cpu().numpy(), rgb_r)
+    assert np.array_equal(sidx.cpu().numpy(), sidx_r) and np.array_equal(sw.cpu().numpy(), sw_r)
+    assert (rgb_r[fim_r < 0] == bg[:, None, :].repeat(S * S, 1).reshape(B, S, S, 3)[fim_r < 0]).all() and (fim_r >= 0).mean() > 0.1
+    # texture adjoint
+    g = synth.uniform(62, "g", (B, S, S, 3))
+    gt_r = raster_oracle.backward_textures(fim_r, sw_r, sidx_r, g, NF, ts)
+    gd = torch.from_numpy(g).cuda()
+    gt_a = torch.zeros((B, NF, ts, ts, ts, 3), device="cuda")
+    ops.check(L.jaf_rasterize_texture_bwd(ops._s(), ops._p(fim), ops._p(sw), ops._p(sidx), ops._p(gd), ops._p(gt_a), B, NF, S, ts),
+              "jaf_rasterize_texture_bwd")
+    gt_b = torch.zeros_like(gt_a)
+    ops.check(L.jaf_rasterize_texture_bwd_rebuild(ops._s(), ops._p(f), ops._p(fim), ops._p(wim), ops._p(depth), ops._p(gd),
+                                                  ops._p(gt_b), B, NF, S, ts, 1e-3), "jaf_rasterize_texture_bwd_rebuild")
+    scale = float(np.abs(gt_r).max())
+    assert scale > 0
+    assert np.abs(gt_a.cpu().numpy() - gt_r).max() <= 1e-5 * scale           # fp32 atomics: summation order only
+    assert np.abs(gt_b.cpu().numpy() - gt_r).max() <= 1e-5 * scale
+    # the C ABI refuses parameters that would put the upper tap outside the texture block
+    assert L.jaf_rasterize_texture_fwd(ops._s(), ops._p(f), ops._p(t), ops._p(fim), ops._p(wim), ops._p(depth), ops._p(rgb), None,
+                                       None, ops._p(torch.from_numpy(bg).cuda()), 1, B, NF, S, ts, 0.0) == -1
+
+
+def test_rgb_gradient_known_answers_and_oracle():
+    """The reference's two hand-checked vertex gradients of the RGB path (tests/test_rasterize.py:84-156: Renderer with
+    ambient light 1.0, all-ones 4^3 textures, rasterizer eps 1e-3, rtol 1e-2) through lighting -> rasterize_textured, and
+    grad_faces of the colour + coverage gradient bit-exact vs the C restatement on the body mesh."""
+    from oracle import raster_oracle
+    from oracle import torch_oracle as O
+    from jafpro_amd import synth
+    ops = _ops()
+
+    def kat(verts, pyi, pxi, minus1):
+        v = torch.zeros(4, 3, 3)
+        v[2] = torch.tensor(verts)
+        v = v.cuda().requires_grad_(True)
+        fi = torch.tensor([[0, 1, 2], [2, 1, 0]], device="cuda", dtype=torch.int32)      # fill_back
+        tex = torch.zeros(4, 2, 4, 4, 4, 3, device="cuda")
+        tex[2] = 1
+        tex = ops.lighting(ops.vertices_to_faces(v, fi), tex, 1.0, 0.0)
+        eye = torch.tensor([0.0, 0.0, float(np.float32(O.EYE_Z))], device="cuda")
+        faces = ops.vertices_to_faces(v - eye, fi)                # look_at from (0,0,eye_z): identity rotation
+        img = ops.rasterize_textured(faces, tex, 64, False, 0.1, 100.0, 1e-3).mean(1)
+        torch.sum(torch.abs(img[:, pyi, pxi] - (1 if minus1 else 0))).backward()
+        return v.grad[2].cpu().numpy()
+
+    g1 = kat([[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]], 25, 35, True)
+    g2 = kat([[0.8, 0.8, 1.], [-0.5, -0.8, 1.], [0.8, -0.8, 1.]], 40, 50, False)
+    r1 = np.array([[1.6725862, -0.26021874, 0.], [1.41986704, -1.64284933, 0.], [0., 0., 0.]], np.float32)
+    r2 = np.array([[0.98646867, 1.04628897, 0.], [-1.03415668, -0.10403691, 0.], [3.00094461, -1.55173182, 0.]], np.float32)
+    assert np.allclose(g1, r1, rtol=1e-2) and np.allclose(g2, r2, rtol=1e-2)
+
+    B, S, ts = 2, 128, 3
+    _, _, _, faces = _mesh_faces(B, 63)
+    NF = faces.shape[1]
+    tex = synth.uniform(63, "tex", (B, NF, ts, ts, ts, 3), 0.0, 1.0)
+    fim_r, wim_r, depth_r, _ = raster_oracle.rasterize_maps(faces.numpy(), S, flip=False)
+    rgb_r, _, _ = raster_oracle.texture_sampling(faces.numpy(), tex, fim_r, wim_r, depth_r, (0.0, 0.0, 0.0), 1e-3)
+    alpha_r = (fim_r >= 0).astype(np.float32)
+    g_rgb, g_a = synth.uniform(64, "grgb", (B, S, S, 3)), synth.uniform(64, "ga", (B, S, S))
+    for with_alpha in (False, True):
+        g_ref = raster_oracle.backward_pixel_map(faces.numpy(), fim_r, alpha_map=alpha_r if with_alpha else None,
+                                                 grad_alpha_map=g_a if with_alpha else None, rgb_map=rgb_r, grad_rgb_map=g_rgb, eps=1e-3)
+        f = faces.cuda().requires_grad_(True)
+        rgb, alpha, _, _, _ = ops.rasterize_rgb(f, torch.from_numpy(tex).cuda(), S, 0.1, 100.0, 1e-3, (0.0, 0.0, 0.0), with_alpha, False)
+        assert np.array_equal(rgb.detach().cpu().numpy(), rgb_r)
+        loss = (rgb * torch.from_numpy(g_rgb).cuda()).sum()
+        if with_alpha:
+            loss = loss + (alpha * torch.from_numpy(g_a).cuda()).sum()
+        loss.backward()
+        assert float(np.abs(g_ref).max()) > 0
+        assert np.array_equal(f.grad.cpu().numpy(), g_ref), with_alpha
+
+
+def test_lighting_vs_oracle():
+    """neural_renderer.lighting (lighting.py:6-58) with ambient + directional light: values, d/d textures, d/d faces vs
+    torch autograd over the oracle's restatement."""
+    from oracle import raster_autograd as RA
+    from jafpro_amd import synth
+    ops = _ops()
+    B, ts = 2, 3
+    v, _, fidx, _ = _mesh_faces(B, 65)
+    fi = torch.from_numpy(fidx.astype(np.int64))
+    faces_c = torch.from_numpy(v)[:, fi].clone().requires_grad_(True)
+    tex_c = torch.from_numpy(synth.uniform(65, "tex", (B, fidx.shape[0], ts, ts, ts, 3), 0.0, 1.0)).requires_grad_(True)
+    proj = torch.from_numpy(synth.uniform(65, "proj", tuple(tex_c.shape)))
+    args = (0.7, 0.3, (1.0, 0.9, 0.8), (0.5, 1.0, 0.25), (1.0, 0.5, 1.0))
+    ref = RA.lighting(faces_c, tex_c, *args)
+    (ref * proj).sum().backward()
+    faces_g = faces_c.detach().cuda().requires_grad_(True)
+    tex_g = tex_c.detach().cuda().requires_grad_(True)
+    out = ops.lighting(faces_g, tex_g, *args)
+    (out * proj.cuda()).sum().backward()
+    assert (out.cpu() - ref).abs().max().item() <= 2e-6
+    assert (tex_g.grad.cpu() - tex_c.grad).abs().max().item() <= 2e-6
+    gs = float(faces_c.grad.abs().max())
+    assert gs > 0 and (faces_g.grad.cpu() - faces_c.grad).abs().max().item() <= 1e-4 * gs
+    # ambient only (the SMPLRenderer default): the faces carry no gradient
+    out = ops.lighting(faces_g, tex_g, 1, 0)
+    assert torch.equal(out, tex_g)
+
+
+def test_smpl_renderer_textured_forward_and_gradients():
+    """SMPLRenderer.forward (src/nmr.py:192-244, :364-395): dynamic sampler, texture extraction, lighting, projection,
+    textured anti-aliased rasterisation -- against the oracle composed the same way: images, textures, gradients w.r.t.
+    the source image and the vertices."""
+    from oracle import raster_autograd as RA
+    from jafpro_amd import synth
+    from jafpro_amd.nmr import SMPLRenderer
+    B, S, T = 2, 64, 3
+    v, cam, fidx, _ = _mesh_faces(B, 66)
+    r = SMPLRenderer(faces=fidx, image_size=S, tex_size=T, anti_aliasing=True, background_color=(-1, -1, -1)).cuda()
+    r.set_ambient_light(0.3, 0.7, (1, 0.5, 1))
+    img = synth.uniform(66, "uv", (B, 3, 96, 80))
+    proj = torch.from_numpy(synth.uniform(66, "p", (B, 3, S, S)))
+    img_g = torch.from_numpy(img).cuda().requires_grad_(True)
+    v_g = torch.from_numpy(v).cuda().requires_grad_(True)
+    images, textures, fim = r(torch.from_numpy(cam).cuda(), v_g, img_g, dynamic=True, get_fim=True)
+    (images * proj.cuda()).sum().backward()
+    # oracle
+    img_c = torch.from_numpy(img).requires_grad_(True)
+    v_c = torch.from_numpy(v).requires_grad_(True)
+    cam_c = torch.from_numpy(cam)
+    sampler = RA.dynamic_sampler(cam_c, v_c, fidx, T)
+    tex_c = RA.extract_tex(img_c, sampler, T)
+    ref = RA.smpl_render(cam_c, v_c, tex_c, fidx, S, True, 0.1, 25.0, (0.7, 0.3, (1, 1, 1), (1, 1, 1), (1, 0.5, 1)), (-1, -1, -1), 1e-3)
+    (ref * proj).sum().backward()
+    assert (r.dynamic_sampler(torch.from_numpy(cam).cuda(), v_g).cpu() - sampler).abs().max().item() <= 1e-6
+    assert (textures.cpu() - tex_c).abs().max().item() <= 1e-5
+    # a pixel whose winning face flips under a 1e-7 difference of the lit textures cannot occur: the maps come from the same faces
+    assert (images.cpu() - ref).abs().max().item() <= 1e-5
+    assert fim.shape == (B, S, S) and 0.1 < float((fim >= 0).float().mean()) < 0.9
+    gi = float(img_c.grad.abs().max())
+    assert gi > 0 and (img_g.grad.cpu() - img_c.grad).abs().max().item() <= 1e-4 * gi
+    gv = float(v_c.grad.abs().max())
+    assert gv > 0 and (v_g.grad.cpu() - v_c.grad).abs().max().item() <= 1e-3 * gv

@@ -6,41 +6,37 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SEEDS = {"accu": 201, "inpaint": 202, "bg": 203, "refine": 204, "flow": 205, "D": 206, "face": 207, "vgg": 208}
+from tests._step_util import (LOSSES, TRAINABLE, build, check_losses_golden, check_step_golden, golden_step, gpu_models,
+                              rel_l2)
+
+FWD_KEYS = ("accu", "inpaint", "inpaint_warp", "refine_output", "fg_mask", "bg_output", "fusion_output", "tsf_image",
+            "final_mask", "final_output")
 
 
-def build(B):
-    from jafpro_amd import synth
-    from jafpro_amd.step import Stage4Models, Stage4Trainer, _to_dev
-    from oracle.step_oracle import OracleStage4
-    _, fidx = synth.body_mesh()
-    M = Stage4Models(fidx)
-    mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
-            "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
-    for k, m in mods.items():
-        synth.load_synth(m, SEEDS[k])
-    sds = {k: {kk: vv.detach().clone() for kk, vv in m.state_dict().items()} for k, m in mods.items()}
-    M = M.cuda()
-    batch = synth.stage4_batch(300, B)
-    return M, Stage4Trainer(M), OracleStage4(sds, fidx), batch, _to_dev(batch, "cuda"), mods
-
-
-def rel_l2(a, b):
-    a, b = a.double().reshape(-1), b.double().reshape(-1)
-    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+def fwd_err(gold, k, t):
+    """max |diff| of a generator_forward tensor against fixture fwd_s300_b1 (frames whole, the 24-part tensors as the
+    fixture's strided samples + their sum of squares) and its relative L2 distance on the same values."""
+    from oracle import step_digest as SD
+    if "fwd." + k in gold:
+        ref = torch.from_numpy(gold["fwd." + k])
+        return (t.cpu() - ref).abs().max().item(), rel_l2(t.cpu(), ref), ref.abs().max().item()
+    ref = torch.from_numpy(gold["fwd." + k + ".strided"])
+    flat = t.reshape(-1)
+    got = flat[::SD.stride_for(flat.numel(), 65536)].cpu()
+    sq = float((flat.double() ** 2).sum())
+    assert abs(sq - float(gold["fwd." + k + ".sq"])) <= 1e-2 * float(gold["fwd." + k + ".sq"]), (k, sq)
+    return (got - ref).abs().max().item(), rel_l2(got, ref), ref.abs().max().item()
 
 
 def test_generator_forward_parity():
-    """BASELINE config 2 chain for one target frame (forward only)."""
+    """BASELINE config 2 chain for one target frame (forward only) vs fixture fwd_s300_b1 (oracle/make_step_golden.py)."""
     from jafpro_amd.step import generator_forward
-    M, tr, orc, batch, dbatch, _ = build(1)
+    M, tr, _, batch, dbatch, _ = build(1)
+    gold = golden_step("fwd_s300_b1")
     with torch.no_grad():
         g = generator_forward(M, dbatch, (0, 1, 2, 3), 0)
-        cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
-        r = orc.generator_forward(cb, (0, 1, 2, 3), 0)
-    for k in ("accu", "inpaint", "inpaint_warp", "refine_output", "fg_mask", "bg_output", "fusion_output", "tsf_image",
-              "final_mask", "final_output"):
-        err = (g[k].cpu() - r[k]).abs().max().item()
+    for k in FWD_KEYS:
+        err, _, _ = fwd_err(gold, k, g[k])
         print("%-16s max|diff| = %.3e" % (k, err))
         assert err <= 1e-3, (k, err)
 
@@ -55,70 +51,41 @@ def test_generator_forward_parity():
 def test_generator_forward_matrix_core_modes(mode, linf, rl2):
     from jafpro_amd import ops
     from jafpro_amd.step import generator_forward
-    M, tr, orc, batch, dbatch, _ = build(1)
+    M, tr, _, batch, dbatch, _ = build(1)
+    gold = golden_step("fwd_s300_b1")
     prev = ops.set_precision(mode)
     try:
         with torch.no_grad():
             g = generator_forward(M, dbatch, (0, 1, 2, 3), 0)
     finally:
         ops.set_precision(prev)
-    with torch.no_grad():
-        cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
-        r = orc.generator_forward(cb, (0, 1, 2, 3), 0)
     for k in ("accu", "inpaint", "refine_output", "fg_mask", "bg_output", "final_output"):
-        err = (g[k].cpu() - r[k]).abs().max().item()
-        print("%-8s %-16s max|diff| = %.3e  rel-L2 = %.3e  (ref max %.3f)" % (mode, k, err, rel_l2(g[k].cpu(), r[k]), r[k].abs().max().item()))
-    k = "final_output"
-    assert (g[k].cpu() - r[k]).abs().max().item() <= linf
-    assert rel_l2(g[k].cpu(), r[k]) <= rl2
+        err, rl, mx = fwd_err(gold, k, g[k])
+        print("%-8s %-16s max|diff| = %.3e  rel-L2 = %.3e  (ref max %.3f)" % (mode, k, err, rl, mx))
+    err, rl, _ = fwd_err(gold, "final_output", g["final_output"])
+    assert err <= linf
+    assert rl <= rl2
 
 
 def test_train_step_bf16_runs_and_tracks_fp32():
-    """One bf16 train step: finite, and every loss within 2 % of the fp32 oracle's."""
+    """One bf16 train step: finite, and every loss within 2 % of the fp32 oracle's (fixture s300_b1)."""
     from jafpro_amd import ops
-    M, tr, orc, batch, dbatch, mods = build(1)
+    M, tr, _, batch, dbatch, mods = build(1)
     prev = ops.set_precision("bf16")
     try:
         out = tr.train_step(dbatch)
     finally:
         ops.set_precision(prev)
-    cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
-    ref = orc.train_step(cb)
-    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
-        a, b = float(out[k].reshape(-1)[0]), float(ref[k].reshape(-1)[0])
-        print("%-10s bf16 %.6f fp32-oracle %.6f" % (k, a, b))
-        assert np.isfinite(a) and abs(a - b) <= 2e-2 * max(1.0, abs(b)), (k, a, b)
+    check_losses_golden(out, golden_step("s300_b1")["losses"], 2e-2, "bf16")
 
 
 def test_train_step_parity():
-    M, tr, orc, batch, dbatch, mods = build(1)
+    """B=1 step vs fixture s300_b1: frame, six losses, gradients left in the buffers after the step (incl. the F10
+    accumulation in D / face-D), BatchNorm buffers; every trainable buffer stepped once (D three times)."""
+    M, tr, _, batch, dbatch, mods = build(1)
     out = tr.train_step(dbatch)
-    cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
-    ref = orc.train_step(cb)
-    assert (out["final_output"].cpu() - ref["final_output"]).abs().max().item() <= 1e-3
-    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
-        a, b = float(out[k].reshape(-1)[0]), float(ref[k].reshape(-1)[0])
-        print("%-10s gpu %.6f cpu %.6f" % (k, a, b))
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
-    # gradients left in the buffers after the step (incl. the F10 accumulation in D / face-D)
-    for name, key in (("accu", "accu"), ("inpaint", "inpaint"), ("refine", "refine"), ("flow", "flow"), ("D", "D"), ("face", "face")):
-        gsd = {k: v for k, v in mods[name].state_dict(keep_vars=True).items()}
-        num = den = 0.0
-        for k, p in orc.sd[key].items():
-            if not p.requires_grad:
-                continue
-            q = gsd[k]
-            gq = q.grad if q.grad is not None else None
-            if gq is None:      # grouped parameter: slice of the grouped gradient
-                from tests.test_gpu_modules import grouped_grad
-                gq = grouped_grad(mods[name], k)
-            d = (gq.detach().cpu().double() - p.grad.double())
-            num += float((d * d).sum()); den += float((p.grad.double() ** 2).sum())
-        rel = (num / max(den, 1e-300)) ** 0.5
-        print("grad rel-L2 %-8s %.3e" % (name, rel))
-        assert rel <= 5e-3, (name, rel)
-    # parameters moved by Adam: every trainable buffer changed, frozen ones did not
-    for name in ("accu", "inpaint", "refine", "flow", "D", "face"):
+    check_step_golden("s300_b1", out, mods, grad_bars=5e-3)
+    for name in TRAINABLE:
         assert tr.flat[name].step_count == (3 if name == "D" else 1)
 
 
@@ -156,11 +123,11 @@ def test_train_step_with_gradient_overlap_on_one_rank_group():
         M, tr, orc, batch, dbatch, mods = build(1)
         out_a = tr.train_step(dbatch)
         ga = {n: f.grad.clone() for n, f in tr.flat.items()}
-        M2, _, _, _, _, _ = build(1)
+        M2, _ = gpu_models()
         tr2 = Stage4Trainer(M2, reducer=GradReducer(bucket_bytes=8 << 20, skip_single=False))
         out_b = tr2.train_step(dbatch)
         assert tr2.overlap_order == ["flow", "refine", "inpaint", "accu"]
-        for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
+        for k in LOSSES:
             a, b = float(out_a[k].reshape(-1)[0]), float(out_b[k].reshape(-1)[0])
             assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (k, a, b)
         for n, f in tr2.flat.items():          # gradients left in the flat buffers (wgrad atomics reorder sums)
@@ -171,7 +138,8 @@ def test_train_step_with_gradient_overlap_on_one_rank_group():
 
 def test_forward_clip_parity():
     """BASELINE config 2 (test/conv_pro_test.py -n 4, forward only, fp32): B=2 clips, 3 target frames each,
-    every frame propagated from the reference nearest in time: pred_target <= 1e-3 L-inf vs the CPU oracle."""
+    every frame propagated from the reference nearest in time: pred_target <= 1e-3 L-inf vs the CPU oracle's
+    forward_clip (fixture clip_s400)."""
     import time
     from jafpro_amd import synth
     from jafpro_amd.step import forward_clip, _to_dev
@@ -185,8 +153,7 @@ def test_forward_clip_parity():
     out = forward_clip(M, dclip)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    cc = {k: (torch.from_numpy(np.ascontiguousarray(v)) if k != "chosen_frame" else v) for k, v in clip.items()}
-    ref = orc.forward_clip(cc)
+    ref = torch.from_numpy(golden_step("clip_s400")["pred_target"])
     assert out.shape == (2, 3, 3, 256, 256)
     err = (out.cpu() - ref).abs().max().item()
     print("forward_clip B=2 F=3: max|diff| = %.3e, %.1f ms (fp32, %.1f frames/s)" % (err, dt * 1e3, 6 / dt))
@@ -246,23 +213,19 @@ def test_full_size_batch_independence(mode):
 
 
 def test_second_step_uses_updated_weights():
-    """Two consecutive train steps vs two oracle steps (fp32): the second step's losses depend on the six Adam updates
-    of the first AND on the packed weight images having been re-made from the updated weights (they are
-    refreshed in place on a side stream right after each Adam, ops.refresh_packed_weights).  The bf16 mode's twin,
-    with the bit-exact cached-vs-fresh image comparison, is tests/test_gpu_step_parity.py::
+    """Two consecutive train steps vs two oracle steps (fp32, fixture s300_b1 `step2.*`): the second step's losses and
+    frame depend on the six Adam updates of the first AND on the packed weight images having been re-made from the
+    updated weights (they are refreshed in place on a side stream right after each Adam, ops.refresh_packed_weights).
+    The bf16 mode's twin, with the bit-exact cached-vs-fresh image comparison, is tests/test_gpu_step_parity.py::
     test_bf16_second_step_uses_refreshed_weight_images."""
     from jafpro_amd import ops
     from jafpro_amd.step import generator_forward
-    M, tr, orc, batch, dbatch, mods = build(1)
-    cb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+    M, tr, _, batch, dbatch, mods = build(1)
+    gold = golden_step("s300_b1")
     tr.train_step(dbatch, next_batch=dbatch)
     out = tr.train_step(dbatch)
-    orc.train_step(cb)
-    ref = orc.train_step(cb)
-    for k in ("total_loss", "vgg_l1", "errD", "errG", "F_errD", "F_errG"):
-        a, b = float(out[k].reshape(-1)[0]), float(ref[k].reshape(-1)[0])
-        print("step 2 %-10s gpu %.6f cpu %.6f" % (k, a, b))
-        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (k, a, b)
+    check_losses_golden(out, gold["step2.losses"], 2e-3, "step 2")
+    assert (out["final_output"].cpu() - torch.from_numpy(gold["step2.final_output"])).abs().max().item() <= 1e-3
     # a stale image would show: the cached (refreshed) images against images re-made from scratch
     with torch.no_grad():
         g_cached = generator_forward(M, dbatch, (0, 1, 2, 3), 0)["fusion_output"]
@@ -277,12 +240,8 @@ def test_config5_forward_at_512():
     oracle -- the forward chain must run at 512 in both arithmetic modes and the modes must agree with each
     other within the bf16 mode's bars."""
     from jafpro_amd import ops, synth
-    from jafpro_amd.step import Stage4Models, generator_forward, _to_dev
-    _, fidx = synth.body_mesh()
-    M = Stage4Models(fidx, image_size=512)
-    for i, m in enumerate((M.Accu_model, M.inpaint_model, M.bg_model, M.refine_model, M.propagater)):
-        synth.load_synth(m, 201 + i)
-    M = M.cuda()
+    from jafpro_amd.step import generator_forward, _to_dev
+    M, _ = gpu_models(512)
     M.set_train_modes()
     b = _to_dev(synth.stage4_batch(500, 2, S=512), "cuda")
     outs = {}
@@ -303,14 +262,8 @@ def test_config5_forward_at_512():
 def test_config5_train_step_at_512():
     """One full bf16 train step at 512x512 (B=1): every loss finite, every trainable module updated once (D three times)."""
     from jafpro_amd import ops, synth
-    from jafpro_amd.step import Stage4Models, Stage4Trainer, _to_dev
-    _, fidx = synth.body_mesh()
-    M = Stage4Models(fidx, image_size=512)
-    mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
-            "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
-    for k, m in mods.items():
-        synth.load_synth(m, SEEDS[k])
-    M = M.cuda()
+    from jafpro_amd.step import Stage4Trainer, _to_dev
+    M, mods = gpu_models(512)
     tr = Stage4Trainer(M)
     b = _to_dev(synth.stage4_batch(501, 1, S=512), "cuda")
     prev = ops.set_precision("bf16")

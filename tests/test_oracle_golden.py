@@ -235,9 +235,104 @@ def test_raster_pin_covers_depth_and_gradients(golden_dir):
     import os
     pin = json.load(open(os.path.join(golden_dir, "raster_pin.json")))
     for k in ("teapot_silhouette_equal", "teapot_depth_silhouette_equal", "teapot_depth_allclose_1e-2", "silhouette_grad_kat1",
-              "silhouette_grad_kat2", "look_at_kat", "perspective_kat"):
+              "silhouette_grad_kat2", "look_at_kat", "perspective_kat", "teapot_rgb_equals_silhouette", "rgb_grad_kat1",
+              "rgb_grad_kat2"):
         assert pin[k] is True, k
     assert pin["teapot_depth_max_abs_diff"] <= 1e-2
+
+
+def test_raster_rgb_backward_known_answers():
+    """third_party/neural_renderer/tests/test_rasterize.py:84-156: the two hand-checked vertex gradients of the RGB path
+    (Renderer(camera_mode='look_at'), perspective off, ambient 1.0 / directional 0.0, all-ones 4^3 textures, rasterizer eps
+    1e-3), rtol 1e-2 as there -- through the oracle's texture sampler, background fill and colour backward_pixel_map."""
+    import numpy as np
+    import torch
+    from oracle import raster_autograd as RA
+
+    def kat(verts, pyi, pxi, minus1):
+        v = torch.zeros(4, 3, 3)
+        v[2] = torch.tensor(verts)
+        v.requires_grad_(True)
+        tex = torch.zeros(4, 1, 4, 4, 4, 3)
+        tex[2] = 1
+        img = RA.renderer_render(v, np.array([[0, 1, 2]]), tex, 64, False, perspective=False,
+                                 light=(1.0, 0.0, (1, 1, 1), (1, 1, 1), (0, 1, 0))).mean(1)
+        torch.sum(torch.abs(img[:, pyi, pxi] - (1 if minus1 else 0))).backward()
+        return v.grad[2].numpy()
+    g1 = kat([[0.8, 0.8, 1.], [0.0, -0.5, 1.], [0.2, -0.4, 1.]], 25, 35, True)
+    g2 = kat([[0.8, 0.8, 1.], [-0.5, -0.8, 1.], [0.8, -0.8, 1.]], 40, 50, False)
+    r1 = np.array([[1.6725862, -0.26021874, 0.], [1.41986704, -1.64284933, 0.], [0., 0., 0.]], np.float32)
+    r2 = np.array([[0.98646867, 1.04628897, 0.], [-1.03415668, -0.10403691, 0.], [3.00094461, -1.55173182, 0.]], np.float32)
+    assert np.allclose(g1, r1, rtol=1e-2) and np.allclose(g2, r2, rtol=1e-2)
+
+
+def test_raster_texture_sampler_properties():
+    """oracle texture sampler (rasterize_cuda_kernel.cu:171-243): the 8 tap weights of a hit pixel sum to 1, taps stay inside
+    the ts^3 block, all-ones textures render the silhouette, the background colour fills the rest, and backward_textures
+    (:506-541) is the adjoint of the (linear in the textures) forward: <rgb(tex), g> == <tex, grad_tex(g)>."""
+    import numpy as np
+    import torch
+    from jafpro_amd import synth
+    from oracle import raster_oracle
+    from oracle import torch_oracle as O
+    B, S, ts = 1, 64, 3
+    v = synth.posed_vertices(71, "v", B)
+    cam = np.zeros((B, 3), np.float32); cam[:, 0] = 0.9
+    _, fidx = synth.body_mesh()
+    faces = O.project_faces(torch.from_numpy(v), torch.from_numpy(cam), fidx).numpy()
+    NF = faces.shape[1]
+    fim, wim, depth, _ = raster_oracle.rasterize_maps(faces, S, flip=False)
+    fg = fim >= 0
+    tex = synth.uniform(71, "tex", (B, NF, ts, ts, ts, 3), 0.0, 1.0)
+    rgb, sidx, sw = raster_oracle.texture_sampling(faces, tex, fim, wim, depth, (0.5, -0.5, 0.25), 1e-3)
+    assert 0.1 < fg.mean() < 0.9
+    assert np.allclose(sw[fg].sum(-1), 1.0, atol=1e-5) and (sw[~fg] == 0).all() and (sidx[~fg] == 0).all()
+    assert sidx.min() >= 0 and sidx.max() < ts ** 3
+    assert (rgb[~fg] == np.array([0.5, -0.5, 0.25], np.float32)).all()
+    ones, _, _ = raster_oracle.texture_sampling(faces, np.ones_like(tex), fim, wim, depth, (0, 0, 0), 1e-3)
+    assert np.allclose(ones[..., 0], fg.astype(np.float32), atol=1e-5)
+    g = synth.uniform(72, "g", (B, S, S, 3))
+    gt = raster_oracle.backward_textures(fim, sw, sidx, g, NF, ts)
+    lhs = float((rgb.astype(np.float64) * g * fg[..., None]).sum())
+    rhs = float((tex.astype(np.float64) * gt).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs))
+
+
+def test_step_fixture_replays_on_the_cpu_oracle(golden_dir):
+    """tests/golden/step_s330_u2_p2.npz (made by oracle/make_step_golden.py; the GPU parity tests compare against these
+    fixtures instead of re-running the oracle on the GPU box): the oracle run again here reproduces its frame, losses and
+    gradient digest, and the digest's sampled relative-L2 estimator agrees with the exact one on a perturbed gradient."""
+    import os
+    import numpy as np
+    import torch
+    from jafpro_amd import synth
+    from oracle import step_digest as SD
+    from oracle.step_oracle import OracleStage4
+    from tests._step_util import LOSSES, TRAINABLE, build_models, host
+    gold = dict(np.load(os.path.join(golden_dir, "step_s330_u2_p2.npz")))
+    ix = dict(np.load(os.path.join(golden_dir, "step_index.npz")))
+    _, _, sds, fidx = build_models()
+    orc = OracleStage4(sds, fidx)
+    r = orc.train_step(host(synth.stage4_batch(330, 1)), used=(2,), prosrc=2)
+    assert np.abs(r["final_output"].numpy() - gold["final_output"]).max() <= 1e-5
+    for k, b in zip(LOSSES, gold["losses"]):
+        assert abs(float(r[k].reshape(-1)[0]) - float(b)) <= 1e-5 * max(1.0, abs(float(b))), k
+    for n in TRAINABLE:
+        tr = {k: p for k, p in orc.sd[n].items() if p.requires_grad}
+        assert list(tr) == [str(k) for k in ix["keys." + n]] and [p.numel() for p in tr.values()] == list(ix["numel." + n])
+        dg = SD.digest({k: p.grad.numpy() for k, p in tr.items()}, ix["idx." + n])
+        ref = gold["g.%s.val" % n].astype(np.float64)
+        rel = np.sqrt(((dg["val"] - ref) ** 2).sum() / (ref ** 2).sum())
+        assert rel <= 2e-3, (n, rel)               # run-to-run: thread count / summation order of the CPU kernels only
+        assert np.allclose(np.sqrt(dg["sq"]), np.sqrt(gold["g.%s.sq" % n]), rtol=2e-3, atol=1e-6 * np.sqrt(gold["g.%s.sq" % n].sum()))
+    # the estimator: perturb the refine gradient by 1 % relative noise -> sampled rel-L2 ~ 1e-2 like the exact one
+    tr = {k: p for k, p in orc.sd["refine"].items() if p.requires_grad}
+    flat = SD.flat_of(p.grad.numpy() for p in tr.values()).astype(np.float64)
+    noise = np.random.default_rng(0).normal(size=flat.shape) * np.sqrt((flat ** 2).mean()) * 1e-2
+    exact = np.sqrt((noise ** 2).sum() / (flat ** 2).sum())
+    idx = ix["idx.refine"]
+    sampled = np.sqrt((noise[idx] ** 2).sum() / (flat[idx] ** 2).sum())
+    assert abs(sampled - exact) <= 0.25 * exact, (sampled, exact)
 
 
 # ---- stage 1 (BASELINE config 1) and checkpoint files (SURVEY 8(f3)) ----
