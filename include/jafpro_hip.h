@@ -108,6 +108,16 @@ int jaf_conv2d_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jaf_conv2d_pack(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode,
                     const float* w, int32_t w_rows_tot, float* packed);
 
+/* Many weight images in one launch (bf16 / bf16x3 plans): the images of a module are re-made right after its optimiser
+ * step (the reference's counterpart is cuDNN's per-call filter transform).  jaf_conv2d_pack_item fills ONE entry
+ * (jaf_conv2d_pack_item_bytes() bytes, opaque) of a HOST table from the arguments of jaf_conv2d_pack and reports the
+ * image's element count; the caller uploads the table once and jaf_conv2d_pack_batch(table_dev, n, max element count)
+ * re-packs all n images from the current weights. */
+int64_t jaf_conv2d_pack_item_bytes(void);
+int jaf_conv2d_pack_item(const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w, int32_t w_rows_tot,
+                         void* packed, void* item_host, int64_t* total_out);
+int jaf_conv2d_pack_batch(jaf_stream_t s, const void* table_dev, int32_t n, int64_t max_total);
+
 int jaf_conv2d_fwd(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                    const float* src0, const float* src1, const float* src2,
                    const float* packed_w, const float* bias, float* out);
@@ -508,6 +518,10 @@ int jaf_linear_bwd(jaf_stream_t s, const float* dz, const float* x, const float*
  * over one flat parameter buffer. step is the 1-based step count. */
 int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, int32_t step);
+/* The same update with the step count on the device: state[0] (int32 bits) = steps taken so far, advanced by the call;
+ * state[1..2] scratch.  For launches replayed from a captured hipGraph, whose arguments cannot change. */
+int jaf_adam_step_dev(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float* state);
 /* y = a*x + b*y elementwise (gradient accumulation, scaling). */
 int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float* y, int64_t n);
 

@@ -510,14 +510,83 @@ __global__ void conv_pack_bf16_kernel(const PackBArgs a) {
     }
 }
 
+static int jafb_pack_args(const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w, int32_t w_rows_tot,
+                          void* packed, PackBArgs& a);
+
 int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
               int32_t w_rows_tot, void* packed) {
+    PackBArgs a;
+    const int e = jafb_pack_args(d, plan, mode, w, w_rows_tot, packed, a);
+    if (e) return e;
+    hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(jaf_ew_grid(a.total)), dim3(256), 0, s, a);
+    return jaf_launch_status();
+}
+
+// Many weight images in ONE launch (the re-packing after an optimiser step: ~40 images per module): blockIdx.y picks
+// the image's argument block out of a device-resident table.
+__global__ void conv_pack_bf16_batch_kernel(const PackBArgs* __restrict__ table) {
+    const PackBArgs a = table[blockIdx.y];
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.total; e += (long)gridDim.x * blockDim.x) {
+        long t = e;
+        const int j = (int)(t & 7); t >>= 3;
+        const int row = (int)(t & 15); t >>= 4;
+        const int q = (int)(t & 3); t >>= 2;
+        const int mt = (int)(t % a.MT); t /= a.MT;
+        const int st = (int)(t % a.nsteps); t /= a.nsteps;
+        const int img = (int)(t % a.nimg); t /= a.nimg;
+        const int chunk = (int)(t % a.nchunks); t /= a.nchunks;
+        const int mb = (int)(t % a.mblocks); t /= a.mblocks;
+        const int g = (int)t;
+        const int ngc = (chunk == a.nchunks - 1) ? a.ng_last : a.NG;
+        const int s = 4 * st + q;
+        float v = 0.f;
+        if (s < a.taps * ngc) {
+            const int tap = s / ngc, grp = s - tap * ngc;
+            const int ch = (chunk * a.NG + grp) * 8 + j;
+            const int r = mb * 16 * a.MT + mt * 16 + row;
+            if (r < a.M && ch < a.Cred) {
+                int srow = r;
+                if (a.lstmC > 0) srow = (r & 3) * a.lstmC + (r >> 2);
+                const int stap = a.flip ? (a.taps - 1 - tap) : tap;
+                v = a.w[a.base + g * a.sg + srow * a.srow + ch * a.sch + stap];
+            }
+        }
+        __bf16 h = (__bf16)v;
+        if (img == 1) h = (__bf16)(v - (float)h);
+        a.out[e] = __builtin_bit_cast(unsigned short, h);
+    }
+}
+
+extern "C" int64_t jaf_conv2d_pack_item_bytes(void) { return (int64_t)sizeof(PackBArgs); }
+
+extern "C" int jaf_conv2d_pack_item(const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
+                                    int32_t w_rows_tot, void* packed, void* item_host, int64_t* total_out) {
+    JAF_REQUIRE(d && item_host && d->precision != JAF_PREC_F32);
+    PackBArgs a;
+    const int e = jafb_pack_args(d, plan, mode, w, w_rows_tot, packed, a);
+    if (e) return e;
+    *(PackBArgs*)item_host = a;
+    if (total_out) *total_out = a.total;
+    return JAF_OK;
+}
+
+extern "C" int jaf_conv2d_pack_batch(jaf_stream_t s, const void* table_dev, int32_t n, int64_t max_total) {
+    JAF_REQUIRE(table_dev && n >= 1 && n <= 65535 && max_total >= 1);
+    long gx = jaf_cdiv(max_total, 256L * 8);          // ~8 elements per lane for the largest image; the others loop less
+    if (gx < 1) gx = 1;
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(conv_pack_bf16_batch_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)s,
+                       (const PackBArgs*)table_dev);
+    return jaf_launch_status();
+}
+
+static int jafb_pack_args(const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w, int32_t w_rows_tot,
+                          void* packed, PackBArgs& a) {
     // the packed-input kernel (conv_dma.hip) shares this weight image: only the fields that shape it are checked
     JAF_REQUIRE(plan && w && packed && plan->precision == d->precision && plan->MT >= 1 && plan->MT <= 4 &&
                 plan->NG >= 1 && plan->NG <= 4 && plan->nchunks == jaf_cdiv(jaf_cdiv(d->Cin, 8), plan->NG) &&
                 plan->ng_last == jaf_cdiv(d->Cin, 8) - (plan->nchunks - 1) * plan->NG &&
                 plan->nsteps == jaf_cdiv(d->KH * d->KW * plan->NG, 4) && plan->mblocks == jaf_cdiv(d->Cout, 16 * plan->MT));
-    PackBArgs a;
     a.w = w;
     a.out = (unsigned short*)packed;
     a.G = d->G;
@@ -552,8 +621,7 @@ int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, 
     } else {
         return JAF_EINVAL;
     }
-    hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(jaf_ew_grid(a.total)), dim3(256), 0, s, a);
-    return jaf_launch_status();
+    return JAF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

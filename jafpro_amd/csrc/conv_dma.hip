@@ -906,7 +906,8 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 // ---------------------------------------------------------------------------------------------
 template <int MT, int NT, bool LSTM>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
-                                            int n, int g, int mb, int q, int OHW, unsigned char* smem) {
+                                            int n, int g, int mb, int q, int OHW, unsigned char* smem,
+                                            const f32x4 (&cpre)[MT]) {
     const jaf_conv_desc& d = a.d;
     constexpr int MR = 16 * MT;
     // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel).
@@ -1019,7 +1020,14 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             if (vec) {
                 if (opix[0] < 0) continue;
                 fvec cp, vi, vf, vo, vg, vc, vh;
-                if (a.c_prev) cp = *(const fvec*)(a.c_prev + hc + opix[0]);
+                if (a.c_prev) {
+                    if (NT == 4) {                      // fetched before the matrix-core loop (conv_dma_kernel): no exposed latency here
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) cp[nt] = cpre[mt][nt & 3];
+                    } else {
+                        cp = *(const fvec*)(a.c_prev + hc + opix[0]);
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     vi[nt] = jaf_sigmoid(acc[mt][nt][0] + bi);
@@ -1211,6 +1219,21 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // ConvLSTM: the previous cell state of this lane's 4 consecutive pixels (vector epilogue, NT == 4) is requested NOW, so
+    // that its HBM latency runs under the patch DMA and the matrix-core loop instead of inside the epilogue (with 3
+    // workgroups per CU nothing else hides it: the 200 x 200 level sat at 3.1 TB/s)
+    f32x4 cpre[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cpre[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (LSTM && NT == 4 && a.c_prev && a.vec && opix[0] >= 0) {
+        const int C = d.Cout >> 2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ch = ((mb * MR + mt * 16) >> 2) + q;
+            if (ch < C) cpre[mt] = *(const f32x4*)(a.c_prev + (((long)n * d.G + g) * C + ch) * OHW + opix[0]);
+        }
+    }
+
     const long wchunk_bytes = (long)P.nsteps * MT * 1024;
     const unsigned char* wbase = a.wpk + ((long)(g * P.mblocks + mb) * P.nchunks) * wchunk_bytes;
 
@@ -1265,7 +1288,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     }
 
     // ---- epilogue ----
-    cd_epilogue<MT, NT, LSTM>(a, acc, opix, n, g, mb, q, OHW, smem);
+    cd_epilogue<MT, NT, LSTM>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1309,11 +1332,16 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     int bTW = 0, bNT = 0, bNG = 0, bMT = 0;
     const int ngcap = 4;          // channel groups of 8 per chunk (slot table and DMA rounds are sized for <= 4)
     const int cand_tw[4] = {16, 32, 64, d->OW};
+    // experiment hooks (scratch/mb_part.py): restrict the search to one NT / one tile width
+    static const int force_nt = getenv("JAF_PLAN_NT") ? atoi(getenv("JAF_PLAN_NT")) : 0;
+    static const int force_tw = getenv("JAF_PLAN_TW") ? atoi(getenv("JAF_PLAN_TW")) : 0;
     for (int cMT = mt_hi; cMT >= mt_lo; --cMT)
     for (int ci = 0; ci < 4; ++ci) {
         const int TW = cand_tw[ci];
         if (ci < 3 && TW >= d->OW) continue;
+        if (force_tw && d->G >= 8 && ci < 3 && TW != force_tw) continue;
         for (int NT = 4; NT >= 1; NT >>= 1) {
+            if (force_nt && d->G >= 8 && NT != force_nt) continue;           // (the 24-part networks only)
             const int MT = cMT;
             const int Pn = 64 * NT;
             int rows_span, tiles_x, tiles_p;

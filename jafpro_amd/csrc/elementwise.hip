@@ -386,6 +386,55 @@ extern "C" int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m,
     return jaf_launch_status();
 }
 
+// The same update with the step count held ON THE DEVICE (state[0] as int32: steps taken so far; state[1], state[2]: the
+// bias corrections of the step being taken): a captured hipGraph replays the launch with unchanged arguments, so the
+// count cannot be a kernel argument there.  adam_tick advances the count and derives the corrections, adam_dev_kernel
+// reads them.
+__global__ void adam_tick_kernel(float* state, float b1, float b2) {
+    int* cnt = (int*)state;
+    const int step = cnt[0] + 1;
+    cnt[0] = step;
+    state[1] = 1.f - powf(b1, (float)step);
+    state[2] = sqrtf(1.f - powf(b2, (float)step));
+}
+
+__global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                                const float* state) {
+    const float bc1 = state[1], bc2_sqrt = state[2];
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long n4 = n >> 2;
+    f32x4* p4 = (f32x4*)p; const f32x4* g4 = (const f32x4*)g; f32x4* m4 = (f32x4*)m; f32x4* v4 = (f32x4*)v;
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 pv = p4[i], gv = g4[i], mv = m4[i], vv = v4[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mv[k] = mv[k] + (gv[k] - mv[k]) * (1.f - b1);
+            vv[k] = vv[k] * b2 + (1.f - b2) * gv[k] * gv[k];
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pv[k] = pv[k] - step_size * (mv[k] / denom);
+        }
+        p4[i] = pv; m4[i] = mv; v4[i] = vv;
+    }
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float mv = m[i] + (g[i] - m[i]) * (1.f - b1);
+        float vv = v[i] * b2 + (1.f - b2) * g[i] * g[i];
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mv / denom);
+        m[i] = mv; v[i] = vv;
+    }
+}
+
+extern "C" int jaf_adam_step_dev(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float* state) {
+    JAF_REQUIRE(p && g && m && v && state && n >= 1);
+    JAF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, state, beta1, beta2);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(jaf_ew_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr, beta1,
+                       beta2, eps, (const float*)state);
+    return jaf_launch_status();
+}
+
 __global__ void axpby_kernel(float a, const float* x, float b, float* y, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

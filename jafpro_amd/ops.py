@@ -22,7 +22,7 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DG
 __all__ = ["set_precision", "get_precision", "conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
            "reflect_pad", "texture_warp", "grid_sample", "blend", "mul_bcast", "part_mask_mul",
            "atlas_to_parts", "vgg_preprocess", "l1_loss", "bce_loss", "linear", "adam_step",
-           "project_faces", "rasterize_fim_wim", "bc_transform", "axpby", "ACT_NONE", "ACT_LRELU",
+           "project_faces", "rasterize_fim_wim", "bc_transform", "axpby", "conv_transpose2d", "ACT_NONE", "ACT_LRELU",
            "ACT_RELU", "ACT_SIGMOID", "ACT_TANH"]
 
 
@@ -480,10 +480,17 @@ def refresh_packed_weights(params) -> None:
     st = aux_stream(2)
     st.wait_stream(main)                      # after the optimiser kernel and every reader of the old images
     L = lib()
+    # the bf16-family images of one call (= one module) are re-made by ONE launch over a device-resident argument table,
+    # built the first time this exact set of cache entries is seen (243 launches of ~8 us per step before)
+    batch = [(t, e) for t, e in todo if e.d.precision != PREC_F32] if _BATCHED_REPACK else []
+    table = _repack_table(batch) if len(batch) > 1 else None
     with torch.cuda.stream(st):
+        if table is not None:
+            check(L.jaf_conv2d_pack_batch(_s(), _p(table[0]), len(batch), table[1]), "jaf_conv2d_pack_batch")
         for t, e in todo:
-            check(L.jaf_conv2d_pack(_s(), ctypes.byref(e.d), ctypes.byref(e.pl), e.mode, _p(t), e.rows, _p(e.buf)),
-                  "jaf_conv2d_pack")
+            if table is None or e.d.precision == PREC_F32:
+                check(L.jaf_conv2d_pack(_s(), ctypes.byref(e.d), ctypes.byref(e.pl), e.mode, _p(t), e.rows, _p(e.buf)),
+                      "jaf_conv2d_pack")
             if st != main:
                 # both blocks were allocated on another stream: the allocator must not hand them out again (cache
                 # dropped, model freed) while this stream still reads the weights / writes the image
@@ -495,6 +502,33 @@ def refresh_packed_weights(params) -> None:
             ev.record(st)
     for _, e in todo:
         e.event, e.waited = ev, (set() if ev is not None else {main.cuda_stream})
+
+
+_BATCHED_REPACK = os.environ.get("JAF_NO_BATCHED_REPACK") is None
+_REPACK_TABLES: dict = {}
+
+
+def _repack_table(batch):
+    """(device table of jaf_conv2d_pack_item entries, largest image's element count) for this list of (weight, cache
+    entry) pairs; keyed by the entries' identities and addresses (a re-made entry or a moved weight gets a new table)."""
+    key = tuple((id(e), e.buf.data_ptr(), t.data_ptr()) for t, e in batch)
+    hit = _REPACK_TABLES.get(key)
+    if hit is not None:
+        return hit
+    L = lib()
+    nb = int(L.jaf_conv2d_pack_item_bytes())
+    host = (ctypes.c_ubyte * (nb * len(batch)))()
+    most = 0
+    tot = ctypes.c_int64(0)
+    for i, (t, e) in enumerate(batch):
+        check(L.jaf_conv2d_pack_item(ctypes.byref(e.d), ctypes.byref(e.pl), e.mode, _p(t), e.rows, _p(e.buf),
+                                     ctypes.byref(host, i * nb), ctypes.byref(tot)), "jaf_conv2d_pack_item")
+        most = max(most, int(tot.value))
+    dev = torch.frombuffer(host, dtype=torch.uint8).clone().to(batch[0][0].device)
+    if len(_REPACK_TABLES) > 64:
+        _REPACK_TABLES.clear()
+    hit = _REPACK_TABLES[key] = (dev, most, [e for _, e in batch])      # the entries stay alive with their table
+    return hit
 
 
 def _out_size(n, k, s, p):
@@ -903,6 +937,29 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     elif not _wgrad_packed_ok(m):
         raise RuntimeError("conv2d: lazily resized sources need a layer whose weight gradient runs on the packed kernel")
     return _ConvFn.apply(weight, bias, m, *srcs)
+
+
+def conv_transpose2d(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 2, pad: int = 1,
+                     act: int = ACT_NONE, slope: float = 0.0) -> torch.Tensor:
+    """nn.ConvTranspose2d (weight [Cin, Cout, KH, KW], output_padding 0, groups 1) with fused bias + activation, FORWARD ONLY
+    (the FlowNetSD evaluation network, src/flownet2_pytorch/networks/submodules.py:34-38).  A transposed convolution is the
+    data gradient of the convolution whose weight tensor it shares, so this is the data-gradient launch of `conv2d`
+    (zero-dilated input, flipped / transposed packed weights) with an epilogue."""
+    _chk(x, "conv_transpose2d input"); _chk(weight, "conv_transpose2d weight")
+    if bias is not None:
+        _chk(bias, "conv_transpose2d bias")
+    if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+        raise RuntimeError("conv_transpose2d is forward-only: call it under torch.no_grad()")
+    N, Cin, H, W = (int(v) for v in x.shape)
+    if weight.dim() != 4 or weight.shape[0] != Cin:
+        raise RuntimeError("conv_transpose2d: weight must be [Cin, Cout, KH, KW]")
+    Cout, KH, KW = int(weight.shape[1]), int(weight.shape[2]), int(weight.shape[3])
+    if KH != KW or pad > KH - 1:
+        raise RuntimeError("conv_transpose2d: square kernels with pad <= k - 1 only")
+    OH, OW = (H - 1) * stride - 2 * pad + KH, (W - 1) * stride - 2 * pad + KW
+    pad_d = KH - 1 - pad
+    return _conv_raw([x], [(Cin, Cin, 0, Cin)], weight, Cin, PACK_DGRAD, bias, N, 1, Cin, Cout, H, W, OH, OW, KH, KW, 1, pad_d, pad_d,
+                     stride, Cout, 0, act, float(slope))
 
 
 def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=0.0, groups=1):
@@ -1645,18 +1702,39 @@ def linear(x, w, b, act=ACT_NONE, slope=0.0):
     return _LinearFn.apply(_chk(x, "linear x"), _chk(w, "linear w"), _chk(b, "linear b"), act, float(slope))
 
 
-def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, params=None, refresh: bool = False):
-    """In-place torch.optim.Adam update of a flat parameter buffer.  `params`: the parameter tensors that
-    view into it (their packed-weight images are dropped, or with `refresh` re-made on a side stream;
-    None drops every cached image)."""
+def adam_step(p, g, m, v, lr: float, step: int, beta1=0.9, beta2=0.999, eps=1e-8, params=None, refresh: bool = False,
+              state: Optional[torch.Tensor] = None):
+    """torch.optim.Adam defaults over one flat buffer.  `state` (fp32 [4] on the device, element 0 = the int32 count of steps
+    taken so far): the step count lives on the device and `step` is ignored -- the form a captured hipGraph needs."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, "adam " + n)
-    check(lib().jaf_adam_step(_s(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step),
-          "jaf_adam_step")
+    if state is not None:
+        check(lib().jaf_adam_step_dev(_s(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, _p(_chk(state, "adam state"))),
+              "jaf_adam_step_dev")
+    else:
+        check(lib().jaf_adam_step(_s(), _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, step),
+              "jaf_adam_step")
     if refresh and params is not None:
         refresh_packed_weights(params)
     else:
         invalidate_packed_weights(params)
+
+
+def reset_pack_events():
+    """Forgets the cross-stream events of the cached weight images (everything is idle: call after a device synchronise).
+    Events recorded while a hipGraph was being captured are not real events, and a capture must not wait on events recorded
+    before it began (GraphedTrainStep brackets its capture with this)."""
+    for e in _PACK_CACHE.values():
+        e.event, e.waited = None, set()
+
+
+def cache_census():
+    """Sizes of the host-side caches a train step may still be filling (plans, descriptors, weight images, re-pack tables)."""
+    return (len(_PLAN_CACHE), len(_DESC_CACHE), len(_PACK_CACHE), len(_REPACK_TABLES), len(_SMALL_CONSTS))
+
+
+def pack_cache_entries():
+    return list(_PACK_CACHE.values())
 
 
 def invalidate_packed_weights(params=None):

@@ -29,6 +29,9 @@ from .networks import (Accumulate_LSTM_no_loss, FaceDiscriminator, ImageDiscrimi
 LRS = {"accu": 1e-5, "inpaint": 1e-5, "refine": 1e-5, "flow": 5e-5, "D": 3e-6, "face": 1e-6}   # :169-175
 
 
+_CAPTURE = {"on": False}        # True while a train step is being captured into a hipGraph (GraphedTrainStep)
+
+
 class FlatParams:
     """All parameters of a module in ONE contiguous buffer (and one gradient buffer): Adam is a
     single launch over it and the RCCL all-reduce a single message per module."""
@@ -51,6 +54,7 @@ class FlatParams:
             off += sz
         self.params = ps
         self.step_count = 0
+        self.dev_state = None           # fp32 [4]: the step count on the device (graph-captured steps, see GraphedTrainStep)
         ops.invalidate_packed_weights()
 
     def zero_grad(self):
@@ -59,7 +63,14 @@ class FlatParams:
     def adam(self, lr: float):
         ops.join_wgrad_stream()         # weight gradients may have been written on the side stream
         self.step_count += 1
-        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params, refresh=True)
+        ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params, refresh=True,
+                      state=self.dev_state if _CAPTURE["on"] else None)
+
+    def sync_dev_state(self):
+        """Puts the host's step count on the device (before a capture; the captured launches advance it from there)."""
+        if self.dev_state is None:
+            self.dev_state = torch.zeros(4, device=self.flat.device, dtype=torch.float32)
+        self.dev_state.view(torch.int32)[0] = self.step_count
 
 
 class Stage4Models(nn.Module):
@@ -217,7 +228,8 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
     inpaint = M.inpaint_model.forward_grouped(masked)                           # :300
     inpaint_warp = ops.texture_warp(inpaint, b["tgt_IUV255"], align_corners)    # :309-312
     refine_output, fg_mask = M.refine_model(inpaint_warp, S)                    # :318
-    main.wait_event(prepared.event)
+    if prepared.event is not None:          # None: static buffers of a captured step, already ordered before this stream
+        main.wait_event(prepared.event)
     for t in (bg_output, tsf, prepared.src0):
         t.record_stream(main)
     fusion = ops.blend(refine_output, bg_output, fg_mask)                       # :321
@@ -301,6 +313,24 @@ class Stage4Trainer:
             ops.join_wgrad_stream()
             ops.set_wgrad_stream(prev_ws)
 
+    def train_step_graphed(self, batch, used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0, align_corners: bool = False,
+                           next_batch=None, next_prosrc: Optional[int] = None):
+        """`train_step` through a captured hipGraph (GraphedTrainStep): the first call with a new key -- batch geometry,
+        `used`, `prosrc`, face boxes, with / without a next clip -- captures
+        (that call's own step runs eagerly); later calls copy the clips into the graph's static buffers and replay.  The returned tensors are the graph's own
+        output buffers: valid until the next replay."""
+        nps = prosrc if next_prosrc is None else next_prosrc
+        key = (tuple(used), prosrc, nps, bool(align_corners), next_batch is not None, ops.get_precision(),
+               tuple(int(v) for v in np.asarray(batch["face_bbox"]).reshape(-1)),
+               tuple((k, tuple(v.shape)) for k, v in sorted(batch.items()) if isinstance(v, torch.Tensor)))
+        graphs = self.__dict__.setdefault("_graphs", {})
+        g = graphs.get(key)
+        if g is None:
+            g = graphs[key] = GraphedTrainStep(self, batch, used, prosrc, align_corners, next_batch, nps)
+            return g.first
+        g.load(batch, next_batch)
+        return g.replay()
+
     def _train_step(self, batch, used, prosrc, align_corners, next_batch, next_prosrc):
         M, b = self.M, batch
         fw = self._face_weight(count_faces(b["face_bbox"]))      # before anything is enqueued: may raise on every rank
@@ -313,7 +343,8 @@ class Stage4Trainer:
         vgg_target = None
         prep = g["prepared"]
         if prep.vgg_target is not None:         # target features came from the side stream
-            torch.cuda.current_stream().wait_event(prep.vgg_event)
+            if prep.vgg_event is not None:
+                torch.cuda.current_stream().wait_event(prep.vgg_event)
             vgg_target = prep.vgg_target
             for t in [vgg_target[0]] + list(vgg_target[1]):
                 t.record_stream(torch.cuda.current_stream())
@@ -384,6 +415,114 @@ class Stage4Trainer:
         return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),
                 "errG": errG.detach(), "F_errD": (F_errD_real + F_errD_fake).detach(), "F_errG": F_errG.detach(),
                 "final_output": final_d}
+
+
+class GraphedTrainStep:
+    """One full stage-4 train step captured ONCE into a hipGraph and replayed: ~1500 kernel launches on four streams become
+    one graph launch, so the step no longer depends on how fast the host can enqueue (profiles/round2_host_enqueue.txt: 35-58
+    ms of Python + launch calls per 65 ms step; eight ranks share one host).  Same kernels, same arithmetic, same order.
+
+    What a captured step fixes, and how the moving parts are handled:
+      * geometry and host integers -- batch shapes, the reference subset `used`, the propagation source, the face boxes
+        (kernel arguments of the crops) -- are the graph's key: `Stage4Trainer.train_step_graphed` keeps one graph per key
+        and falls back to the eager step for keys it has not captured;
+      * the batch lives in static device buffers (`load` copies a new batch in; the next clip has its own set);
+      * Adam's bias correction needs the step count: it lives on the device (jaf_adam_step_dev), advanced inside the graph;
+      * the next clip's preparation (side stream 0) is produced INSIDE the graph into graph-owned tensors and copied into
+        the static PreparedClip the next replay starts from -- the cross-step overlap of the eager step, kept;
+      * every side stream is joined before the capture ends (weight gradients, re-packed weight images, preparation).
+    Single-rank only: the gradient exchange of N > 1 ranks stays on the eager path."""
+
+    def __init__(self, trainer: "Stage4Trainer", batch, used, prosrc, align_corners, next_batch, next_prosrc):
+        if trainer.reducer is not None and trainer.reducer.active:
+            raise RuntimeError("GraphedTrainStep: the multi-rank gradient exchange is not captured; use train_step")
+        tr = self.trainer = trainer
+        self.used, self.prosrc, self.align, self.next_prosrc = tuple(used), prosrc, align_corners, next_prosrc
+        clone = lambda b: {k: (v.clone() if isinstance(v, torch.Tensor) else np.array(v, copy=True)) for k, v in b.items()}
+        self.cur = clone(batch)
+        self.nxt = clone(next_batch) if next_batch is not None else None
+        # THIS call's step runs eagerly on the static buffers: it fills every host-side cache (plans, packed weight images,
+        # constants, LDS opt-ins) and leaves the preparation of `nxt` behind; the capture below executes nothing
+        self.settle_steps = 0
+        while True:
+            before = ops.cache_census()
+            out = tr.train_step(self.cur, self.used, prosrc, align_corners, next_batch=self.nxt, next_prosrc=next_prosrc)
+            if self.settle_steps == 0:
+                self.first = {k: v.clone() for k, v in out.items()}
+            self.settle_steps += 1
+            # a cold process builds its weight images (and the argument tables of their re-packing) over its first two
+            # steps -- the discriminator's data-gradient images only exist after the first generator backward -- and a
+            # capture must not find anything left to build (uploads are illegal while capturing)
+            if ops.cache_census() == before or self.settle_steps >= 3:
+                break
+        torch.cuda.synchronize()
+        self.prep = tr._prepared                     # PreparedClip in ordinary memory: the graph's static hand-over slot
+        if self.prep is not None:
+            self.prep.event = self.prep.vgg_event = None
+        counts = {n: f.step_count for n, f in tr.flat.items()}
+        for f in tr.flat.values():
+            f.sync_dev_state()
+        ops.reset_pack_events()
+        self.graph = torch.cuda.CUDAGraph()
+        _CAPTURE["on"] = True
+        try:
+            with torch.cuda.graph(self.graph):
+                main = torch.cuda.current_stream()
+                if self.nxt is not None:             # this replay's clip is what the previous one prepared: nxt -> cur
+                    for k, v in self.cur.items():
+                        if isinstance(v, torch.Tensor):
+                            v.copy_(self.nxt[k])
+                if self.prep is not None:            # (after the copies: they bump the tensors' versions, which the key holds)
+                    self.prep.batch, self.prep.key = self.cur, _clip_key(self.cur, prosrc)
+                tr._prepared = self.prep
+                self.out = tr.train_step(self.cur, self.used, prosrc, align_corners, next_batch=self.nxt, next_prosrc=next_prosrc)
+                new = tr._prepared
+                if new is not None:                  # hand the next clip's preparation over through the static slot
+                    main.wait_event(new.event)
+                    if new.vgg_event is not None:
+                        main.wait_event(new.vgg_event)
+                    for a, b in self._prep_pairs(self.prep, new):
+                        a.copy_(b)
+                for which in (0, 1, 2):              # nothing may be left running on a side stream when the capture ends
+                    st = ops.aux_stream(which)
+                    if st != main:
+                        main.wait_stream(st)
+        finally:
+            _CAPTURE["on"] = False
+        for n, f in tr.flat.items():                 # the capture advanced the host's counters without running anything
+            f.step_count = counts[n]
+        tr._prepared = None
+        ops.reset_pack_events()
+        self.pack_entries = ops.pack_cache_entries()         # the graph writes these images: they must outlive it
+        self.replays = 0
+
+    @staticmethod
+    def _prep_pairs(dst: PreparedClip, src: PreparedClip):
+        pairs = [(dst.src0, src.src0), (dst.bg_output, src.bg_output), (dst.tsf, src.tsf)]
+        if dst.vgg_target is not None:
+            pairs.append((dst.vgg_target[0], src.vgg_target[0]))
+            pairs += list(zip(dst.vgg_target[1], src.vgg_target[1]))
+        return pairs
+
+    def load(self, batch=None, next_batch=None):
+        """Copies a new clip (and the clip after it) into the static buffers.  With a next-clip slot the graph itself moves
+        `nxt` into `cur` at the start of a replay, so only `next_batch` is needed from the second call on."""
+        def put(dst, src):
+            for k, v in dst.items():
+                if isinstance(v, torch.Tensor) and src[k] is not v and src[k].data_ptr() != v.data_ptr():
+                    v.copy_(src[k])
+        if self.nxt is None:
+            if batch is not None:
+                put(self.cur, batch)
+        elif next_batch is not None:
+            put(self.nxt, next_batch)
+
+    def replay(self):
+        self.graph.replay()
+        self.replays += 1
+        for n, f in self.trainer.flat.items():
+            f.step_count += 3 if n == "D" else 1
+        return self.out
 
 
 @torch.no_grad()

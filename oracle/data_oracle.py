@@ -2,8 +2,11 @@
 Fusion_dataset_smpl_interval.__getitem__ (src/data.py:640-773), TransferTexture (src/utils.py:369-394) and the
 permutes / casts of train/4.convLSTM_flowpro_interval.py:216-237, on already-decoded uint8 frames (cv2.imread is file
 I/O, out of scope).  float64 arithmetic and the final .float() cast exactly as the reference.
-Parity unpinned by a reference fixture: the reference holds no test or golden for its data pipeline and the functions
-need cv2 / a dataset to run, so this restatement is pinned by reading the cited lines only."""
+Pinning (round 3): `transfer_texture` reproduces the reference's own TransferTexture exactly -- oracle/make_golden.py g_data
+takes that function out of src/utils.py's syntax tree (the module itself needs tensorflow / cv2 / moviepy) and runs it on
+seeded inputs: max |diff| = 0, outputs committed as tests/golden/transfer_texture.npz.  The rest (the normalisations and
+permutes of src/data.py:736-763, the face box of :699-716) sits inside a dataset method that needs cv2 and files: pinned by
+reading the cited lines only."""
 from __future__ import annotations
 
 import numpy as np

@@ -416,6 +416,70 @@ def g_checkpoints():
     report["checkpoint_files_roundtrip"] = len(out)
 
 
+# ---- 12. FlowNetSD of the evaluation script (test/video_evaluation.py:66,197-206) ----------------------
+def g_flownet():
+    from src.flownet2_pytorch.networks.FlowNetSD import FlowNetSD as RFlowNetSD
+    ref = RFlowNetSD(args=[], batchNorm=False)            # left in train mode, as the script does: forward returns 5 flows
+    synth.load_synth(ref, 811)
+    st = {}
+    # two frame pairs of a synthetic video in (-1, 1), through flownet_preprocess (:34-36)
+    frames = synth.uniform(812, "flow_frames", (3, 3, 128, 192))
+    smooth = torch.nn.functional.avg_pool2d(T(frames), 5, 1, 2)                  # some spatial structure, still seeded
+    pairs = torch.cat([smooth[:-1], smooth[1:]], 1) / 2.0 + 0.5
+    with torch.no_grad():
+        flows = ref(pairs)
+        mine = O.flownet_sd_forward(sd_of(ref), pairs, True)
+    assert len(flows) == 5
+    for i, (a, b) in enumerate(zip(flows, mine)):
+        report["flownet_sd_flow%d" % (i + 2)] = close(b, a, 0.0, "FlowNetSD flow%d" % (i + 2))
+    st["pairs"] = pairs.numpy()
+    for i, a in enumerate(flows):
+        put(st, "flow%d" % (i + 2), a, full=True)
+    ref.eval()
+    with torch.no_grad():
+        assert len(ref(pairs)) == 1 and torch.equal(ref(pairs)[0], flows[0])
+    st["flow_l1"] = np.float64(torch.nn.functional.l1_loss(flows[0][:1], flows[0][1:]).item())   # the script's per-frame term
+    np.savez_compressed(os.path.join(GOLD, "flownet_sd.npz"), **st)
+    schema_path = os.path.join(GOLD, "state_dict_schema.json")
+    schema = json.load(open(schema_path))
+    schema["FlowNetSD"] = [[k, list(v.shape)] for k, v in ref.state_dict().items()]
+    json.dump(schema, open(schema_path, "w"))
+
+
+# ---- 13. TransferTexture of the data pipeline (src/utils.py:369-394) ---------------------------------
+def g_data():
+    """src/utils.py cannot be imported (tensorflow, cv2, moviepy at module level), but TransferTexture itself is pure
+    NumPy: the function definition is taken out of the module's syntax tree and executed here, in memory, with `np` as its
+    only global -- the reference's own code producing the expected outputs of oracle/data_oracle.transfer_texture."""
+    import ast
+    from oracle import data_oracle
+    path = "/root/reference/src/utils.py"
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "TransferTexture"]
+    assert len(fn) == 1
+    ns = {"np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    ref_fn = ns["TransferTexture"]
+    raw = synth.stage4_raw(821, 3)
+    st, worst = {}, 0
+    for i in range(3):
+        tex, iuv, im = raw["src_texture_u8"][i, 0], raw["tgt_IUV_u8"][i], raw["tgt_img_u8"][i]
+        for tag, bg in (("plain", None), ("over_image", im)):
+            ref = ref_fn(tex.copy(), iuv.copy(), None if bg is None else bg.copy())
+            mine = data_oracle.transfer_texture(tex, iuv, bg)
+            assert ref.dtype == np.uint8 and ref.shape == (256, 256, 3)
+            worst = max(worst, int(np.abs(ref.astype(np.int64) - mine.astype(np.int64)).max()))
+            st["%s.%d" % (tag, i)] = ref
+    ones = ref_fn(np.ones((800, 1200, 3), np.uint8), raw["src_IUV0_u8"][0].copy())          # the mask use of src/data.py:690-695
+    assert np.array_equal(ones, data_oracle.transfer_texture(np.ones((800, 1200, 3), np.uint8), raw["src_IUV0_u8"][0]))
+    st["ones_mask.0"] = ones
+    st["seed"] = np.int64(821)
+    print("  oracle vs reference TransferTexture          max|diff| = %d" % worst)
+    assert worst == 0
+    report["transfer_texture"] = float(worst)
+    np.savez_compressed(os.path.join(GOLD, "transfer_texture.npz"), **st)
+
+
 # ---- 11. state_dict schema of the boundary modules (SURVEY Appendix A) -------------------------------
 def g_schema():
     mods = {"Accumulate_LSTM_no_loss": RN.Accumulate_LSTM_no_loss(), "UNet_inpainter": RN.UNet_inpainter(),

@@ -378,3 +378,33 @@ def mask_parts(parts: Sequence[torch.Tensor], area):
         for j in range(6):
             out.append(parts[i * 6 + j] * area[:, :, i * 200:(i + 1) * 200, j * 200:(j + 1) * 200])
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# FlowNetSD (src/flownet2_pytorch/networks/FlowNetSD.py:11-106, submodules.py:7-38) with batchNorm=False, as the
+# evaluation script builds it (test/video_evaluation.py:66): functional over the reference's state_dict.
+# ------------------------------------------------------------------------------------------------
+def flownet_sd_forward(sd: SD, x, training: bool = True):
+    lrelu = lambda t: F.leaky_relu(t, 0.1)
+    cv = lambda name, t, s=1: lrelu(F.conv2d(t, sd[name + ".0.weight"], sd[name + ".0.bias"], stride=s, padding=1))
+    plain = lambda name, t: F.conv2d(t, sd[name + ".weight"], sd[name + ".bias"], stride=1, padding=1)
+    icv = lambda name, t: F.conv2d(t, sd[name + ".0.weight"], sd[name + ".0.bias"], stride=1, padding=1)
+    dcv = lambda name, t: lrelu(F.conv_transpose2d(t, sd[name + ".0.weight"], sd[name + ".0.bias"], stride=2, padding=1))
+    up = lambda name, t: F.conv_transpose2d(t, sd[name + ".weight"], sd[name + ".bias"], stride=2, padding=1)
+    c0 = cv("conv0", x)
+    c1 = cv("conv1_1", cv("conv1", c0, 2))
+    c2 = cv("conv2_1", cv("conv2", c1, 2))
+    c3 = cv("conv3_1", cv("conv3", c2, 2))
+    c4 = cv("conv4_1", cv("conv4", c3, 2))
+    c5 = cv("conv5_1", cv("conv5", c4, 2))
+    c6 = cv("conv6_1", cv("conv6", c5, 2))
+    flow6 = plain("predict_flow6", c6)
+    cat5 = torch.cat((c5, dcv("deconv5", c6), up("upsampled_flow6_to_5", flow6)), 1)
+    flow5 = plain("predict_flow5", icv("inter_conv5", cat5))
+    cat4 = torch.cat((c4, dcv("deconv4", cat5), up("upsampled_flow5_to_4", flow5)), 1)
+    flow4 = plain("predict_flow4", icv("inter_conv4", cat4))
+    cat3 = torch.cat((c3, dcv("deconv3", cat4), up("upsampled_flow4_to_3", flow4)), 1)
+    flow3 = plain("predict_flow3", icv("inter_conv3", cat3))
+    cat2 = torch.cat((c2, dcv("deconv2", cat3), up("upsampled_flow3_to_2", flow3)), 1)
+    flow2 = plain("predict_flow2", icv("inter_conv2", cat2))
+    return (flow2, flow3, flow4, flow5, flow6) if training else (flow2,)

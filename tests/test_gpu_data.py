@@ -68,3 +68,22 @@ def test_pipeline_feeds_the_train_step():
     for k in LOSSES:
         assert abs(float(o1[k].reshape(-1)[0]) - float(o2[k].reshape(-1)[0])) <= 1e-5 * max(1.0, abs(float(o2[k].reshape(-1)[0]))), k
     assert torch.isfinite(o1["final_output"]).all()
+
+
+def test_transfer_texture_golden(golden_dir):
+    """jaf_transfer_texture_u8 vs the outputs of the REFERENCE's TransferTexture (src/utils.py:369-394; fixture made by
+    oracle/make_golden.py g_data from the function's own code): bit-exact, batched and shared-atlas forms."""
+    import os
+    from jafpro_amd import data, synth
+    st = dict(np.load(os.path.join(golden_dir, "transfer_texture.npz")))
+    raw = synth.stage4_raw(int(st["seed"]), 3)
+    tex = torch.from_numpy(raw["src_texture_u8"][:, 0].copy()).cuda()
+    iuv = torch.from_numpy(raw["tgt_IUV_u8"]).cuda()
+    im = torch.from_numpy(raw["tgt_img_u8"]).cuda()
+    a = data.transfer_texture(tex, iuv).cpu().numpy()
+    b = data.transfer_texture(tex, iuv, im).cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(a[i], st["plain.%d" % i]) and np.array_equal(b[i], st["over_image.%d" % i])
+    ones = torch.ones((800, 1200, 3), dtype=torch.uint8, device="cuda")
+    m = data.transfer_texture(ones, torch.from_numpy(raw["src_IUV0_u8"][:1].copy()).cuda()).cpu().numpy()
+    assert np.array_equal(m[0], st["ones_mask.0"])

@@ -61,4 +61,53 @@ def test_video_evaluator_end_to_end():
         ref_vgg += sum(w * float(F.l1_loss(a, b)) for w, a, b in zip(O.VGG_WEIGHTS, fp, fg))
     assert abs(out["vgg"] - ref_vgg / 2) <= 1e-3 * ref_vgg / 2
     assert abs(out["ssim"] - np.mean([MO.compare_ssim(MO.bgr_to_gray(pred[f]), MO.bgr_to_gray(gt[f])) for f in range(2)])) <= 1e-9
-    assert set(out) == {"ssim", "msssim", "psnr", "l1", "vgg"} and all(np.isfinite(v) for v in out.values())
+    assert set(out) == {"ssim", "msssim", "psnr", "l1", "vgg", "flow"} and all(np.isfinite(v) for v in out.values())
+    # the temporal term: FlowNetSD on the two consecutive-frame pairs (:197-206), oracle = functional restatement pinned
+    # bit-exactly on the imported reference module (oracle/make_golden.py g_flownet)
+    fsd = {k[len("flow_criterion."):]: v for k, v in sd.items() if k.startswith("flow_criterion.")}
+    rgb = lambda a: torch.from_numpy(((a[..., ::-1] / 255. - 0.5) * 2).astype(np.float32).copy()).permute(0, 3, 1, 2)
+    pr, gr = rgb(pred), rgb(gt)
+    with torch.no_grad():
+        a = O.flownet_sd_forward(fsd, torch.cat([pr[:-1], pr[1:]], 1) / 2.0 + 0.5)[0]
+        b = O.flownet_sd_forward(fsd, torch.cat([gr[:-1], gr[1:]], 1) / 2.0 + 0.5)[0]
+    ref_flow = float(F.l1_loss(a, b)) / 2
+    assert ref_flow > 0 and abs(out["flow"] - ref_flow) <= 1e-3 * ref_flow, (out["flow"], ref_flow)
+
+
+def test_flownet_sd_golden(golden_dir):
+    """FlowNetSD (src/flownet2_pytorch/networks/FlowNetSD.py:11-106, batchNorm=False) vs the golden recorded from the
+    imported reference module on the same synthetic weights: all five flows in train mode, flow2 alone in eval mode;
+    conv_transpose2d vs torch for the shapes the network uses; state_dict keys / shapes = the reference's."""
+    import json
+    import os
+    import torch.nn.functional as F
+    from jafpro_amd import ops, synth
+    from jafpro_amd.flownet_sd import FlowNetSD
+    st = dict(np.load(os.path.join(golden_dir, "flownet_sd.npz")))
+    m = FlowNetSD(args=[], batchNorm=False)
+    schema = json.load(open(os.path.join(golden_dir, "state_dict_schema.json")))["FlowNetSD"]
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == schema
+    synth.load_synth(m, 811)
+    m = m.cuda()
+    pairs = torch.from_numpy(st["pairs"]).cuda()
+    flows = m(pairs)
+    assert len(flows) == 5
+    for i, f in enumerate(flows):
+        ref = torch.from_numpy(st["flow%d" % (i + 2)])
+        err = (f.cpu() - ref).abs().max().item()
+        print("flow%d max|diff| %.3e (ref max %.3f)" % (i + 2, err, ref.abs().max().item()))
+        assert err <= 1e-3 * max(1.0, ref.abs().max().item()), (i, err)
+    m.eval()
+    assert len(m(pairs)) == 1 and torch.equal(m(pairs)[0], flows[0])
+    l1 = float(ops.l1_loss(flows[0][:1].contiguous(), flows[0][1:].contiguous()))
+    assert abs(l1 - float(st["flow_l1"])) <= 1e-3 * float(st["flow_l1"])
+    # the transposed convolution alone, odd channel counts and sizes
+    g = torch.Generator().manual_seed(5)
+    for cin, cout, H, W in ((2, 2, 5, 7), (19, 11, 6, 4), (130, 64, 8, 12)):
+        x, w, b = torch.rand(2, cin, H, W, generator=g) - 0.5, torch.rand(cin, cout, 4, 4, generator=g) - 0.5, torch.rand(cout, generator=g)
+        ref = F.leaky_relu(F.conv_transpose2d(x, w, b, stride=2, padding=1), 0.1)
+        with torch.no_grad():
+            out = ops.conv_transpose2d(x.cuda(), w.cuda(), b.cuda(), 2, 1, ops.ACT_LRELU, 0.1)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+    with pytest.raises(RuntimeError):
+        ops.conv_transpose2d(x.cuda().requires_grad_(True), w.cuda(), b.cuda())

@@ -335,6 +335,23 @@ def test_step_fixture_replays_on_the_cpu_oracle(golden_dir):
     assert abs(sampled - exact) <= 0.25 * exact, (sampled, exact)
 
 
+def test_transfer_texture_golden(golden_dir):
+    """oracle/data_oracle.transfer_texture vs the outputs of the reference's own TransferTexture (src/utils.py:369-394,
+    executed by oracle/make_golden.py g_data) on the same seeded uint8 inputs: bit-exact."""
+    import os
+    import numpy as np
+    from jafpro_amd import synth
+    from oracle import data_oracle
+    st = dict(np.load(os.path.join(golden_dir, "transfer_texture.npz")))
+    raw = synth.stage4_raw(int(st["seed"]), 3)
+    for i in range(3):
+        tex, iuv, im = raw["src_texture_u8"][i, 0], raw["tgt_IUV_u8"][i], raw["tgt_img_u8"][i]
+        assert np.array_equal(data_oracle.transfer_texture(tex, iuv), st["plain.%d" % i])
+        assert np.array_equal(data_oracle.transfer_texture(tex, iuv, im), st["over_image.%d" % i])
+    assert np.array_equal(data_oracle.transfer_texture(np.ones((800, 1200, 3), np.uint8), raw["src_IUV0_u8"][0]), st["ones_mask.0"])
+    assert 0.2 < (st["ones_mask.0"] > 0).mean() < 0.6
+
+
 # ---- stage 1 (BASELINE config 1) and checkpoint files (SURVEY 8(f3)) ----
 def test_stage1_config1_step_golden(golden_dir):
     """BASELINE configs[0]: one stage-1 step, B=1, T=4 -- loss, gradients and Adam(1e-4) updates of the oracle against the
