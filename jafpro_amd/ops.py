@@ -371,6 +371,7 @@ def set_packed_images(flag: bool) -> bool:
     return prev
 
 
+_Y_SIGN_FROM_IMAGE = os.environ.get("JAF_NO_Y_SIGN_FROM_IMAGE") is None
 _LAZY_RESIZE = os.environ.get("JAF_NO_LAZY_RESIZE") is None
 
 
@@ -415,6 +416,13 @@ def _check_image(img: PackedImage, N, G, Cin, H, W, what: str):
 def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mode: int, key) -> torch.Tensor:
     """Packs `weight` for (desc, plan, mode); cached while the SAME tensor object is not modified
     (the entry holds a weak reference: a new tensor that reuses a freed address must not hit)."""
+    if not weight.is_leaf:
+        # a temporary (the concatenated CRN head weights, crn_model.py): a new tensor every step, so caching its image only
+        # grew the cache by two dead entries per step; packed into a scratch buffer of the current stream instead
+        buf = torch.empty(int(pl.packed_floats), device=weight.device, dtype=torch.float32)
+        check(lib().jaf_conv2d_pack(_s(), ctypes.byref(d), ctypes.byref(pl), mode, _p(weight), w_rows_tot, _p(buf)),
+              "jaf_conv2d_pack")
+        return buf
     ck = (id(weight), weight.data_ptr(), weight._version, mode, key, pl.MT, pl.CK, pl.precision, pl.nsteps, pl.plane)
     hit = _PACK_CACHE.get(ck)
     if hit is not None and hit.ref() is weight:
@@ -548,7 +556,7 @@ def set_serial_streams(flag: bool) -> bool:
 
 def aux_stream(which: int = 0) -> "torch.cuda.Stream":
     """One of a few long-lived side HIP streams of the current device (0: clip preparation, 1: weight
-    gradients, 2: weight re-packing)."""
+    gradients, 2: weight re-packing, 3: the perceptual loss and its frame gradient beside the discriminator phase)."""
     cur = torch.cuda.current_stream()
     if _SERIAL_STREAMS:
         return cur
@@ -557,6 +565,21 @@ def aux_stream(which: int = 0) -> "torch.cuda.Stream":
     if st is None:
         st = torch.cuda.Stream(device=cur.device)
         _AUX_STREAMS[k] = st
+    return st
+
+
+_CHAIN_STREAMS = {}
+
+
+def chain_stream() -> Optional["torch.cuda.Stream"]:
+    """The high-priority HIP stream a trainer runs its dependent chain on (one per device); None while the streams are
+    serialised for profiling."""
+    if _SERIAL_STREAMS:
+        return None
+    dev = torch.cuda.current_device()
+    st = _CHAIN_STREAMS.get(dev)
+    if st is None:
+        st = _CHAIN_STREAMS[dev] = torch.cuda.Stream(device=dev, priority=-1)
     return st
 
 
@@ -768,8 +791,12 @@ class _ConvFn(Function):
                           and m.act in (ACT_LRELU, ACT_RELU), lazy=m.lazy)
         if m.lazy is not None and xp is None:
             raise RuntimeError("conv2d: a lazily resized source reached a convolution outside the packed bf16 path")
-        # y only as bf16 inside the consumer's image: the activation backward reads it from there
-        ctx.y_img = (m.dst.image, m.dst.coff, m.dst.img_off) if (y.stride(0) == 0 and y.numel() > 1) else None
+        # the activation backward needs only the SIGN of y (ReLU / LeakyReLU), which the consumer's packed bf16 image holds
+        # too: read it from there whenever this layer wrote one (2 B per element instead of 4; the only copy when the fp32
+        # tensor was skipped)
+        ctx.y_img = (m.dst.image, m.dst.coff, m.dst.img_off) if (
+            xp is not None and use_img and m.dst is not None and m.dst.coff % 8 == 0 and m.act in (ACT_LRELU, ACT_RELU)
+            and _Y_SIGN_FROM_IMAGE) or (y.stride(0) == 0 and y.numel() > 1) else None
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
         ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.xp_ng8 = m.prepacked.ng8 if (use_img and m.prepacked is not None) else 0

@@ -119,6 +119,8 @@ WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradi
 # "bwd": everything right before the loss backward, where the CRN competes with the backward's own kernels.
 # Measured at B=8: 68.6 vs 70.4 ms/step.
 PREP_AT = os.environ.get("JAF_PREP_AT", "d")
+# the VGG + L1 loss and its gradient w.r.t. the generated frame on side stream 3, beside the discriminator phase
+VGG_SIDE = os.environ.get("JAF_VGG_SIDE", "1") != "0"
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -303,7 +305,6 @@ class Stage4Trainer:
         its parameter-independent preparation (SMPL projection/rasterisation/flow warp, frozen
         background CRN) is issued on the side HIP stream right before this clip's generator loss
         backward and is picked up by that next call (`next_prosrc`: that call's propagation source)."""
-        M, b = self.M, batch
         # weight-gradient kernels run on their own stream beside the data gradients (ops.set_wgrad_stream)
         prev_ws = ops.set_wgrad_stream(None if not WGRAD_STREAM else ops.aux_stream(1))
         try:
@@ -331,6 +332,18 @@ class Stage4Trainer:
         g.load(batch, next_batch)
         return g.replay()
 
+    @staticmethod
+    def _generator_backward(total, final, fl, g_vgg):
+        """total.backward() (:408).  With the perceptual term taken on the side stream (`fl` given): the adversarial terms are
+        differentiated down to the generated frame (which also leaves their never-used deposit in the discriminators' gradient
+        buffers, F10), the two frame gradients are added, and the generator is differentiated from there."""
+        if fl is None:
+            total.backward()
+            return
+        total.backward()                               # loss is detached: this is 2 errG + 2 F_errG down to `fl` and into D / FD
+        ops.axpby(1.0, g_vgg.contiguous(), 1.0, fl.grad)
+        final.backward(fl.grad)
+
     def _train_step(self, batch, used, prosrc, align_corners, next_batch, next_prosrc):
         M, b = self.M, batch
         fw = self._face_weight(count_faces(b["face_bbox"]))      # before anything is enqueued: may raise on every rank
@@ -350,7 +363,29 @@ class Stage4Trainer:
                 t.record_stream(torch.cuda.current_stream())
         mark = self.phase_mark or (lambda name: None)
         mark("generator forward")
-        loss = M.loss_criterion(final, target, target=vgg_target)                # :332
+        # The perceptual loss and ITS gradient w.r.t. the generated frame (VGG forward + data-gradient chain, 2 x 48 GFLOP
+        # per sample and nothing else depends on them until the generator backward) run on side stream 3 beside the
+        # discriminator phase, whose ~330 launches of 5-40 us leave most of the chip idle; the generator backward then
+        # starts from d(loss)/d(final) + d(2 errG)/d(final).  Same arithmetic: the reference's single backward() sums the
+        # two contributions at `final` just the same (train/4...py:332,407-408).
+        split = VGG_SIDE and torch.is_grad_enabled() and final.requires_grad
+        g_vgg = vgg_done = None
+        if split:
+            main = torch.cuda.current_stream()
+            side = ops.aux_stream(3)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fl3 = final.detach().requires_grad_(True)
+                loss = M.loss_criterion(fl3, target, target=vgg_target)          # :332
+                (g_vgg,) = torch.autograd.grad(loss, fl3)
+                loss = loss.detach()
+                vgg_done = torch.cuda.Event()
+                vgg_done.record(side)
+                if side != main:
+                    for t in [final, target] + ([vgg_target[0]] + list(vgg_target[1]) if vgg_target is not None else []):
+                        t.record_stream(side)
+        else:
+            loss = M.loss_criterion(final, target, target=vgg_target)            # :332
         mark("VGG+L1 loss forward")
         face_pred, face_real, face_IUV = face_crops(final, target, b["tgt_IUV"], b["face_bbox"])
         src0 = b["src_img"][:, 0].contiguous()
@@ -389,9 +424,17 @@ class Stage4Trainer:
             self.flat["D"].adam(self.lrs["D"])
         mark("D x3 updates")
         # ---- generator (:398-413)
-        errG = ops.bce_loss(M.discriminator([dview(final), src0_d]), 1.0)
+        if split:
+            fl = final.detach().requires_grad_(True)     # the adversarial term's own leaf: its gradient joins the VGG term's below
+            errG = ops.bce_loss(M.discriminator([dview(fl), src0_d]), 1.0)
+        else:
+            errG = ops.bce_loss(M.discriminator([dview(final), src0_d]), 1.0)
         F_errG = (ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 1.0) if face_pred is not None
                   else torch.zeros(1, device=final.device))
+        if split:
+            torch.cuda.current_stream().wait_event(vgg_done)
+            for t in (loss, g_vgg):
+                t.record_stream(torch.cuda.current_stream())
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
         if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
             self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True,
@@ -403,11 +446,11 @@ class Stage4Trainer:
             ov.watch(g["fusion_output"], "flow", [self.flat["flow"].grad])
             ov.watch(g["inpaint_warp"], "refine", [self.flat["refine"].grad])
             ov.watch(g["masked"], "inpaint", [self.flat["inpaint"].grad])
-            total.backward()
+            self._generator_backward(total, final, fl if split else None, g_vgg)
             ov.finish([(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")])
             self.overlap_order = list(ov.fired)
         else:
-            total.backward()
+            self._generator_backward(total, final, fl if split else None, g_vgg)
         mark("generator loss backward")
         for n in ("accu", "inpaint", "refine", "flow"):
             self.flat[n].adam(self.lrs[n])
@@ -483,7 +526,7 @@ class GraphedTrainStep:
                         main.wait_event(new.vgg_event)
                     for a, b in self._prep_pairs(self.prep, new):
                         a.copy_(b)
-                for which in (0, 1, 2):              # nothing may be left running on a side stream when the capture ends
+                for which in (0, 1, 2, 3):           # nothing may be left running on a side stream when the capture ends
                     st = ops.aux_stream(which)
                     if st != main:
                         main.wait_stream(st)

@@ -19,6 +19,16 @@ for _ in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print("enqueue %.1f ms, total %.1f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
+# the same step replayed from a captured hipGraph (Stage4Trainer.train_step_graphed)
+tr.train_step_graphed(batch, next_batch=batch)
+torch.cuda.synchronize()
+for _ in range(3):
+    t0 = time.perf_counter()
+    tr.train_step_graphed(batch, next_batch=batch)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print("hipGraph replay: enqueue %.1f ms, total %.1f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); tr.train_step(batch, next_batch=batch); pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(18)

@@ -338,3 +338,42 @@ def test_results_do_not_depend_on_side_stream_timing():
         x, y = float(a[k].reshape(-1)[0]), float(b[k].reshape(-1)[0])
         assert abs(x - y) <= 1e-4 * max(1.0, abs(x)), (k, x, y)
     assert rel_l2(b["final_output"], a["final_output"]) <= 1e-4
+
+
+def test_graphed_step_matches_the_eager_step():
+    """Stage4Trainer.train_step_graphed: the whole step captured once into a hipGraph (device-side Adam step counts, the
+    next clip's preparation handed over through a static slot, every side stream joined) and replayed must train like the
+    eager step, f32 arithmetic.  The GAN terms of this step are chaotic at B=1 -- two EAGER trainers started from the same
+    weights differ by 5e-4 in errD after four steps and by 1.2e-2 after six (fp32 atomics reorder the weight-gradient sums,
+    Adam's first updates are sign-like; measured with scratch/graph_dbg.py) -- so the first replay is held to 2e-3 and the two
+    after it to 3e-2; total / perceptual loss to 1e-3 throughout; a stale clip preparation, a missed update or a frozen
+    step count shows up at 1e-1 .. 1.  The first graphed call runs eagerly and captures."""
+    M1, tr1, _, batch, dbatch, _ = build(1)
+    M2, tr2, _, _, _, _ = build(1)
+    for tr in (tr1, tr2):                    # warm every host-side cache: the capture then needs no settling step
+        for _ in range(2):
+            tr.train_step(dbatch, next_batch=dbatch)
+    outs = []
+    for _ in range(4):
+        o = tr1.train_step(dbatch, next_batch=dbatch)
+        outs.append({k: v.clone() for k, v in o.items()})
+    for i in range(4):
+        o = tr2.train_step_graphed(dbatch, next_batch=dbatch)
+        torch.cuda.synchronize()
+        for k in LOSSES:
+            a, b = float(outs[i][k].reshape(-1)[0]), float(o[k].reshape(-1)[0])
+            tol = 1e-3 if k in ("total_loss", "vgg_l1") else (2e-3 if i <= 1 else 3e-2)
+            assert abs(a - b) <= tol * max(1.0, abs(a)), (i, k, a, b)
+        # frames: two eager trainers are ~5e-3 apart by their 4th step and ~2.5e-2 by their 6th
+        assert rel_l2(o["final_output"], outs[i]["final_output"]) <= (1e-2 if i <= 1 else 1e-1), i
+    g = next(iter(tr2._graphs.values()))
+    assert g.settle_steps == 1 and g.replays == 3
+    for n in TRAINABLE:
+        assert tr1.flat[n].step_count == tr2.flat[n].step_count == (18 if n == "D" else 6)
+        assert int(tr2.flat[n].dev_state.view(torch.int32)[0]) == tr2.flat[n].step_count
+        assert rel_l2(tr2.flat[n].flat, tr1.flat[n].flat) <= 2e-3, n
+    # a different propagation source is another graph key: captured separately (that call runs eagerly)
+    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)
+    assert len(tr2._graphs) == 2 and all(bool(torch.isfinite(o_g[k]).all()) for k in LOSSES)
+    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)
+    assert all(bool(torch.isfinite(o_g[k]).all()) for k in LOSSES) and tr2.flat["accu"].step_count == 8
