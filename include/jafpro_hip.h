@@ -189,6 +189,7 @@ int jaf_convlstm_cell_fwd_packed(jaf_stream_t s, const jaf_conv_desc* d, const j
  * by the producers -- and a consumer may read the leading planes of a larger image (enc_{i+1} reads x_i out of the
  * ConvLSTM's [x_i, h] image).  Values are the RNE bf16 roundings jaf_conv2d_pack_input would have produced.
  * All-zero / NULL = the plain behaviour. */
+#define JAF_DZ_BIAS_SLOTS 16
 typedef struct jaf_packed_io {
     int32_t in_ng8_tot;      /* planes per (image, group) of the packed INPUT image; 0 = ceil(Cin/8) */
     void* dst;               /* destination packed image of this launch's outputs (NULL: none) */
@@ -205,6 +206,20 @@ typedef struct jaf_packed_io {
                               * out_coff then only have to be valid for Cout rows; they are not used).  The ConvLSTM's
                               * data gradient w.r.t. [x_t, h_{t-1}] in ONE launch: the gate gradients are read once */
     int32_t split_rows;
+    /* Backward hand-over in bf16 (data-gradient launches): with `dz_mask` set, what goes to `dst` is not act(result + bias) but
+     *   dz = (result [+ *out, when accumulate_f32]) * act'(x),   act' = 1 where x > 0, else dz_slope  (ReLU: 0, LeakyReLU: its slope),
+     * i.e. the PRODUCER layer's packed dz -- the activation backward and the bf16 packing that jaf_conv2d_pack_dz would do in a
+     * pass of its own, taken while the data gradient is in registers.  x = act(y) is read from the packed bf16 image this
+     * launch's consumer layer read in its forward pass (`dz_mask`: dz_mask_ng8 planes per (image, group), the tensor's channels
+     * from dz_mask_coff, a multiple of 8; only the sign is used).  With accumulate_f32 the first consumer's gradient is read
+     * from `out` and NOT written back (use with skip_f32 = 0 only for that read; nothing is stored in fp32).
+     * dz_dbias (nullable): [JAF_DZ_BIAS_SLOTS][G*Cout] += per-channel sums of dz -- the producer's bias gradient, spread over
+     * JAF_DZ_BIAS_SLOTS copies that the caller sums (jaf_sum_slots): one atomic per channel and workgroup goes to copy
+     * (workgroup index % JAF_DZ_BIAS_SLOTS). */
+    const void* dz_mask;
+    int32_t dz_mask_ng8, dz_mask_coff;
+    float dz_slope;
+    float* dz_dbias;
 } jaf_packed_io;
 int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                              const void* packed_in, const void* packed_w, const float* bias, float* out,
@@ -522,6 +537,8 @@ int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m, float* v, 
  * state[1..2] scratch.  For launches replayed from a captured hipGraph, whose arguments cannot change. */
 int jaf_adam_step_dev(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                       float beta2, float eps, float* state);
+/* out[i] (+)= sum over s < slots of in[s*n + i]  (the slot copies of jaf_packed_io.dz_dbias). */
+int jaf_sum_slots(jaf_stream_t s, const float* in, int32_t slots, int64_t n, float* out, int accumulate);
 /* y = a*x + b*y elementwise (gradient accumulation, scaling). */
 int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float* y, int64_t n);
 

@@ -81,7 +81,9 @@ class PackedIO(ctypes.Structure):
     _fields_ = [("in_ng8_tot", ctypes.c_int32), ("dst", ctypes.c_void_p), ("dst_ng8_tot", ctypes.c_int32),
                 ("dst_coff", ctypes.c_int32), ("dst_img_off", ctypes.c_int32), ("dst_pad_tail", ctypes.c_int32),
                 ("skip_f32", ctypes.c_int32), ("accumulate_f32", ctypes.c_int32),
-                ("out2", ctypes.c_void_p), ("split_rows", ctypes.c_int32)]
+                ("out2", ctypes.c_void_p), ("split_rows", ctypes.c_int32),
+                ("dz_mask", ctypes.c_void_p), ("dz_mask_ng8", ctypes.c_int32), ("dz_mask_coff", ctypes.c_int32),
+                ("dz_slope", ctypes.c_float), ("dz_dbias", ctypes.c_void_p)]
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4

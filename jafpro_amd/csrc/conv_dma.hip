@@ -53,6 +53,11 @@ struct ConvDArgs {
     int acc_out;           // out += result (jaf_packed_io.accumulate_f32)
     float* out2;           // rows >= split of every group go here (jaf_packed_io.out2); nullptr: everything to `out`
     int split;
+    // fused activation backward (jaf_packed_io.dz_mask): `dst` receives dz = (acc [+ *out]) * act'(x) of the PRODUCER layer
+    const unsigned char* dz_mask;
+    int dz_mask_ng8, dz_mask_coff;
+    float dz_slope;
+    float* dz_dbias;
 };
 
 // Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
@@ -922,7 +927,15 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             // (dst_coff % 4 == 0); lanes q and q^1 complete the item within the same store instruction.
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
             const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
-            const int cpad = a.dst_pad_tail ? ((a.dst_coff + d.Cout + 7) & ~7) - a.dst_coff : d.Cout;   // rows < cpad are written
+            // dz mode with a second fp32 output (the ConvLSTM's d[x_t, h_{t-1}] launch): only the rows below `split` (dx) are the
+            // producer's dz; the rows from `split` on (dh) leave through out2 as always
+            const int dC = (a.dz_mask && a.out2) ? a.split : d.Cout;
+            float wsum[MT][4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wsum[mt][j] = 0.f;
+            const int cpad = a.dst_pad_tail ? ((a.dst_coff + dC + 7) & ~7) - a.dst_coff : dC;   // rows < cpad are written
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int co0 = mb * MR + mt * 16 + q * 4;
@@ -930,12 +943,60 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 float bv[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bv[j] = (a.bias && co0 + j < d.Cout) ? a.bias[g * d.Cout + co0 + j] : 0.f;
+                float bsum[4] = {0.f, 0.f, 0.f, 0.f};     // dz mode: this lane's share of the producer's bias gradient
+                // dz mode, second of two consumers: the first one's gradient, 4 channels x NT pixels (one vector load per
+                // channel when the lane's pixels are consecutive)
+                float part[4][NT];
+                if (a.dz_mask && a.acc_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) part[j][nt] = 0.f;
+                        if (co0 + j < dC) {
+                            const float* pp = a.out2 ? a.out + (((long)n * d.G + g) * a.split + co0 + j) * OHW
+                                                     : a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co0 + j) * OHW;
+                            if (vec) {
+                                if (opix[0] >= 0) {
+                                    const fvec pv = *(const fvec*)(pp + opix[0]);
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt) part[j][nt] = pv[nt];
+                                }
+                            } else {
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    if (opix[nt] >= 0) part[j][nt] = pp[opix[nt]];
+                            }
+                        }
+                    }
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     if (opix[nt] < 0) continue;
                     float v[4];
+                    if (a.dz_mask) {
+                        // producer's dz: (this data gradient [+ the first consumer's]) * act'(x), x from the packed image the
+                        // consumer layer read (4 consecutive channels = 8 bytes of a 16-byte item)
+                        const long ngm = ((long)n) * d.G + g;
+                        const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
+                                                                                  a.dz_mask_coff + co0, OHW, opix[nt]);
+                        const unsigned int x01 = xp2[0], x23 = xp2[1];
+                        const float xs[4] = {__builtin_bit_cast(float, x01 << 16), __builtin_bit_cast(float, x01 & 0xffff0000u),
+                                             __builtin_bit_cast(float, x23 << 16), __builtin_bit_cast(float, x23 & 0xffff0000u)};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = (co0 + j < d.Cout) ? jaf_act(acc[mt][nt][j] + bv[j], d.act, d.slope) : 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            float t = 0.f;
+                            if (co0 + j < dC) {
+                                t = acc[mt][nt][j];
+                                if (a.acc_out) t += part[j][nt];
+                                t *= (xs[j] > 0.f) ? 1.f : a.dz_slope;
+                            }
+                            v[j] = t;
+                            bsum[j] += t;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (co0 + j < d.Cout) ? jaf_act(acc[mt][nt][j] + bv[j], d.act, d.slope) : 0.f;
+                    }
                     u32x2 w = {cd_pack2(v[0], v[1]), cd_pack2(v[2], v[3])};
                     if (co0 + 4 <= cpad || a.dst_pad_tail) {
                         *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]) = w;
@@ -944,17 +1005,45 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         const unsigned int ww[2] = {w[0], w[1]};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (co0 + j < d.Cout) hp[j] = (unsigned short)(ww[j >> 1] >> ((j & 1) * 16));
+                            if (co0 + j < dC) hp[j] = (unsigned short)(ww[j >> 1] >> ((j & 1) * 16));
+                    }
+                }
+                if (a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = bsum[j];
+                        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
+                        wsum[mt][j] = t;
                     }
                 }
             }
+            if (a.dz_mask && a.dz_dbias) {
+                // workgroup sum of the four waves in LDS (the patch buffer is free once every wave has left the matrix-core
+                // loop), then ONE atomic per channel and workgroup, spread over JAF_DZ_BIAS_SLOTS copies of the vector
+                // (same-address fp32 atomics serialise: one per wave and channel made these launches 3x slower)
+                __syncthreads();
+                float* red = (float*)smem;                      // [4 waves][MT * 16 rows]
+                if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) red[(threadIdx.x >> 6) * (MT * 16) + mt * 16 + q * 4 + j] = wsum[mt][j];
+                }
+                __syncthreads();
+                if (threadIdx.x < MT * 16) {
+                    const int co = mb * MR + threadIdx.x;
+                    const float t = (red[threadIdx.x] + red[MT * 16 + threadIdx.x]) + (red[2 * MT * 16 + threadIdx.x] + red[3 * MT * 16 + threadIdx.x]);
+                    if (co < dC && t != 0.f)
+                        atomicAdd(&a.dz_dbias[(long)(blockIdx.x % JAF_DZ_BIAS_SLOTS) * (d.G * dC) + g * dC + co], t);
+                }
+            }
         }
-        if (a.skip_f32) return;
+        if (a.skip_f32 || (a.dz_mask && !a.out2)) return;
 #define CD_EPILOGUE(ACT_, ST_)                                                                        \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
-                if (co < d.Cout) {                                                                    \
+                if (co < d.Cout && !(a.dz_mask && co < a.split)) {      /* (dz rows went to `dst`) */  \
                     const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
                     const bool second = a.out2 && co >= a.split;                                      \
                     float* op = second ? a.out2 + (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW \
@@ -1528,6 +1617,10 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.acc_out = 0;
     a.out2 = nullptr;
     a.split = 0;
+    a.dz_mask = nullptr;
+    a.dz_mask_ng8 = a.dz_mask_coff = 0;
+    a.dz_slope = 0.f;
+    a.dz_dbias = nullptr;
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1536,14 +1629,24 @@ static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm)
     const int cout = lstm ? (d->Cout >> 2) : d->Cout;        // channels this launch writes per group (LSTM: the hidden state)
     if (io->dst) {
         if (io->dst_ng8_tot < 1 || io->dst_coff < 0 || (io->dst_coff & 3) || io->dst_img_off < 0) return false;
-        const int end = io->dst_coff + (io->dst_pad_tail ? ((cout + 7) & ~7) : cout);
+        const int wr = (!lstm && io->dz_mask && io->out2) ? io->split_rows : cout;          // channels actually written to dst
+        const int end = io->dst_coff + (io->dst_pad_tail ? ((wr + 7) & ~7) : wr);
         if (end > io->dst_ng8_tot * 8) return false;
         if (lstm && io->dst_pad_tail) return false;
     } else if (io->skip_f32 && !lstm) {
         return false;                                         // a launch that writes nothing
     }
-    if (io->accumulate_f32 && (lstm || io->skip_f32)) return false;
-    if (io->out2 && (lstm || io->skip_f32 || io->dst || io->split_rows < 1 || io->split_rows >= d->Cout)) return false;
+    if (io->dz_mask) {
+        // fused activation backward: a plain data-gradient launch whose only output is the packed dz image
+        if (lstm || !io->dst || io->dst_coff != 0 || !io->dst_pad_tail) return false;
+        const int dzc = io->out2 ? io->split_rows : d->Cout;
+        if (io->dz_mask_ng8 < 1 || io->dz_mask_coff < 0 || (io->dz_mask_coff & 7) ||
+            io->dz_mask_coff / 8 + jaf_cdiv(dzc, 8) > io->dz_mask_ng8) return false;
+        if (jaf_cdiv(dzc, 8) > io->dst_ng8_tot) return false;
+        if (io->skip_f32 && io->accumulate_f32) return false;      // the first consumer's gradient is read from `out`
+    }
+    if (io->accumulate_f32 && (lstm || (io->skip_f32 && !io->dz_mask))) return false;
+    if (io->out2 && (lstm || io->skip_f32 || (io->dst && !io->dz_mask) || io->split_rows < 1 || io->split_rows >= d->Cout)) return false;
     return true;
 }
 
@@ -1557,6 +1660,11 @@ static void cd_apply_io(ConvDArgs& a, const jaf_packed_io* io) {
     a.dst_pad_tail = io->dst_pad_tail ? 1 : 0;
     a.skip_f32 = io->skip_f32 ? 1 : 0;
     a.acc_out = io->accumulate_f32 ? 1 : 0;
+    a.dz_mask = (const unsigned char*)io->dz_mask;
+    a.dz_mask_ng8 = io->dz_mask_ng8;
+    a.dz_mask_coff = io->dz_mask_coff;
+    a.dz_slope = io->dz_slope;
+    a.dz_dbias = io->dz_dbias;
     a.out2 = io->out2;
     a.split = io->out2 ? io->split_rows : 0;
 }

@@ -435,6 +435,21 @@ extern "C" int jaf_adam_step_dev(jaf_stream_t s, float* p, const float* g, float
     return jaf_launch_status();
 }
 
+__global__ void sum_slots_kernel(const float* in, int slots, long n, float* out, int accumulate) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float t = 0.f;
+        for (int s = 0; s < slots; ++s) t += in[(long)s * n + i];
+        out[i] = accumulate ? out[i] + t : t;
+    }
+}
+
+extern "C" int jaf_sum_slots(jaf_stream_t s, const float* in, int32_t slots, int64_t n, float* out, int accumulate) {
+    JAF_REQUIRE(in && out && slots >= 1 && n >= 1);
+    hipLaunchKernelGGL(sum_slots_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, in, slots, (long)n, out, accumulate);
+    return jaf_launch_status();
+}
+
 __global__ void axpby_kernel(float a, const float* x, float b, float* y, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

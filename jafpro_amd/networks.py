@@ -119,6 +119,8 @@ class _PartEncoderMixin:
             keep = (i < 8 and ENC_S[i + 1] == 2 and c > 16) or (tap is None and i % 2 == 0)
             x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2,
                             prepacked=img_in, dst=dst, keep_f32=keep)
+            if i % 2 == 1:
+                ops.mark_single_consumer(x)          # x2, x4, x6, x8 feed enc_{i+1} only: dz handed over in bf16 (ops._fusable_producer)
             if i % 2 == 0:
                 if (tap is not None or skips_feed_one_conv) and i < 8:
                     # read by enc_{i+1} and by exactly one more convolution / ConvLSTM (the level's ConvLSTM; the
@@ -450,6 +452,8 @@ class VGG19_CRN(nn.Module):
                 img_in = img_out
                 if idx in self.TAPS:
                     feats.append(x)
+                elif nxt_is_conv:
+                    ops.mark_single_consumer(x)      # read by the next convolution only (the tapped layers also feed the loss)
         return feats
 
 

@@ -392,10 +392,14 @@ def packed_active() -> bool:
 
 
 def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False,
-               accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0) -> Optional[PackedIO]:
+               accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0, dz_fuse=None) -> Optional[PackedIO]:
     if prepacked is None and dst is None and not accumulate and out2 is None:
         return None
     io = PackedIO()
+    if dz_fuse is not None:       # (mask image buffer, its planes per (image, group), channel offset, act' below zero, dbias or None)
+        mbuf, mng8, mcoff, mslope, dbias = dz_fuse
+        io.dz_mask, io.dz_mask_ng8, io.dz_mask_coff, io.dz_slope = mbuf.data_ptr(), int(mng8), int(mcoff), float(mslope)
+        io.dz_dbias = dbias.data_ptr() if dbias is not None else None
     io.accumulate_f32 = 1 if accumulate else 0
     if out2 is not None:
         io.out2, io.split_rows = out2.data_ptr(), split
@@ -630,8 +634,9 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
               xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
               prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False, lazy=None,
-              accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0):
+              accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0, dz_fuse=None):
     """`accumulate`: out += result (packed bf16 path only; `out` must be given): see GradSlot.
+    `dz_fuse`: the launch is a data gradient whose only output is the PRODUCER layer's packed dz in `dst` (jaf_packed_io.dz_mask).
     `out2`, `split`: rows >= split of every group go to out2 [N, G*(Cout-split), OH, OW], the others to `out` taken as
     [N, G*split, OH, OW] (pass out_ctot = G*Cout): jaf_packed_io.out2."""
     skip_f32 = skip_f32 and dst is not None and ln_stats is None
@@ -661,7 +666,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
             if dst.img_off + N > dst.image.N:
                 raise RuntimeError("conv2d destination: images %d..%d outside the packed image (%d)" % (dst.img_off, dst.img_off + N, dst.image.N))
-        io = _io_struct(prepacked, dst, skip_f32, accumulate, out2, split)
+        io = _io_struct(prepacked, dst, skip_f32, accumulate, out2, split, dz_fuse)
         sums = None
         if ln_stats is not None:
             ln_stats.filled = False
@@ -731,14 +736,65 @@ def share_gradslot(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
     slot = getattr(src, "_jaf_gradslot", None)
     if slot is not None:
         view._jaf_gradslot = slot
+        view._jaf_src = src          # the tensor the view was taken of: its producer may take its dz from this consumer
     return view
 
 
+FUSED_STATS = {"dz": 0}                      # data-gradient launches that handed their producer a packed dz (tests)
 SLOT_STATS = {"first": 0, "added": 0}        # how often a slot received a first gradient / an in-place second one (tests)
 
 
 def _slot_of(t) -> Optional["GradSlot"]:
     return getattr(t, "_jaf_gradslot", None)
+
+
+_FUSED_DZ = os.environ.get("JAF_NO_FUSED_DZ") is None
+
+
+def mark_single_consumer(t: torch.Tensor) -> torch.Tensor:
+    """Module code states that `t` (a convolution's output) is read by exactly ONE operation, a convolution: that
+    consumer's data-gradient epilogue may then hand the producer its packed dz directly (no fp32 gradient tensor, no
+    jaf_conv2d_pack_dz pass)."""
+    if t.requires_grad and packed_active():
+        t._jaf_single = True
+    return t
+
+
+_DZ_BIAS_SLOTS = 16       # JAF_DZ_BIAS_SLOTS
+
+
+def _dz_bias_slots(prod, n: int, device):
+    """Slot copies of the producer's bias gradient that a dz-mode launch adds into (None: the producer has no trainable bias)."""
+    if prod.has_bias and prod.needs_input_grad[1]:
+        return torch.zeros(_DZ_BIAS_SLOTS * n, device=device, dtype=torch.float32)
+    return None
+
+
+def _dz_bias_finish(prod, slots, n: int):
+    """Sums the slot copies into the producer's bias gradient: in place when its .grad buffer exists (returns None), else
+    into a new tensor that the producer's backward returns."""
+    if slots is None:
+        return None
+    pb = prod.bias_ref
+    inplace = _grad_inplace(pb)
+    out = pb.grad if inplace else torch.empty(n, device=slots.device, dtype=torch.float32)
+    check(lib().jaf_sum_slots(_s(), _p(slots), _DZ_BIAS_SLOTS, n, _p(out), 1 if inplace else 0), "jaf_sum_slots")
+    return None if inplace else out
+
+
+def _fusable_producer(t: torch.Tensor, spec):
+    """The _ConvFn node that made `t`, if its activation backward can be taken in its consumer's data-gradient epilogue."""
+    fn = t.grad_fn
+    if fn is None or type(fn).__name__ != "_ConvFnBackward" or spec[3] == 0:
+        return None
+    pm = getattr(fn, "meta", None)
+    if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or getattr(fn, "mode", None) != (PREC_BF16, True):
+        return None
+    if pm.G * pm.Cout != t.shape[1] or spec[0] != pm.Cout:          # the whole output, group for group
+        return None
+    if fn.needs_input_grad[0] and fn.xp is None:                      # its weight gradient needs an fp32 dz
+        return None
+    return fn
 
 
 class _ConvMeta:
@@ -805,6 +861,19 @@ class _ConvFn(Function):
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.slots = [_slot_of(t) for t in srcs]
+        # backward hand-over in bf16 (jaf_packed_io.dz_mask): sources whose producer is a ReLU / LeakyReLU convolution of the
+        # packed path get their dz = dx * act'(x), packed, straight from THIS layer's data-gradient epilogue -- when this layer
+        # is the last one to contribute to dx (its only consumer, or the second of a GradSlot pair).  x's sign is read from the
+        # packed image this layer consumed.
+        ctx.fused = None
+        ctx.prods = None
+        ctx.mask = None
+        if xp is not None and _FUSED_DZ and any(ctx.needs_input_grad[3:]):
+            prods = [_fusable_producer(t, spec) for t, spec in zip(srcs, m.specs)]
+            if any(p is not None for p in prods):
+                ctx.prods = prods
+                ctx.single = [bool(getattr(t, "_jaf_single", False)) for t in srcs]
+                ctx.mask = (xp, m.prepacked.ng8 if (use_img and m.prepacked is not None) else (m.Cin + 7) // 8)
         ctx.save_for_backward(weight, y if m.act != ACT_NONE else None, *srcs)
         return y
 
@@ -818,14 +887,22 @@ class _ConvFn(Function):
         m: _ConvMeta = ctx.meta
         weight, y = ctx.saved_tensors[0], ctx.saved_tensors[1]
         srcs = ctx.saved_tensors[2:]
-        dy = _c(dy)
+        if getattr(ctx, "fused", None) is None:       # (a handed-over dz comes with a storage-less placeholder for dy)
+            dy = _c(dy)
         L = lib()
         bias = ctx.bias_ref
         want_db = ctx.has_bias and ctx.needs_input_grad[1]
         db = None
         db_done = False
         dzp = None       # packed dz: shared by the data gradients of all sources and the weight gradient
-        if _USE_PACKED and _PRECISION == PREC_BF16:
+        fused = getattr(ctx, "fused", None)
+        if fused is not None:
+            # the consumer's data-gradient epilogue already made dz (bf16, packed) and the bias gradient: `dy` is a placeholder
+            dzp, db = fused
+            ctx.fused = None
+            dz = None
+            db_done = True
+        elif _USE_PACKED and _PRECISION == PREC_BF16:
             # one pass: activation backward + bias gradient + packed bf16 dz (+ fp32 dz only if the
             # weight gradient of this layer still runs on the fp32-input kernel)
             need_f32 = ctx.needs_input_grad[0] and ctx.xp is None
@@ -880,6 +957,26 @@ class _ConvFn(Function):
                 spec = [(m.Cout, m.G * m.Cout, 0, m.Cout)]
                 slot = ctx.slots[i] if gs != 0 else None
                 first = slot.take((m.N, m.G * c, m.H, m.W)) if slot is not None else None
+                prod = ctx.prods[i] if ctx.prods is not None else None
+                if prod is not None and coff % 8 == 0 and ((slot is not None and first is not None) or (slot is None and ctx.single[i])):
+                    # last contribution to dx: write the producer's packed dz (and bias gradient) instead of an fp32 dx
+                    pm = prod.meta
+                    dzimg = PackedImage(m.N, m.G, c, m.H, m.W, dy.device)
+                    pdb = _dz_bias_slots(prod, m.G * c, dy.device)
+                    mbuf, mng8 = ctx.mask
+                    g, dzp = _conv_raw([dz] if dz is not None else [dy], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c,
+                                       m.OH, m.OW, m.H, m.W, m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0,
+                                       xp=dzp, want_xp=True, out=first, out_ctot=(m.G * c) if first is not None else None,
+                                       accumulate=first is not None, dst=dzimg.slot(0, 0, pad_tail=True), skip_f32=first is None,
+                                       dz_fuse=(mbuf, mng8, coff, pm.slope if pm.act == ACT_LRELU else 0.0, pdb))
+                    prod.fused = (dzimg.buf, _dz_bias_finish(prod, pdb, m.G * c))
+                    FUSED_STATS["dz"] += 1
+                    if first is not None:
+                        g = None
+                        SLOT_STATS["added"] += 1
+                    dsrcs.append(g)      # (single consumer: the storage-less placeholder _conv_raw made)
+                    coff += c
+                    continue
                 g, dzp = _conv_raw([dz] if dz is not None else [dy], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
                                    m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0, xp=dzp,
                                    want_xp=True, out=first, out_ctot=(m.G * c) if first is not None else None,
@@ -1092,6 +1189,11 @@ class _ConvLSTMFn(Function):
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
         ctx.slot = _slot_of(x)
+        # the layer that made x (enc_i) may get its packed dz from this node's d x launches (see _ConvFn.forward)
+        src = getattr(x, "_jaf_src", None)
+        ctx.prod = None
+        if use_img and keep and src is not None and _FUSED_DZ and ctx.slot is not None and src.dim() == 4 and src.shape[0] == T * N:
+            ctx.prod = _fusable_producer(src, (C, GC, 0, C))
         c_last = cs[T - 1].clone() if want_c else None          # (a copy: cs is saved for backward)
         if need_all:
             return hs, c_last
@@ -1136,6 +1238,13 @@ class _ConvLSTMFn(Function):
         dc = _c(dc_last) if dc_last is not None else None
         dh = None
         ng8 = (4 * C + 7) // 8
+        # last contribution to dx (the other consumer's gradient is already in dx_first): hand the producer of x its packed dz
+        prod = getattr(ctx, "prod", None) if (dx_first is not None and fused) else None
+        dzimg = pdb = None
+        if prod is not None:
+            dzimg = PackedImage(T * N, G, C, H, W, x.device)
+            pdb = _dz_bias_slots(prod, GC, x.device)
+            pslope = prod.meta.slope if prod.meta.act == ACT_LRELU else 0.0
         for t in range(T - 1, -1, -1):
             first = t == 0 and not ctx.has_state
             hprev = h0 if t == 0 else hs[t - 1]
@@ -1195,20 +1304,27 @@ class _ConvLSTMFn(Function):
                 # d[x_t, h_{t-1}] in one launch: 2C rows per group, the x rows into dx[t], the h rows into dh -- the packed gate
                 # gradients (4C channels) are read once instead of twice
                 dh = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
+                fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
+                                                    dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
                 _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, 2 * C, H, W, H, W, 3, 3, 1, 1, 1,
                                    1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=2 * GC, out_coff=0, xp=gtp, want_xp=True,
-                                   accumulate=dx_first is not None, out2=dh, split=C)
+                                   accumulate=dx_first is not None, out2=dh, split=C, **(fz or {}))
             else:
                 if dx is not None:
+                    fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
+                                                        dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
                     _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                        1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True,
-                                       accumulate=dx_first is not None)
+                                       accumulate=dx_first is not None, **(fz or {}))
                 if not first:
                     dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                    1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
             dc = dc_prev
         dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None
         dc0 = dc if (ctx.has_state and ctx.needs_input_grad[6]) else None
+        if prod is not None:
+            prod.fused = (dzimg.buf, _dz_bias_finish(prod, pdb, GC))
+            FUSED_STATS["dz"] += 1
         if dx_first is not None:
             dx = None            # added into the other consumer's gradient
             SLOT_STATS["added"] += 1

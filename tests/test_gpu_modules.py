@@ -345,7 +345,15 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                         out = m.forward_grouped(x, T_) if cls is Accumulate_LSTM_no_loss else m.forward_grouped(x)
                     proj = T(synth.uniform(seed, "proj", tuple(out.shape)))
                     added = ops.SLOT_STATS["added"]
+                    handed = ops.FUSED_STATS["dz"]
                     (out * proj).sum().backward()
+                    # with the images on, the last data gradient of a ReLU / LeakyReLU convolution's output hands that layer
+                    # its packed dz directly (jaf_packed_io.dz_mask): in the part encoders x1,3,5,7 (from the second of their
+                    # two consumers: the ConvLSTM's d x launches / enc_{i+1}) and x2 (one consumer; enc4/6/8 are wide
+                    # stride-2 layers whose weight gradient still needs an fp32 dz), in VGG the untapped conv -> conv edges;
+                    # the reference path packs every dz in a pass of its own
+                    want = {Accumulate_LSTM_no_loss: 5, UNet_inpainter: 5, VGG19_CRN: 7, CRN_smaller: 0}[cls] if images else 0
+                    assert ops.FUSED_STATS["dz"] - handed == want, (cls.__name__, images, ops.FUSED_STATS["dz"] - handed)
                     if cls is Accumulate_LSTM_no_loss:
                         # skip features x1, x3, x5, x7 have two consumers (ConvLSTM, enc_{i+1}): with the images on, the
                         # second data gradient is added inside the kernel (ops.GradSlot) -- same numbers, bit for bit

@@ -345,8 +345,8 @@ def test_graphed_step_matches_the_eager_step():
     next clip's preparation handed over through a static slot, every side stream joined) and replayed must train like the
     eager step, f32 arithmetic.  The GAN terms of this step are chaotic at B=1 -- two EAGER trainers started from the same
     weights differ by 5e-4 in errD after four steps and by 1.2e-2 after six (fp32 atomics reorder the weight-gradient sums,
-    Adam's first updates are sign-like; measured with scratch/graph_dbg.py) -- so the first replay is held to 2e-3 and the two
-    after it to 3e-2; total / perceptual loss to 1e-3 throughout; a stale clip preparation, a missed update or a frozen
+    Adam's first updates are sign-like; measured with scratch/graph_dbg.py: F_errG 2.8e-3 apart at the 4th step) -- so the
+    first replay is held to 6e-3 and the two after it to 3e-2; total / perceptual loss to 1e-3 throughout; a stale clip preparation, a missed update or a frozen
     step count shows up at 1e-1 .. 1.  The first graphed call runs eagerly and captures."""
     M1, tr1, _, batch, dbatch, _ = build(1)
     M2, tr2, _, _, _, _ = build(1)
@@ -362,7 +362,7 @@ def test_graphed_step_matches_the_eager_step():
         torch.cuda.synchronize()
         for k in LOSSES:
             a, b = float(outs[i][k].reshape(-1)[0]), float(o[k].reshape(-1)[0])
-            tol = 1e-3 if k in ("total_loss", "vgg_l1") else (2e-3 if i <= 1 else 3e-2)
+            tol = 1e-3 if k in ("total_loss", "vgg_l1") else (6e-3 if i <= 1 else 3e-2)
             assert abs(a - b) <= tol * max(1.0, abs(a)), (i, k, a, b)
         # frames: two eager trainers are ~5e-3 apart by their 4th step and ~2.5e-2 by their 6th
         assert rel_l2(o["final_output"], outs[i]["final_output"]) <= (1e-2 if i <= 1 else 1e-1), i
