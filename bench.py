@@ -128,6 +128,7 @@ def main():
                     help="frame size: 256 = the BASELINE metric's configuration (configs[2]); 512 = configs[4] geometry "
                          "(no reference implementation; throughput only, no cpu_baseline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the forward-only BASELINE configs[1] figure (N=1 only)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each clip inside its own step instead of one step ahead")
@@ -145,14 +146,24 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    # CPU baseline first (rank 0, N=1), before this process initialises the GPU
-    cpu_result = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.size == 256:
+    if args.cpu_baseline_only:
+        # child process of the default run (below): the CPU oracle alone, one JSON line
         from jafpro_amd import synth as _synth
         _, _fidx = _synth.body_mesh()
         _M, _mods = build_models(_fidx)
-        cpu_result = cpu_baseline(_mods, _fidx)
-        del _M, _mods
+        print(json.dumps(cpu_baseline(_mods, _fidx)))
+        return
+    # CPU baseline first (rank 0, N=1), in a CHILD process started before this one touches the GPU: the oracle's 16 OpenMP
+    # threads and its ~40 GB of host memory are gone when the timed loop starts (run in-process they left 80-95 ms
+    # outliers in the first ten timed steps: profiles/round3_a_bench_bf16.json `step_ms`)
+    cpu_result = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.size == 256:
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise SystemExit("cpu baseline failed:\n" + r.stderr[-2000:])
+        cpu_result = json.loads(lines[-1])
     # JAF_BENCH_BACKEND=gloo with JAF_BENCH_SHARE_GPU=1 lets several ranks share one GPU: the way the N>1 control
     # flow of this file is exercised on a 1-GPU box (RCCL refuses two ranks on one device); never a measurement.
     backend = os.environ.get("JAF_BENCH_BACKEND", "nccl")
@@ -212,11 +223,8 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    host_s = 0.0
     for i in range(args.steps):
-        h0 = time.perf_counter()
         out = step_fn(batch, next_batch=nb)
-        host_s += time.perf_counter() - h0
         marks[i + 1].record()           # on the main stream, no synchronisation: per-step durations for the median
     barrier()
     elapsed = time.perf_counter() - t0
@@ -227,6 +235,14 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = world * B * args.steps / elapsed
+
+    # host cost of one step: enqueue time with an EMPTY queue (inside the timed loop the host runs ahead of the GPU until the
+    # HIP queues push back, so its per-step time there only mirrors the GPU's)
+    torch.cuda.synchronize()
+    h0 = time.perf_counter()
+    step_fn(batch, next_batch=nb)
+    host_enqueue_ms = (time.perf_counter() - h0) * 1e3
+    barrier()
 
     result = {
         "metric": "train-step frames/sec, %dx%d 30-frame clips, stage-4" % (args.size, args.size),
@@ -245,9 +261,9 @@ def main():
                    "clips_per_s": frames_per_s / 30.0,
                    "algorithmic_tflop_per_step": gflop_per_sample / 1e3 * world * B,
                    "launch_mode": "hipGraph replay" if args.graph else "eager, 4 HIP streams",
-                   # time the host spends inside the step call (Python + launch calls; it runs ahead of the GPU while the
-                   # step is GPU-bound, and becomes the step time on a slow or shared host)
-                   "host_ms_per_step": host_s / args.steps * 1e3,
+                   # Python + launch calls of one step on an empty queue (profiles/host_enqueue.py): the step is GPU-bound while
+                   # this stays below ms_per_step
+                   "host_enqueue_ms": host_enqueue_ms,
                    "loss": float(out["total_loss"].reshape(-1)[0])},
     }
 

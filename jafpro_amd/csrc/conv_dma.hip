@@ -909,7 +909,10 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 // ---------------------------------------------------------------------------------------------
 // epilogue
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, bool LSTM>
+// DZ: the fused activation backward of jaf_packed_io.dz_mask.  A template parameter, not a run-time branch: with the dz
+// code in every instantiation the compiler kept its extra live ranges in ALL of them (conv_dma_kernel<4,4,false>: 160 -> 192
+// VGPRs, 3 -> 2 waves per SIMD, 9.5 -> 11.0 ms per step over its 94 launches).
+template <int MT, int NT, bool LSTM, bool DZ>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
                                             int n, int g, int mb, int q, int OHW, unsigned char* smem,
                                             const f32x4 (&cpre)[MT]) {
@@ -929,7 +932,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
             // dz mode with a second fp32 output (the ConvLSTM's d[x_t, h_{t-1}] launch): only the rows below `split` (dx) are the
             // producer's dz; the rows from `split` on (dh) leave through out2 as always
-            const int dC = (a.dz_mask && a.out2) ? a.split : d.Cout;
+            const int dC = (DZ && a.out2) ? a.split : d.Cout;
             float wsum[MT][4];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -947,7 +950,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 // dz mode, second of two consumers: the first one's gradient, 4 channels x NT pixels (one vector load per
                 // channel when the lane's pixels are consecutive)
                 float part[4][NT];
-                if (a.dz_mask && a.acc_out) {
+                if (DZ && a.acc_out) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -973,7 +976,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 for (int nt = 0; nt < NT; ++nt) {
                     if (opix[nt] < 0) continue;
                     float v[4];
-                    if (a.dz_mask) {
+                    if (DZ) {
                         // producer's dz: (this data gradient [+ the first consumer's]) * act'(x), x from the packed image the
                         // consumer layer read (4 consecutive channels = 8 bytes of a 16-byte item)
                         const long ngm = ((long)n) * d.G + g;
@@ -1008,7 +1011,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                             if (co0 + j < dC) hp[j] = (unsigned short)(ww[j >> 1] >> ((j & 1) * 16));
                     }
                 }
-                if (a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
+                if (DZ && a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = bsum[j];
@@ -1017,7 +1020,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     }
                 }
             }
-            if (a.dz_mask && a.dz_dbias) {
+            if (DZ && a.dz_dbias) {
                 // workgroup sum of the four waves in LDS (the patch buffer is free once every wave has left the matrix-core
                 // loop), then ONE atomic per channel and workgroup, spread over JAF_DZ_BIAS_SLOTS copies of the vector
                 // (same-address fp32 atomics serialise: one per wave and channel made these launches 3x slower)
@@ -1038,12 +1041,12 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 }
             }
         }
-        if (a.skip_f32 || (a.dz_mask && !a.out2)) return;
+        if (a.skip_f32 || (DZ && !a.out2)) return;
 #define CD_EPILOGUE(ACT_, ST_)                                                                        \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
-                if (co < d.Cout && !(a.dz_mask && co < a.split)) {      /* (dz rows went to `dst`) */  \
+                if (co < d.Cout && !(DZ && co < a.split)) {      /* (dz rows went to `dst`) */  \
                     const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
                     const bool second = a.out2 && co >= a.split;                                      \
                     float* op = second ? a.out2 + (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW \
@@ -1189,7 +1192,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 // ---------------------------------------------------------------------------------------------
 // the convolution kernel
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, bool LSTM>
+template <int MT, int NT, bool LSTM, bool DZ = false>
 __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
@@ -1377,7 +1380,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     }
 
     // ---- epilogue ----
-    cd_epilogue<MT, NT, LSTM>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
+    cd_epilogue<MT, NT, LSTM, DZ>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1557,15 +1560,27 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
 
 template <int MT, int NT, bool LSTM>
 static int cd_launch_one(const ConvDArgs& a, hipStream_t s) {
-    auto k = conv_dma_kernel<MT, NT, LSTM>;
-    static int optin[JAF_MAX_DEVICES];
     const int lds = a.p.lds_bytes;
+    const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
+    if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
+    if constexpr (!LSTM) {
+        if (a.dz_mask) {          // the fused activation backward has its own instantiation (see cd_epilogue)
+            auto kz = conv_dma_kernel<MT, NT, false, true>;
+            static int optin_z[JAF_MAX_DEVICES];
+            if (lds > 48 * 1024) {
+                const int e = jaf_lds_optin((const void*)kz, optin_z);
+                if (e) return e;
+            }
+            hipLaunchKernelGGL(kz, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+            return jaf_launch_status();
+        }
+    }
+    auto k = conv_dma_kernel<MT, NT, LSTM, false>;
+    static int optin[JAF_MAX_DEVICES];
     if (lds > 48 * 1024) {
         const int e = jaf_lds_optin((const void*)k, optin);
         if (e) return e;
     }
-    const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
-    if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }

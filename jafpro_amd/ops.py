@@ -681,7 +681,8 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if sums is not None:
             ln_stats.filled = True
         if ev is not None:
-            _PROF.end("conv_dma_kernel<%d, %d, false>" % (pl.MT, pl.NT), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
+            _PROF.end("conv_dma_kernel<%d, %d, false, %s>" % (pl.MT, pl.NT, "true" if dz_fuse is not None else "false"),
+                      2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
     if accumulate or out2 is not None:
         raise RuntimeError("conv: accumulate / out2 are features of the packed bf16 path")
@@ -749,6 +750,7 @@ def _slot_of(t) -> Optional["GradSlot"]:
 
 
 _FUSED_DZ = os.environ.get("JAF_NO_FUSED_DZ") is None
+_FUSED_DZ_MIN_G = int(os.environ.get("JAF_FUSED_DZ_MIN_G", "1"))      # experiment hook: hand dz over only in layers with >= this many groups
 
 
 def mark_single_consumer(t: torch.Tensor) -> torch.Tensor:
@@ -791,6 +793,8 @@ def _fusable_producer(t: torch.Tensor, spec):
     if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or getattr(fn, "mode", None) != (PREC_BF16, True):
         return None
     if pm.G * pm.Cout != t.shape[1] or spec[0] != pm.Cout:          # the whole output, group for group
+        return None
+    if pm.G < _FUSED_DZ_MIN_G:
         return None
     if fn.needs_input_grad[0] and fn.xp is None:                      # its weight gradient needs an fp32 dz
         return None
@@ -1170,7 +1174,7 @@ class _ConvLSTMFn(Function):
                                                         ctypes.byref(io) if io is not None else None),
                       "jaf_convlstm_cell_fwd_packed_io")
                 if ev is not None:
-                    _PROF.end("conv_dma_kernel<%d, %d, true>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                    _PROF.end("conv_dma_kernel<%d, %d, true, false>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
                                           None if first else _p(hprev), _p(wpk), _p(bias),
