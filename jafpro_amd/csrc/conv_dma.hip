@@ -912,12 +912,48 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 // DZ: the fused activation backward of jaf_packed_io.dz_mask.  A template parameter, not a run-time branch: with the dz
 // code in every instantiation the compiler kept its extra live ranges in ALL of them (conv_dma_kernel<4,4,false>: 160 -> 192
 // VGPRs, 3 -> 2 waves per SIMD, 9.5 -> 11.0 ms per step over its 94 launches).
-template <int MT, int NT, bool LSTM, bool DZ>
+template <int MT, int NT, bool LSTM, bool DZ, bool PLAIN>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
                                             int n, int g, int mb, int q, int OHW, unsigned char* smem,
                                             const f32x4 (&cpre)[MT]) {
     const jaf_conv_desc& d = a.d;
     constexpr int MR = 16 * MT;
+    if constexpr (PLAIN) {
+        // the launch writes ONE fp32 tensor and nothing else (no packed image, statistics, accumulation or second output):
+        // its own instantiation, so that the registers of those features are not carried through the matrix-core loop
+        typedef float pvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
+        const bool pv = a.vec && (NT > 1);
+#define CD_EPILOGUE_PLAIN(ACT_)                                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+                const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
+                if (co < d.Cout) {                                                                    \
+                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
+                    float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;  \
+                    if (pv) {                                                                         \
+                        if (opix[0] >= 0) {                                                           \
+                            pvec o;                                                                   \
+                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
+                                o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
+                            *(pvec*)(op + opix[0]) = o;                                               \
+                        }                                                                             \
+                    } else {                                                                          \
+                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
+                            if (opix[nt] >= 0) op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope); \
+                    }                                                                                 \
+                }                                                                                     \
+            }                                                                                         \
+        }
+        switch (d.act) {
+            case JAF_ACT_LRELU: CD_EPILOGUE_PLAIN(JAF_ACT_LRELU) break;
+            case JAF_ACT_RELU: CD_EPILOGUE_PLAIN(JAF_ACT_RELU) break;
+            case JAF_ACT_SIGMOID: CD_EPILOGUE_PLAIN(JAF_ACT_SIGMOID) break;
+            case JAF_ACT_TANH: CD_EPILOGUE_PLAIN(JAF_ACT_TANH) break;
+            default: CD_EPILOGUE_PLAIN(JAF_ACT_NONE) break;
+        }
+#undef CD_EPILOGUE_PLAIN
+        return;
+    }
     // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel).
     // With the pixel interleave a lane's NT tiles are NT consecutive pixels: one vector access. ----
     typedef float fvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
@@ -1192,8 +1228,14 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 // ---------------------------------------------------------------------------------------------
 // the convolution kernel
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, bool LSTM, bool DZ = false>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
+// Minimum resident workgroups per CU the register allocator must leave room for (256 threads = one wave per SIMD each, so
+// k workgroups = k waves per SIMD = at most 512 / k registers per lane).  Without it the allocator spreads: <4,4> plain took
+// 148 registers (3 waves per SIMD) where 110 do.
+#ifndef CD_MIN_WG
+#define CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN) (((NT) == 4 && (MT) >= 3 && !((LSTM) && (MT) == 4)) ? 4 : 1)
+#endif
+template <int MT, int NT, bool LSTM, bool DZ = false, bool PLAIN = false>
+__global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_dma_kernel(const ConvDArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
     const jaf_conv_plan& P = a.p;
@@ -1380,7 +1422,7 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvDArgs a) {
     }
 
     // ---- epilogue ----
-    cd_epilogue<MT, NT, LSTM, DZ>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
+    cd_epilogue<MT, NT, LSTM, DZ, PLAIN>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1572,6 +1614,19 @@ static int cd_launch_one(const ConvDArgs& a, hipStream_t s) {
                 if (e) return e;
             }
             hipLaunchKernelGGL(kz, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+            return jaf_launch_status();
+        }
+    }
+    if constexpr (!LSTM) {
+        static const int no_plain = getenv("JAF_NO_PLAIN_CONV") ? 1 : 0;
+        if (!no_plain && !a.dst && !a.stats && !a.acc_out && !a.out2 && !a.skip_f32) {
+            auto kp = conv_dma_kernel<MT, NT, false, false, true>;
+            static int optin_p[JAF_MAX_DEVICES];
+            if (lds > 48 * 1024) {
+                const int e = jaf_lds_optin((const void*)kp, optin_p);
+                if (e) return e;
+            }
+            hipLaunchKernelGGL(kp, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
             return jaf_launch_status();
         }
     }

@@ -681,7 +681,11 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if sums is not None:
             ln_stats.filled = True
         if ev is not None:
-            _PROF.end("conv_dma_kernel<%d, %d, false, %s>" % (pl.MT, pl.NT, "true" if dz_fuse is not None else "false"),
+            # named as rocprofv3 names the instantiation jaf_conv2d_fwd_packed_io picks: <MT, NT, LSTM, DZ, PLAIN>
+            plain = (dz_fuse is None and dst is None and sums is None and not accumulate and out2 is None and not skip_f32
+                     and not _NO_PLAIN_CONV)
+            _PROF.end("conv_dma_kernel<%d, %d, false, %s, %s>" % (pl.MT, pl.NT, "true" if dz_fuse is not None else "false",
+                                                                  "true" if plain else "false"),
                       2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
     if accumulate or out2 is not None:
@@ -749,6 +753,7 @@ def _slot_of(t) -> Optional["GradSlot"]:
     return getattr(t, "_jaf_gradslot", None)
 
 
+_NO_PLAIN_CONV = os.environ.get("JAF_NO_PLAIN_CONV") is not None
 _FUSED_DZ = os.environ.get("JAF_NO_FUSED_DZ") is None
 _FUSED_DZ_MIN_G = int(os.environ.get("JAF_FUSED_DZ_MIN_G", "1"))      # experiment hook: hand dz over only in layers with >= this many groups
 
@@ -1174,7 +1179,7 @@ class _ConvLSTMFn(Function):
                                                         ctypes.byref(io) if io is not None else None),
                       "jaf_convlstm_cell_fwd_packed_io")
                 if ev is not None:
-                    _PROF.end("conv_dma_kernel<%d, %d, true, false>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                    _PROF.end("conv_dma_kernel<%d, %d, true, false, false>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
                                           None if first else _p(hprev), _p(wpk), _p(bias),

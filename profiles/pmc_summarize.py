@@ -53,7 +53,7 @@ def main():
         fh.write("%-56s %8s %16s %16s %18s\n" % ("kernel", "launches", "FETCH_KiB/launch", "WRITE_KiB/launch", "est_HBM_MB/launch"))
         for k, n, f, w, mb, _ in rows:
             fh.write("%-56s %8d %16.1f %16.1f %18.2f\n" % (k[:56], n, f, w, mb))
-    dom = sys.argv[2] if len(sys.argv) > 2 else "conv_dma_kernel<4, 4, false, false>"
+    dom = sys.argv[2] if len(sys.argv) > 2 else "conv_dma_kernel<4, 4, false, false, false>"
     for k, n, f, w, mb, _ in rows:
         if k == dom:
             json.dump({"kernel": dom, "launches": n, "fetch_kib_per_launch": f, "write_kib_per_launch": w,
