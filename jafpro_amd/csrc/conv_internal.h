@@ -2,6 +2,7 @@
 // implementation in conv_bf16.hip / wgrad_bf16.hip.
 #pragma once
 #include "jaf_common.h"
+#include <stdlib.h>
 
 // Upper bound of the pixel splits of every weight-gradient kernel: all workgroups of one (co, ci) block add their
 // partial sums to the same dW addresses with fp32 atomics, which serialise (~0.25 us per workgroup and address
@@ -15,6 +16,10 @@
 static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, double t_item = 2.5e-6, double slots = 768.0,
                                     long max_split = JAF_WGRAD_MAX_SPLIT) {
     const double atomics_per_s = 3e11;
+    // experiment hook: workgroup slots a weight-gradient launch is sized for (768 = the whole chip at 3 per CU; the kernels run
+    // beside the data-gradient chain on their own stream)
+    static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
+    if (slots_env > 0.0 && slots == 768.0) slots = slots_env;
     long best = 1;
     double best_t = 1e30;
     const long hi = items < max_split ? items : max_split;
