@@ -31,6 +31,25 @@ static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, 
     return best;
 }
 
+// The same trade with the launch's TRUE residency: `slots` = workgroups the chip holds at once (occupancy x CUs, asked of
+// the runtime for the very kernel and LDS size), and whole rounds -- 528 workgroups on 512 slots take two rounds, not 1.03:
+// measured on the 24 -> 48 @ 200 x 200 ConvLSTM layer (2 workgroups per CU by registers), 22 splits (528 workgroups, what the
+// continuous model picks for 512 slots) 0.59 ms, 32 splits (768 = 1.5 rounds) 0.46 ms, 21 splits (504, one round) 0.36 ms.
+static inline long jaf_wgrad_nsplit_rounds(long items, long outblocks, long dw_floats, double slots, double t_item = 2.5e-6,
+                                           long max_split = JAF_WGRAD_MAX_SPLIT) {
+    const double atomics_per_s = 3e11;
+    long best = 1;
+    double best_t = 1e30;
+    const long hi = items < max_split ? items : max_split;
+    for (long ns = 1; ns <= hi; ++ns) {
+        const long blocks = outblocks * ns;
+        const long rounds = (long)(((double)blocks + slots - 1.0) / slots);
+        const double t = (double)((items + ns - 1) / ns) * t_item * (double)(rounds < 1 ? 1 : rounds) + (double)ns * (double)dw_floats / atomics_per_s;
+        if (t < best_t * 0.999) { best_t = t; best = ns; }
+    }
+    return best;
+}
+
 int jafb_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
               int32_t w_rows_tot, void* packed);

@@ -67,6 +67,29 @@ __device__ __forceinline__ float jaf_act(float v, int act, float slope) {
     }
 }
 
+// 16-byte-per-lane buffer load straight into LDS (lane l lands at lds_addr + 16 l), issued from inline assembly.
+// The builtin (__builtin_amdgcn_raw_ptr_buffer_load_lds) is tracked by the compiler as an LDS WRITE: with one dynamic LDS
+// array it cannot prove that a later ds_read touches another buffer, and it puts `s_waitcnt vmcnt(0)` in front of the first
+// LDS read that follows the DMA -- which serialises exactly the overlap a second tile buffer is for (seen in the ISA of the
+// double-buffered weight-gradient kernel: the wait sat between the DMA of tile i+1 and the first ds_read of tile i, and the
+// kernel ran no faster than the single-buffered one).  From assembly the compiler inserts nothing; the caller owns the
+// ordering: `s_waitcnt vmcnt(0)` + a workgroup barrier before anybody reads the buffer, a barrier after the last read
+// before it is filled again.  `rsrc`: buffer resource words (base, base_hi | stride, bytes, 0x00020000), wave-uniform.
+typedef unsigned int jaf_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ jaf_u32x4 jaf_make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long b = (unsigned long long)base;
+    jaf_u32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ void jaf_dma16_async(jaf_u32x4 rsrc, unsigned lds_addr, int voffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(rsrc) : "memory");
+}
+
 __device__ __forceinline__ double jaf_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

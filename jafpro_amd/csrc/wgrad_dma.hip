@@ -40,6 +40,7 @@ struct WgDArgs {
     int xplane;            // bytes of one ci-tile plane: PH*PWp*32
     int nx;                // DMA instructions per ci-tile plane
     int off_dz;
+    int bufsz;             // DB: bytes of one (patch, dz) tile buffer; the second buffer follows the first
     int ngin8, ngout8;
     int xng8;              // planes per (image, group) of the packed input image (>= ngin8)
     float inv_pwp;
@@ -48,7 +49,13 @@ struct WgDArgs {
 // PAIR (Cin <= 8, i.e. one packed item per position): the 16 columns of an MFMA are TWO taps x 8 channels instead of one
 // tap x 16 channels of which 8 are padding -- lanes p = 2, 3 of the transposed read point at the next tap's position --
 // so a 5x5 layer issues 13 MFMAs per k-step instead of 25 and keeps 13 accumulators.
-template <int MTW, int KS, bool PAIR>
+//
+// DB (tiles of at most 40 KB, i.e. the 24-part networks and the other narrow layers, which are bound by HBM and not by the
+// matrix cores): two tile buffers.  The DMA of tile i+1 is issued right after the barrier that publishes tile i and runs
+// under tile i's matrix-core pass, so a workgroup keeps two tiles' worth of bytes in flight instead of alternating between
+// "waiting for a tile" and "multiplying it"; one barrier per tile instead of two.  The wide layers (46 KB tiles) stay
+// single-buffered: a second buffer would halve their residency (2 -> 1 workgroups per CU), which measured slower.
+template <int MTW, int KS, bool PAIR, bool DB>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
     constexpr int NTAP = KS * KS;
     constexpr int NACC = PAIR ? (NTAP + 1) / 2 : NTAP;
@@ -67,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
     unsigned char* s_x = smem;
     unsigned char* s_dz = smem + a.off_dz;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address of smem
 
     int L;
     {
@@ -149,7 +157,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     const int xbytes = a.xng8 * HW * 16;
     const int zbytes = a.ngout8 * OHW * 16;
 
-    for (int item = split; item < items; item += a.nsplit) {
+    // DMA of one tile (image, pixel tile) into the buffer at byte offset `boff`
+    auto issue = [&](int item, int boff) {
         const int n = item / tiles;
         const int tile = item - n * tiles;
         const int ty = tile / a.tiles_x;
@@ -157,48 +166,67 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         const int oy0 = ty * WD_TH, ox0 = tx * WD_TW;
         const int iy0 = oy0 * s - d.pad_t;
         const int ix0 = ox0 * s - d.pad_l;
-
-        __syncthreads();   // previous tile consumed
-
-        {
-            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.xp + ((long)n * d.G + g) * (long)xbytes), 0, xbytes, 0x00020000);
-            const int tbase = (iy0 * d.W + ix0) * 16;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.xp + ((long)n * d.G + g) * (long)xbytes), 0, xbytes, 0x00020000);
+        const jaf_u32x4 rxa = jaf_make_rsrc(a.xp + ((long)n * d.G + g) * (long)xbytes, (unsigned)xbytes);
+        const int tbase = (iy0 * d.W + ix0) * 16;
 #pragma unroll
-            for (int j = 0; j < WD_XI; ++j) {
-                const int i = wave + 4 * j;
-                if (i < nxi) {
-                    const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
-                    const int iy = iy0 + r, ix = ix0 + c;
-                    const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
-                    const int tci = i / a.nx;
+        for (int j = 0; j < WD_XI; ++j) {
+            const int i = wave + 4 * j;
+            if (i < nxi) {
+                const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
+                const int iy = iy0 + r, ix = ix0 + c;
+                const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
+                const int tci = i / a.nx;
+                if (DB)      // (from assembly: see jaf_dma16_async)
+                    jaf_dma16_async(rxa, lds0 + boff + tci * a.xplane + (i - tci * a.nx) * 1024, ok ? x_goff[j] + tbase : WD_OOB);
+                else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rx, (__attribute__((address_space(3))) void*)(s_x + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
+                        rx, (__attribute__((address_space(3))) void*)(s_x + boff + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
                         ok ? x_goff[j] + tbase : WD_OOB, 0, 0, 0);
-                }
-            }
-            const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(a.dzp + ((long)n * d.G + g) * (long)zbytes), 0, zbytes, 0x00020000);
-            const int y = z_yx >> 16, x = z_yx & 0xffff;
-            const bool okp = (oy0 + y < d.OH) && (ox0 + x < d.OW);
-            const int zb = z_goff + (oy0 * d.OW + ox0) * 16;
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) {
-                const int grp8 = (co0 >> 3) + 2 * mt + z_half;
-                const bool ok = okp && (grp8 < a.ngout8);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rz, (__attribute__((address_space(3))) void*)(s_dz + mt * 4096 + wave * 1024), 16,
-                    ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB, 0, 0, 0);
             }
         }
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(a.dzp + ((long)n * d.G + g) * (long)zbytes), 0, zbytes, 0x00020000);
+        const jaf_u32x4 rza = jaf_make_rsrc(a.dzp + ((long)n * d.G + g) * (long)zbytes, (unsigned)zbytes);
+        const int y = z_yx >> 16, x = z_yx & 0xffff;
+        const bool okp = (oy0 + y < d.OH) && (ox0 + x < d.OW);
+        const int zb = z_goff + (oy0 * d.OW + ox0) * 16;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int grp8 = (co0 >> 3) + 2 * mt + z_half;
+            const bool ok = okp && (grp8 < a.ngout8);
+            if (DB)
+                jaf_dma16_async(rza, lds0 + a.off_dz + boff + mt * 4096 + wave * 1024, ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rz, (__attribute__((address_space(3))) void*)(s_dz + boff + mt * 4096 + wave * 1024), 16,
+                    ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB, 0, 0, 0);
+        }
+    };
+
+    int cur = 0;                 // DB: byte offset of the buffer that holds the tile being multiplied
+    if (DB && split < items) issue(split, 0);
+    for (int item = split; item < items; item += a.nsplit) {
+        if (DB) {
+            __builtin_amdgcn_s_waitcnt(0);      // this wave's share of tile `item` has landed
+            __syncthreads();                    // ... everybody's has, and everybody is done with the other buffer
+            if (item + a.nsplit < items) issue(item + a.nsplit, cur ^ a.bufsz);
+        } else {
+            __syncthreads();   // previous tile consumed
+            issue(item, 0);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+        const unsigned char* c_x = s_x + cur;
+        const unsigned char* c_dz = s_dz + cur;
+        if (DB) cur ^= a.bufsz;
 
         for (int ks = wk; ks < 4; ks += WK) {
             bf16x8 af[MTW];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
-                const unsigned char* ap = s_dz + mt * 4096 + ks * 1024;
+                const unsigned char* ap = c_dz + mt * 4096 + ks * 1024;
                 const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[0]));
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[1]));
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -215,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                     for (int h = 0; h < 2; ++h) {
                         const int c0h = (8 * (q & 1) + 4 * h + qp) * s + kx;
                         const int ad = ((((q >> 1) + 2 * ks) * s + ky) * PWp + c0h) * 32 + (pp & 1) * 8;
-                        bb[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + (ad ^ ((c0h & 8) << 4))));
+                        bb[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + (ad ^ ((c0h & 8) << 4))));
                     }
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bb[0], bb[1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
@@ -230,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 for (int kx = 0; kx < KS; ++kx) {
                     const int a0 = (bbase[0][kx] + rowoff) ^ bswz[0][kx];
                     const int a1 = (bbase[1][kx] + rowoff) ^ bswz[1][kx];
-                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a0));
-                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(s_x + a1));
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a0));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a1));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
@@ -301,6 +329,46 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
 static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 
+// Workgroups of `kernel` (256 threads, `lds` bytes) the device holds at once, asked of the runtime once per
+// (instantiation, LDS size, device): registers decide it for the 3 x 3 kernels (2 per CU at 16*3 and 16*4 rows, 3 at 16*2,
+// 4 at 16), LDS for the stride-2 and double-buffered ones.
+struct WgdOcc { int lds, slots; };
+static int wgd_slots(const void* kernel, int lds, WgdOcc (*cache)[4]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= JAF_MAX_DEVICES) return 512;
+    WgdOcc* c = cache[dev];
+    for (int i = 0; i < 4; ++i)
+        if (c[i].lds == lds && c[i].slots > 0) return c[i].slots;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, (size_t)lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int slots = per_cu * cus;
+    for (int i = 0; i < 4; ++i)
+        if (c[i].slots == 0) { c[i].lds = lds; c[i].slots = slots; break; }
+    return slots;
+}
+
+template <int MTW, int KS, bool PAIR, bool DB>
+static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
+    auto k = conv_wgrad_dma_kernel<MTW, KS, PAIR, DB>;
+    static int optin[JAF_MAX_DEVICES];
+    static WgdOcc occ[JAF_MAX_DEVICES][4];
+    if (lds > 48 * 1024) {
+        const int e = jaf_lds_optin((const void*)k, optin);
+        if (e) return e;
+    }
+    // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of atomic
+    // traffic per launch at 1536 workgroups) and contends for the same addresses: see jaf_wgrad_nsplit
+    static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
+    const double slots = slots_env > 0.0 ? slots_env : (double)wgd_slots((const void*)k, lds, occ);
+    a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
+                                     : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
+    const long nblk = outblocks * a.nsplit;
+    if (nblk > 0x7fffffffL) return JAF_EINVAL;
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+    return jaf_launch_status();
+}
+
 extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x,
                                        const void* packed_dz, float* dw, int accumulate) {
     return jaf_conv2d_wgrad_packed_ex(s_, d, packed_x, 0, packed_dz, dw, accumulate);
@@ -357,43 +425,35 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     a.inv_pwp = 1.0f / (float)a.PWp;
     JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
     int lds = a.off_dz + MTW * 4096;
+    // two tile buffers when two workgroups per CU still fit (see the kernel's header)
+    static const int no_db = getenv("JAF_WGRAD_NO_DB") ? 1 : 0;
+    const bool db = !no_db && lds <= 40 * 1024;
+    a.bufsz = db ? lds : 0;
+    if (db) lds *= 2;
     const int lds_ep = 4 * 16 * WD_EP * 4;
     if (KS == 3 && lds < lds_ep) lds = lds_ep;
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of atomic
-    // traffic per launch at 1536 workgroups) and contends for the same addresses: see jaf_wgrad_nsplit
-    const long nsplit = jaf_wgrad_nsplit(items, outblocks, (long)d->G * d->Cout * d->Cin * KS * KS);
-    a.nsplit = (int)nsplit;
-    const long nblk = outblocks * nsplit;
-    JAF_REQUIRE(nblk <= 0x7fffffffL);
+    const long dw_floats = (long)d->G * d->Cout * d->Cin * KS * KS;
 #define JAF_WGD(MT_, KS_) JAF_WGDP(MT_, KS_, false)
-#define JAF_WGDP(MT_, KS_, PAIR_)                                                                      \
-    do {                                                                                               \
-        auto k = conv_wgrad_dma_kernel<MT_, KS_, PAIR_>;                                               \
-        static int optin[JAF_MAX_DEVICES];                                                             \
-        if (lds > 48 * 1024) {                                                                         \
-            const int e = jaf_lds_optin((const void*)k, optin);                                        \
-            if (e) return e;                                                                           \
-        }                                                                                              \
-        hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
-    } while (0)
+#define JAF_WGDP(MT_, KS_, PAIR_) \
+    return db ? wgd_launch<MT_, KS_, PAIR_, true>(a, lds, items, outblocks, dw_floats, s) \
+              : wgd_launch<MT_, KS_, PAIR_, false>(a, lds, items, outblocks, dw_floats, s)
     if (KS == 5 && d->Cin <= 8) JAF_WGDP(1, 5, true);
     else if (KS == 5) JAF_WGD(1, 5);
     else if (KS == 1) switch (MTW) {
-        case 1: JAF_WGD(1, 1); break;
-        case 2: JAF_WGD(2, 1); break;
-        case 3: JAF_WGD(3, 1); break;
-        default: JAF_WGD(4, 1); break;
+        case 1: JAF_WGD(1, 1);
+        case 2: JAF_WGD(2, 1);
+        case 3: JAF_WGD(3, 1);
+        default: JAF_WGD(4, 1);
     }
     else switch (MTW) {
-        case 1: JAF_WGD(1, 3); break;
-        case 2: JAF_WGD(2, 3); break;
-        case 3: JAF_WGD(3, 3); break;
-        default: JAF_WGD(4, 3); break;
+        case 1: JAF_WGD(1, 3);
+        case 2: JAF_WGD(2, 3);
+        case 3: JAF_WGD(3, 3);
+        default: JAF_WGD(4, 3);
     }
 #undef JAF_WGD
 #undef JAF_WGDP
-    return jaf_launch_status();
 }

@@ -120,7 +120,10 @@ class _arith:
         return False
 
 
-def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, OH: int = 1 << 20, OW: int = 1 << 20) -> str:
+_WGRAD_NO_DB = os.environ.get("JAF_WGRAD_NO_DB") is not None
+
+
+def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, OH: int = 1 << 20, OW: int = 1 << 20, stride: int = 1) -> str:
     """Template instantiation jaf_conv2d_wgrad_packed launches (same rule as csrc/wgrad_dma.hip), so that the
     bench's per-kernel rows carry the names rocprofv3 reports."""
     mt_best, pad_best = 1, None
@@ -138,7 +141,13 @@ def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, O
                 wc >>= 1
             else:
                 break
-    return "conv_wgrad_dma_kernel<%d, %d, %s>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false")
+    else:
+        wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
+    # two tile buffers when a (patch, dz) tile is at most 40 KB
+    ph, pw = 7 * stride + KS, 15 * stride + KS
+    xplane = -(-(ph * (-(-pw // 8) * 8) * 32) // 1024) * 1024
+    db = (wc * xplane + mt_best * 4096 <= 40 * 1024) and not _WGRAD_NO_DB
+    return "conv_wgrad_dma_kernel<%d, %d, %s, %s>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false", "true" if db else "false")
 
 
 def _wgrad_name(KH, KW) -> str:
@@ -834,7 +843,7 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool, stream=None):
             dzp = pack_input([dz], dzd)
         check(L.jaf_conv2d_wgrad_packed_ex(sh, ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
                                            1 if inplace else 0), "jaf_conv2d_wgrad_packed_ex")
-        wname = _wgrad_dma_name(m.Cout, m.KH, m.Cin, m.G, m.N, m.OH, m.OW)
+        wname = _wgrad_dma_name(m.Cout, m.KH, m.Cin, m.G, m.N, m.OH, m.OW, m.stride)
     else:
         check(L.jaf_conv2d_wgrad(sh, ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
               "jaf_conv2d_wgrad")
