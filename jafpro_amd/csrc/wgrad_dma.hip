@@ -24,7 +24,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 
 #define WD_TW 16
 #define WD_TH 8
-#define WD_XI 8         // patch DMA instructions per wave per tile (upper bound)
+#define WD_XI 11        // patch DMA instructions per wave per tile (upper bound: a stride-2 3 x 3 patch of 32 channels = 44 KB)
 #define WD_EP 145
 #define WD_OOB 0x7ffffff0
 
@@ -397,7 +397,14 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
         long pad = (long)jaf_cdiv(d->Cout, 16 * mt) * 16 * mt;
         if (pad < bestPad) { bestPad = pad; MTW = mt; }
     }
+    a.PH = (WD_TH - 1) * d->stride + KS;
+    a.PW = (WD_TW - 1) * d->stride + KS;
+    a.PWp = rup_w(a.PW, 8);
+    a.xplane = rup_w(a.PH * a.PWp * 32, 1024);
+    a.nx = a.xplane / 1024;
     a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
+    // stride-2 patches are 22 KB per 16 channels: at most 32 channels per workgroup (more input-channel blocks instead)
+    while (a.WC > 1 && jaf_cdiv(a.WC * a.nx, 4) > WD_XI) a.WC >>= 1;
     {   // launches that cannot fill the chip: smaller output blocks = more, shorter workgroups (see jafb_wgrad)
         const long items0 = (long)d->N * jaf_cdiv(d->OW, WD_TW) * jaf_cdiv(d->OH, WD_TH);
         const long sp = items0 < JAF_WGRAD_MAX_SPLIT ? items0 : JAF_WGRAD_MAX_SPLIT;
@@ -412,12 +419,7 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);
     a.tiles_x = jaf_cdiv(d->OW, WD_TW);
     a.tiles_y = jaf_cdiv(d->OH, WD_TH);
-    a.PH = (WD_TH - 1) * d->stride + KS;
-    a.PW = (WD_TW - 1) * d->stride + KS;
-    a.PWp = rup_w(a.PW, 8);
-    a.xplane = rup_w(a.PH * a.PWp * 32, 1024);
-    a.nx = a.xplane / 1024;
-    if (jaf_cdiv(a.WC * a.nx, 4) > WD_XI) return JAF_EUNSUPPORTED;   // stride-2 patches of wide layers: caller falls back
+    if (jaf_cdiv(a.WC * a.nx, 4) > WD_XI) return JAF_EUNSUPPORTED;
     a.off_dz = a.WC * a.xplane;
     a.ngin8 = jaf_cdiv(d->Cin, 8);
     a.ngout8 = jaf_cdiv(d->Cout, 8);

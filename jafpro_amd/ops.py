@@ -131,8 +131,13 @@ def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, O
         pad = -(-Cout // (16 * mt)) * 16 * mt
         if pad_best is None or pad < pad_best:
             mt_best, pad_best = mt, pad
+    ph, pw = 7 * stride + KS, 15 * stride + KS
+    xplane = -(-(ph * (-(-pw // 8) * 8) * 32) // 1024) * 1024
+    nx = xplane // 1024
     if KS != 5:        # launches that cannot fill the chip use smaller output blocks
         wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
+        while wc > 1 and -(-(wc * nx) // 4) > 11:
+            wc >>= 1
         sp = min(N * -(-OW // 16) * -(-OH // 8), 96)
         while G * -(-Cout // (16 * mt_best)) * -(-Cin // (16 * wc)) * sp < 512:
             if mt_best > 1:
@@ -144,8 +149,6 @@ def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, O
     else:
         wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
     # two tile buffers when a (patch, dz) tile is at most 40 KB
-    ph, pw = 7 * stride + KS, 15 * stride + KS
-    xplane = -(-(ph * (-(-pw // 8) * 8) * 32) // 1024) * 1024
     db = (wc * xplane + mt_best * 4096 <= 40 * 1024) and not _WGRAD_NO_DB
     return "conv_wgrad_dma_kernel<%d, %d, %s, %s>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false", "true" if db else "false")
 
@@ -709,7 +712,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
 
 
 def _wgrad_packed_ok(m) -> bool:
-    return m.KH == m.KW and m.KH in (1, 3, 5) and (m.stride == 1 or m.Cin <= 16)
+    return m.KH == m.KW and m.KH in (1, 3, 5) and m.stride in (1, 2)
 
 
 def _grad_inplace(p: torch.Tensor) -> bool:

@@ -349,10 +349,10 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                     (out * proj).sum().backward()
                     # with the images on, the last data gradient of a ReLU / LeakyReLU convolution's output hands that layer
                     # its packed dz directly (jaf_packed_io.dz_mask): in the part encoders x1,3,5,7 (from the second of their
-                    # two consumers: the ConvLSTM's d x launches / enc_{i+1}) and x2 (one consumer; enc4/6/8 are wide
-                    # stride-2 layers whose weight gradient still needs an fp32 dz), in VGG the untapped conv -> conv edges;
+                    # two consumers: the ConvLSTM's d x launches / enc_{i+1}) and x2, x4, x6, x8 (one consumer: the stride-2
+                    # layer that follows), in VGG the untapped conv -> conv edges;
                     # the reference path packs every dz in a pass of its own
-                    want = {Accumulate_LSTM_no_loss: 5, UNet_inpainter: 5, VGG19_CRN: 7, CRN_smaller: 0}[cls] if images else 0
+                    want = {Accumulate_LSTM_no_loss: 8, UNet_inpainter: 8, VGG19_CRN: 7, CRN_smaller: 0}[cls] if images else 0
                     assert ops.FUSED_STATS["dz"] - handed == want, (cls.__name__, images, ops.FUSED_STATS["dz"] - handed)
                     if cls is Accumulate_LSTM_no_loss:
                         # skip features x1, x3, x5, x7 have two consumers (ConvLSTM, enc_{i+1}): with the images on, the
