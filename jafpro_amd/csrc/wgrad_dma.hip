@@ -429,7 +429,8 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     int lds = a.off_dz + MTW * 4096;
     // two tile buffers when two workgroups per CU still fit (see the kernel's header)
     static const int no_db = getenv("JAF_WGRAD_NO_DB") ? 1 : 0;
-    const bool db = !no_db && lds <= 40 * 1024;
+    static const int db_max = getenv("JAF_WGRAD_DB_MAX_KB") ? atoi(getenv("JAF_WGRAD_DB_MAX_KB")) : 40;      // experiment hook
+    const bool db = !no_db && lds <= db_max * 1024;
     a.bufsz = db ? lds : 0;
     if (db) lds *= 2;
     const int lds_ep = 4 * 16 * WD_EP * 4;
