@@ -298,6 +298,16 @@ int jaf_layernorm_lrelu_bwd(jaf_stream_t s, const float* dy, const float* x, con
                             float* dbeta, double* workspace /* 32*N doubles */, int32_t N,
                             int32_t C, int32_t HW, float slope, float eps);
 
+/* The same backward when x is the output of a convolution without activation whose only reader is this LayerNorm (the
+ * CRN's conv -> LayerNorm -> LeakyReLU blocks, src/crn_model.py:90-106): dx leaves as that convolution's packed bf16 dz image
+ * [n][ceil(C/8)][HW][8] (channels up to the next multiple of 8 zeroed) instead of an fp32 tensor, and its bias gradient
+ * (sum of dx over images and pixels; conv_dbias nullable, `accumulate_dbias`: += instead of =) comes out of the reduction
+ * pass.  scratch: 2*N*C floats. */
+int jaf_layernorm_lrelu_bwd_packed(jaf_stream_t s, const float* dy, const float* x, const float* stats,
+                                   const float* gamma, const float* beta, void* packed_dx, float* dgamma,
+                                   float* dbeta, double* workspace /* 32*N doubles */, float* scratch, float* conv_dbias,
+                                   int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps);
+
 /* BatchNorm2d in training mode (src/flow_net.py:13-51, src/networks.py:369-390; eps 1e-5,
  * momentum 0.1, biased var for normalisation, unbiased for running_var) + activation
  * (+ optional residual add: ResnetBlock, src/flow_net.py:139-141).

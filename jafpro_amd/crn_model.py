@@ -42,11 +42,12 @@ class LayerNorm(nn.Module):
         self.beta = nn.Parameter(torch.zeros(num_features))
         self.pre_stats = ops.LNStats()
 
-    def forward(self, x, slope: float = 1.0, pre=None, dst=None, keep_f32=True):
+    def forward(self, x, slope: float = 1.0, pre=None, dst=None, keep_f32=True, sole=False):
         """slope=1.0 is the bare LayerNorm; ConvBlock passes the LeakyReLU slope 0.01, the statistics
         its convolution's epilogue already accumulated (ops.LNStats) and, on the packed bf16 path, the packed image of
-        the convolution that consumes the result (ops.PackedDst)."""
-        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope, pre, dst, keep_f32)
+        the convolution that consumes the result (ops.PackedDst); sole: x is a convolution's output that nothing else reads
+        (its gradient may then go back to that convolution as a packed bf16 image)."""
+        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope, pre, dst, keep_f32, sole)
 
 
 class ConvBlock(nn.Module):
@@ -74,7 +75,7 @@ class ConvBlock(nn.Module):
                 img_out = ops.PackedImage(x.shape[0], 1, x.shape[1], x.shape[2], x.shape[3], x.device)
             # the LayerNorm between the block's two convolutions, and a block output whose only reader is the convolution
             # behind `out_image`, are consumed through their packed image alone
-            x = ln(x, 0.01, st, img_out.slot(0) if img_out is not None else None, keep_f32=img_out is None)
+            x = ln(x, 0.01, st, img_out.slot(0) if img_out is not None else None, keep_f32=img_out is None, sole=True)
             img_in = img_out
         return x
 

@@ -219,19 +219,19 @@ extern "C" int jaf_layernorm_lrelu_fwd_packed(jaf_stream_t s, const float* x, co
 template <int V>
 __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const float* stats, const float* gamma,
                                      const float* beta, float* dgamma, float* dbeta, double* ws, int C, int HW,
-                                     float slope) {
+                                     float slope, float* cn /* nullable: [N][C][2] = (gamma_c * sum dz, sum xhat) */) {
     const int c = blockIdx.x;
     const int n = blockIdx.y;
     const long base = ((long)n * C + c) * HW;
     const float mean = stats[2 * n], r = stats[2 * n + 1];
     const float g = gamma[c], b = beta[c];
-    double sa = 0.0, sb = 0.0;
+    double sa = 0.0, sb = 0.0, sx = 0.0;
     if (V == 4) {
         const f32x4* x4 = (const f32x4*)(x + base);
         const f32x4* d4 = (const f32x4*)(dy + base);
         for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
             const f32x4 xv = x4[i], dv = d4[i];
-            float pa = 0.f, pb = 0.f;
+            float pa = 0.f, pb = 0.f, px = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xh = (xv[k] - mean) * r;
@@ -239,9 +239,11 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
                 const float dz = dv[k] * (z > 0.f ? 1.f : slope);
                 pa += dz;
                 pb += dz * xh;
+                px += xh;
             }
             sa += (double)pa;
             sb += (double)pb;
+            sx += (double)px;
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
@@ -250,16 +252,22 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
             const float dz = dy[base + i] * (z > 0.f ? 1.f : slope);
             sa += (double)dz;
             sb += (double)dz * (double)xh;
+            sx += (double)xh;
         }
     }
-    __shared__ double ra[4], rb[4];
+    __shared__ double ra[4], rb[4], rx[4];
     sa = jaf_wave_sum(sa);
     sb = jaf_wave_sum(sb);
-    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rb[threadIdx.x >> 6] = sb; }
+    if (cn) sx = jaf_wave_sum(sx);
+    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rb[threadIdx.x >> 6] = sb; rx[threadIdx.x >> 6] = sx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const double a = ra[0] + ra[1] + ra[2] + ra[3];
         const double bb = rb[0] + rb[1] + rb[2] + rb[3];
+        if (cn) {
+            cn[((long)n * C + c) * 2] = (float)((double)g * a);
+            cn[((long)n * C + c) * 2 + 1] = (float)(rx[0] + rx[1] + rx[2] + rx[3]);
+        }
         atomicAdd(&dbeta[c], (float)a);
         atomicAdd(&dgamma[c], (float)bb);
         double* w = ws + ((long)n * LN_BWD_SLOTS + (c & (LN_BWD_SLOTS - 1))) * 2;
@@ -326,17 +334,125 @@ extern "C" int jaf_layernorm_lrelu_bwd(jaf_stream_t s_, const float* dy, const f
     if (e != hipSuccess) return (int)e;
     if ((HW % 4 == 0) && al16(dy, x, dx)) {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel<4>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                           workspace, C, HW, slope);
+                           workspace, C, HW, slope, (float*)nullptr);
         hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
         hipLaunchKernelGGL(ln_bwd_apply_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
                            beta, workspace, dx, C, HW, slope, eps);
     } else {
         hipLaunchKernelGGL(ln_bwd_reduce_kernel<1>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                           workspace, C, HW, slope);
+                           workspace, C, HW, slope, (float*)nullptr);
         hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
         hipLaunchKernelGGL(ln_bwd_apply_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
                            beta, workspace, dx, C, HW, slope, eps);
     }
+    return jaf_launch_status();
+}
+
+// The same backward with the result handed to the PRODUCING convolution (act NONE, groups 1: the CRN's conv -> LayerNorm
+// -> LeakyReLU blocks, src/crn_model.py:90-106) in the form its data / weight gradient kernels read: dx as a packed bf16
+// image [n][ceil(C/8)][HW][8] -- a lane owns 8 channels x V pixels, as in ln_lrelu_fwd_packed_kernel -- instead of an fp32
+// tensor that jaf_conv2d_pack_dz would read back (4 + 4 + 2 bytes per element become 2).  grid (pixel blocks, ceil(C/8), N).
+template <int V>
+__global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, const double* __restrict__ ws,
+                                                                  unsigned char* __restrict__ dst, int C, int HW, float slope, float eps) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int cg = blockIdx.y, n = blockIdx.z;
+    const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (pix >= HW) return;
+    const double M = (double)C * (double)HW;
+    const float mean = stats[2 * n], r = stats[2 * n + 1];
+    const float sigma = 1.0f / r - eps;
+    const double* w = ws + (long)n * LN_BWD_SLOTS * 2;
+    const float m1 = (float)(w[0] / M);
+    const float kk = (sigma > 0.f) ? (float)(w[1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
+    float o[8][V];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[j][k] = 0.f;
+        if (c < C) {
+            const long e = ((long)n * C + c) * HW + pix;
+            const float g = gamma[c], b = beta[c];
+            if (V == 4) {
+                const f32x4 xv = *(const f32x4*)(x + e), dv = *(const f32x4*)(dy + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xh = (xv[k] - mean) * r;
+                    const float z = xh * g + b;
+                    const float dxh = dv[k] * (z > 0.f ? 1.f : slope) * g;
+                    o[j][k] = r * (dxh - m1 - xh * kk);
+                }
+            } else {
+                const float xh = (x[e] - mean) * r;
+                const float z = xh * g + b;
+                const float dxh = dy[e] * (z > 0.f ? 1.f : slope) * g;
+                o[j][0] = r * (dxh - m1 - xh * kk);
+            }
+        }
+    }
+    unsigned char* op = dst + (((long)n * gridDim.y + cg) * (long)HW + pix) * 16;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        u32x4 wv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const f32x2 v2 = {o[2 * u][k], o[2 * u + 1][k]};
+            wv[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2));
+        }
+        *(u32x4*)(op + k * 16) = wv;
+    }
+}
+
+// The producing convolution's bias gradient, sum over images and pixels of dx, from the per-(image, channel) sums the
+// reduce pass already took: sum_p dx[n][c] = r_n (gamma_c sum dz - HW m1_n - kk_n sum xhat).  One thread per channel.
+__global__ void ln_bwd_conv_bias_kernel(const float* cn, const float* stats, const double* ws, float* dbias, int N, int C, int HW,
+                                        float eps, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double M = (double)C * (double)HW;
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float r = stats[2 * n + 1];
+        const float sigma = 1.0f / r - eps;
+        const double* w = ws + (long)n * LN_BWD_SLOTS * 2;
+        const float m1 = (float)(w[0] / M);
+        const float kk = (sigma > 0.f) ? (float)(w[1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
+        acc += (double)r * ((double)cn[((long)n * C + c) * 2] - (double)HW * (double)m1 - (double)kk * (double)cn[((long)n * C + c) * 2 + 1]);
+    }
+    dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)acc;
+}
+
+extern "C" int jaf_layernorm_lrelu_bwd_packed(jaf_stream_t s_, const float* dy, const float* x, const float* stats,
+                                              const float* gamma, const float* beta, void* packed_dx, float* dgamma,
+                                              float* dbeta, double* workspace, float* scratch, float* conv_dbias,
+                                              int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps) {
+    JAF_REQUIRE(dy && x && stats && gamma && beta && packed_dx && dgamma && dbeta && workspace && scratch);
+    JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535 && C <= 65535);
+    hipStream_t s = (hipStream_t)s_;
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * LN_BWD_SLOTS * N, s);
+    if (e != hipSuccess) return (int)e;
+    const bool v4 = (HW % 4 == 0) && al16(dy, x);
+    if (v4)
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel<4>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
+                           workspace, C, HW, slope, scratch);
+    else
+        hipLaunchKernelGGL(ln_bwd_reduce_kernel<1>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
+                           workspace, C, HW, slope, scratch);
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
+    if (v4)
+        hipLaunchKernelGGL(ln_bwd_apply_packed_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), jaf_cdiv(C, 8), N), dim3(256), 0, s, dy, x, stats,
+                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps);
+    else
+        hipLaunchKernelGGL(ln_bwd_apply_packed_kernel<1>, dim3(jaf_cdiv(HW, 256), jaf_cdiv(C, 8), N), dim3(256), 0, s, dy, x, stats,
+                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps);
+    if (conv_dbias)
+        hipLaunchKernelGGL(ln_bwd_conv_bias_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, scratch, stats, workspace, conv_dbias, N, C,
+                           HW, eps, accumulate_dbias ? 1 : 0);
     return jaf_launch_status();
 }
 

@@ -757,7 +757,7 @@ def share_gradslot(src: torch.Tensor, view: torch.Tensor) -> torch.Tensor:
     return view
 
 
-FUSED_STATS = {"dz": 0}                      # data-gradient launches that handed their producer a packed dz (tests)
+FUSED_STATS = {"dz": 0, "ln": 0}             # data-gradient launches / LayerNorm backwards that handed their producer a packed dz (tests)
 SLOT_STATS = {"first": 0, "added": 0}        # how often a slot received a first gradient / an in-place second one (tests)
 
 
@@ -1376,11 +1376,29 @@ def convlstm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: 
 # --------------------------------------------------------------------------------------------
 # normalisation
 # --------------------------------------------------------------------------------------------
+def _ln_producer(x: torch.Tensor):
+    """The _ConvFn node that made `x`, if a LayerNorm that is its only reader may hand it dz in packed bf16
+    (jaf_layernorm_lrelu_bwd_packed): a convolution without activation on the packed bf16 path, one group, whose weight
+    gradient (if any) runs on the packed kernel."""
+    fn = x.grad_fn
+    if not _FUSED_DZ or fn is None or type(fn).__name__ != "_ConvFnBackward":
+        return None
+    pm = getattr(fn, "meta", None)
+    if pm is None or pm.act != ACT_NONE or pm.G != 1 or pm.Cout != x.shape[1] or getattr(fn, "mode", None) != (PREC_BF16, True):
+        return None
+    if getattr(fn, "y_img", None) is not None or (fn.needs_input_grad[0] and fn.xp is None):
+        return None
+    return fn
+
+
 class _LayerNormLReLUFn(Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats], dst=None, keep_f32=True):
+    def forward(ctx, x, gamma, beta, eps: float, slope: float, pre: Optional[LNStats], dst=None, keep_f32=True, sole=False):
         N, C, H, W = x.shape
         L = lib()
+        # backward hand-over: x is a convolution's output and this LayerNorm its only reader -> dx goes back as that layer's
+        # packed dz (+ bias gradient), no fp32 dx, no jaf_conv2d_pack_dz pass
+        ctx.prod = _ln_producer(x) if (sole and ctx.needs_input_grad[0] and _USE_PACKED and _PRECISION == PREC_BF16) else None
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
         if pre is not None and pre.filled:       # sums came out of the producing convolution's epilogue
             check(L.jaf_layernorm_finalize(_s(), _p(pre.sums), N, pre.slots, C * H * W, eps, _p(stats)), "jaf_layernorm_finalize")
@@ -1411,24 +1429,44 @@ class _LayerNormLReLUFn(Function):
         x, gamma, beta, stats = ctx.saved_tensors
         N, C, H, W = x.shape
         dy = _c(dy)
-        dx = torch.empty_like(x)
         # the kernel accumulates (+=): parameters that already own a .grad buffer are updated in place
         gi, bi = _grad_inplace(gamma), _grad_inplace(beta)
         dgamma = gamma.grad if gi else torch.zeros_like(gamma)
         dbeta = beta.grad if bi else torch.zeros_like(beta)
         ws = torch.empty(32 * N, device=x.device, dtype=torch.float64)      # [N][16 slots][2], include/jafpro_hip.h
+        prod = getattr(ctx, "prod", None)
+        if prod is not None and _PRECISION == PREC_BF16 and _USE_PACKED:
+            ctx.prod = None
+            dzp = torch.empty(N * ((C + 7) // 8) * H * W * 16, device=x.device, dtype=torch.uint8)
+            scratch = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
+            pb = prod.bias_ref
+            db, dbt, acc = None, None, 0
+            if prod.has_bias and prod.needs_input_grad[1]:
+                if _grad_inplace(pb):
+                    dbt, acc = pb.grad, 1
+                else:
+                    dbt = db = torch.empty(C, device=x.device, dtype=torch.float32)
+            with _hbm("ln_bwd_apply_packed_kernel", x.numel() * 8.0 + dzp.numel()):
+                check(lib().jaf_layernorm_lrelu_bwd_packed(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dzp), _p(dgamma),
+                                                           _p(dbeta), _p(ws), _p(scratch), _p(dbt), acc, N, C, H * W, ctx.slope, ctx.eps),
+                      "jaf_layernorm_lrelu_bwd_packed")
+            prod.fused = (dzp, db)
+            FUSED_STATS["ln"] += 1
+            dx = torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=torch.float32)     # placeholder
+            return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None, None, None
+        dx = torch.empty_like(x)
         check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
                                             _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
               "jaf_layernorm_lrelu_bwd")
-        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None, None
+        return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None, None, None
 
 
 def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01, pre: Optional[LNStats] = None,
-                    dst: Optional[PackedDst] = None, keep_f32: bool = True):
+                    dst: Optional[PackedDst] = None, keep_f32: bool = True, sole_consumer: bool = False):
     """`dst`: the consumer convolution's packed image slot; keep_f32=False: that convolution is the only reader, so no
     fp32 result is written (both on the packed bf16 path only, see PackedImage)."""
     _chk(x, "layernorm x"); _chk(gamma, "gamma"); _chk(beta, "beta")
-    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre, dst, keep_f32)
+    return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre, dst, keep_f32, sole_consumer)
 
 
 class _BatchNormActFn(Function):

@@ -244,6 +244,41 @@ def test_layernorm_lrelu():
     assert maxerr(bd.grad, br.grad) <= 1e-4
 
 
+@pytest.mark.parametrize("N,Cin,C,H,W", [(2, 8, 16, 12, 20), (3, 5, 10, 9, 7), (1, 16, 24, 32, 32)])
+def test_layernorm_backward_hands_packed_dz_to_its_convolution(N, Cin, C, H, W):
+    """bf16 path, conv (no activation) -> LayerNorm -> LeakyReLU with the LayerNorm as the convolution's only reader
+    (src/crn_model.py:90-106): the LayerNorm backward writes the convolution's packed bf16 dz and its bias gradient
+    (jaf_layernorm_lrelu_bwd_packed) instead of an fp32 dx that jaf_conv2d_pack_dz would read back.  Same expressions in
+    both paths: the data and weight gradients agree to a bf16 ulp of isolated elements, the bias gradient (summed
+    analytically instead of element by element) to fp32 rounding."""
+    ops = _ops()
+    prev = ops.set_precision("bf16")
+    try:
+        x, w, b = R(1, N, Cin, H, W), R(2, C, Cin, 3, 3, lo=-0.3, hi=0.3), R(3, C, lo=-0.2, hi=0.2)
+        g, be = R(4, C, lo=0.3, hi=1.2), R(5, C, lo=-0.2, hi=0.2)
+        proj = dev(R(6, N, C, H, W))
+        res = []
+        for sole in (True, False):
+            xd, wd, bd, gd, bed = (dev(t).requires_grad_(True) for t in (x, w, b, g, be))
+            handed = ops.FUSED_STATS["ln"]
+            y = ops.conv2d(xd, wd, bd, stride=1, pad=1, act=0)
+            z = ops.layernorm_lrelu(y, gd, bed, 1e-5, 0.01, sole_consumer=sole)
+            (z * proj).sum().backward()
+            assert ops.FUSED_STATS["ln"] - handed == (1 if sole else 0)
+            res.append((z.detach().clone(), xd.grad, wd.grad, bd.grad, gd.grad, bed.grad))
+        a, r = res
+        assert torch.equal(a[0], r[0])
+        for k, name in ((1, "dx"), (2, "dw")):
+            scale = r[k].abs().max().item()
+            d = (a[k] - r[k]).abs()
+            assert d.max().item() <= 2e-2 * scale, (name, d.max().item(), scale)               # a flipped bf16 ulp of one dz element
+            assert (d > 1e-6 * scale).float().mean().item() <= 2e-2, (name, (d > 1e-6 * scale).float().mean().item())
+        assert maxerr(a[3], r[3].cpu()) <= 2e-5 * max(1.0, r[3].abs().max().item()), "conv bias gradient"
+        assert torch.equal(a[4], r[4]) and torch.equal(a[5], r[5])                            # gamma / beta: the same reduce pass
+    finally:
+        ops.set_precision(prev)
+
+
 @pytest.mark.parametrize("act,res,training", [(2, False, True), (0, True, True), (1, False, True), (2, False, False)])
 def test_batchnorm_act(act, res, training):
     ops = _ops()

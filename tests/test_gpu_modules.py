@@ -346,6 +346,7 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                     proj = T(synth.uniform(seed, "proj", tuple(out.shape)))
                     added = ops.SLOT_STATS["added"]
                     handed = ops.FUSED_STATS["dz"]
+                    ln_handed = ops.FUSED_STATS["ln"]
                     (out * proj).sum().backward()
                     # with the images on, the last data gradient of a ReLU / LeakyReLU convolution's output hands that layer
                     # its packed dz directly (jaf_packed_io.dz_mask): in the part encoders x1,3,5,7 (from the second of their
@@ -354,6 +355,9 @@ def test_packed_images_are_bit_identical_to_the_packing_pass():
                     # the reference path packs every dz in a pass of its own
                     want = {Accumulate_LSTM_no_loss: 8, UNet_inpainter: 8, VGG19_CRN: 7, CRN_smaller: 0}[cls] if images else 0
                     assert ops.FUSED_STATS["dz"] - handed == want, (cls.__name__, images, ops.FUSED_STATS["dz"] - handed)
+                    # every conv -> LayerNorm pair of the CRN gets its dz from the LayerNorm backward (packed bf16, with or without
+                    # the images): 13 blocks x 2
+                    assert ops.FUSED_STATS["ln"] - ln_handed == (26 if cls is CRN_smaller else 0), ops.FUSED_STATS["ln"] - ln_handed
                     if cls is Accumulate_LSTM_no_loss:
                         # skip features x1, x3, x5, x7 have two consumers (ConvLSTM, enc_{i+1}): with the images on, the
                         # second data gradient is added inside the kernel (ops.GradSlot) -- same numbers, bit for bit
