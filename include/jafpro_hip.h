@@ -318,6 +318,13 @@ int jaf_batchnorm_stats(jaf_stream_t s, const float* x, int32_t N, int32_t C, in
 int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float* stats, const float* weight,
                           const float* bias, const float* residual, float* y, int32_t N,
                           int32_t C, int32_t HW, int act, float slope);
+/* jaf_batchnorm_stats + jaf_batchnorm_act_fwd as ONE call: feature maps of at most 65536 elements per channel (the
+ * discriminators' 4 x 4 .. 64 x 64 levels) take the statistics and apply them in a single launch, one workgroup per channel;
+ * larger ones run the two calls above.  Same arguments, same results.  jaf_batchnorm_act_bwd makes the same choice. */
+int jaf_batchnorm_act_fwd_fused(jaf_stream_t s, const float* x, int32_t N, int32_t C, int32_t HW, float eps,
+                                float momentum, float* running_mean, float* running_var, float* stats,
+                                int training, double* workspace, const float* weight, const float* bias,
+                                const float* residual, float* y, int act, float slope);
 int jaf_batchnorm_act_bwd(jaf_stream_t s, const float* dy, const float* x, const float* y,
                           const float* stats, const float* weight, float* dx, float* dweight,
                           float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,

@@ -578,6 +578,100 @@ extern "C" int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float
     return jaf_launch_status();
 }
 
+// Small tensors (the discriminators' 4 x 4 .. 64 x 64 feature maps: 55 BatchNorm layers per train step, each a chain of
+// memset + partial sums + finalize + apply launches of 3-7 us that the next layer waits for): ONE workgroup per channel
+// takes the statistics and applies them, the second pass over its <= 256 KB coming from L2.  Same fp64 sums and the same
+// finalisation arithmetic as the three-kernel path.
+#define BN_SMALL_MAX 65536      // elements per channel (N * HW)
+template <int V>
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* x, int N, int C, int HW, float eps, float momentum,
+                                                           float* running_mean, float* running_var, float* stats,
+                                                           const float* w, const float* b, const float* residual, float* y,
+                                                           int act, float slope) {
+    const int c = blockIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float* p = x + ((long)n * C + c) * HW;
+        if (V == 4) {
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const f32x4 v = *(const f32x4*)(p + i);
+                s += (double)((v[0] + v[1]) + (v[2] + v[3]));
+                ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                const double v = (double)p[i];
+                s += v;
+                ss += v * v;
+            }
+        }
+    }
+    __shared__ double rs[4], rss[4];
+    __shared__ float sh[2];
+    s = jaf_wave_sum(s);
+    ss = jaf_wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rss[threadIdx.x >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double cnt = (double)N * (double)HW;
+        const double mean = ((rs[0] + rs[1]) + (rs[2] + rs[3])) / cnt;
+        double var = ((rss[0] + rss[1]) + (rss[2] + rss[3])) / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        sh[0] = (float)mean;
+        sh[1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[c] = sh[0];
+        stats[C + c] = sh[1];
+        if (running_mean) {
+            const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+    __syncthreads();
+    const float mean = sh[0], sc = sh[1] * w[c], bb = b[c];
+    for (int n = 0; n < N; ++n) {
+        const long base = ((long)n * C + c) * HW;
+        if (V == 4) {
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const f32x4 xv = *(const f32x4*)(x + base + i);
+                f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+                if (residual) rv = *(const f32x4*)(residual + base + i);
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[k] - mean) * sc + bb, act, slope) + rv[k];
+                *(f32x4*)(y + base + i) = o;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float v = jaf_act((x[base + i] - mean) * sc + bb, act, slope);
+                if (residual) v += residual[base + i];
+                y[base + i] = v;
+            }
+        }
+    }
+}
+
+extern "C" int jaf_batchnorm_act_fwd_fused(jaf_stream_t s_, const float* x, int32_t N, int32_t C, int32_t HW, float eps,
+                                           float momentum, float* running_mean, float* running_var, float* stats,
+                                           int training, double* workspace, const float* weight, const float* bias,
+                                           const float* residual, float* y, int act, float slope) {
+    JAF_REQUIRE(x && stats && workspace && weight && bias && y && N >= 1 && C >= 1 && HW >= 1 && C <= 65535 && N <= 65535);
+    JAF_REQUIRE(training || (running_mean && running_var));
+    JAF_REQUIRE(!residual || act == JAF_ACT_NONE);
+    if (training && (long)N * HW <= BN_SMALL_MAX) {
+        if ((HW % 4 == 0) && al16(x, y, residual))
+            hipLaunchKernelGGL(bn_fwd_small_kernel<4>, dim3(C), dim3(256), 0, (hipStream_t)s_, x, N, C, HW, eps, momentum, running_mean,
+                               running_var, stats, weight, bias, residual, y, act, slope);
+        else
+            hipLaunchKernelGGL(bn_fwd_small_kernel<1>, dim3(C), dim3(256), 0, (hipStream_t)s_, x, N, C, HW, eps, momentum, running_mean,
+                               running_var, stats, weight, bias, residual, y, act, slope);
+        return jaf_launch_status();
+    }
+    const int rc = jaf_batchnorm_stats(s_, x, N, C, HW, eps, momentum, running_mean, running_var, stats, training, workspace);
+    if (rc != JAF_OK) return rc;
+    return jaf_batchnorm_act_fwd(s_, x, stats, weight, bias, residual, y, N, C, HW, act, slope);
+}
+
 __device__ __forceinline__ float bn_dz(float dy, float y, int act, float slope) {
     switch (act) {
         case JAF_ACT_LRELU: return dy * (y > 0.f ? 1.f : slope);
@@ -661,6 +755,78 @@ __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float
     }
 }
 
+// The backward counterpart of bn_fwd_small_kernel: one workgroup per channel reduces (sum dz, sum dz * xhat), writes the
+// parameter gradients and applies -- instead of memset + reduce + finalize + apply.
+template <int V>
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* dy, const float* x, const float* y, const float* stats,
+                                                           const float* w, float* dx, float* dweight, float* dbias, int N, int C,
+                                                           int HW, int act, float slope, int training, int accumulate) {
+    const int c = blockIdx.x;
+    const float mean = stats[c], r = stats[C + c];
+    double sa = 0.0, sb = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const long base = ((long)n * C + c) * HW;
+        if (V == 4) {
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const f32x4 dv = *(const f32x4*)(dy + base + i), xv = *(const f32x4*)(x + base + i);
+                const f32x4 yv = *(const f32x4*)(y + base + i);
+                float pa = 0.f, pb = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = bn_dz(dv[k], yv[k], act, slope);
+                    pa += dz;
+                    pb += dz * ((xv[k] - mean) * r);
+                }
+                sa += (double)pa;
+                sb += (double)pb;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                const float dz = bn_dz(dy[base + i], y[base + i], act, slope);
+                sa += (double)dz;
+                sb += (double)dz * (double)((x[base + i] - mean) * r);
+            }
+        }
+    }
+    __shared__ double ra[4], rb[4];
+    __shared__ float sh[2];
+    sa = jaf_wave_sum(sa);
+    sb = jaf_wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { ra[threadIdx.x >> 6] = sa; rb[threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double a = (ra[0] + ra[1]) + (ra[2] + ra[3]), bsum = (rb[0] + rb[1]) + (rb[2] + rb[3]);
+        dbias[c] = (accumulate ? dbias[c] : 0.f) + (float)a;
+        dweight[c] = (accumulate ? dweight[c] : 0.f) + (float)bsum;
+        const float inv_cnt = 1.0f / ((float)N * (float)HW);
+        sh[0] = training ? (float)a * inv_cnt : 0.f;
+        sh[1] = training ? (float)bsum * inv_cnt : 0.f;
+    }
+    __syncthreads();
+    const float db = sh[0], dw = sh[1], wr = w[c] * r;
+    for (int n = 0; n < N; ++n) {
+        const long base = ((long)n * C + c) * HW;
+        if (V == 4) {
+            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
+                const f32x4 dv = *(const f32x4*)(dy + base + i), xv = *(const f32x4*)(x + base + i);
+                const f32x4 yv = *(const f32x4*)(y + base + i);
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = bn_dz(dv[k], yv[k], act, slope);
+                    o[k] = wr * (dz - db - (xv[k] - mean) * r * dw);
+                }
+                *(f32x4*)(dx + base + i) = o;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                const float dz = bn_dz(dy[base + i], y[base + i], act, slope);
+                dx[base + i] = wr * (dz - db - (x[base + i] - mean) * r * dw);
+            }
+        }
+    }
+}
+
 extern "C" int jaf_batchnorm_act_bwd(jaf_stream_t s_, const float* dy, const float* x, const float* y,
                                      const float* stats, const float* weight, float* dx, float* dweight,
                                      float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
@@ -668,9 +834,16 @@ extern "C" int jaf_batchnorm_act_bwd(jaf_stream_t s_, const float* dy, const flo
     JAF_REQUIRE(dy && x && y && stats && weight && dx && dweight && dbias && workspace && N >= 1 && C >= 1 && HW >= 1);
     JAF_REQUIRE(C <= 65535 && N <= 65535);
     hipStream_t s = (hipStream_t)s_;
+    const bool v4 = (HW % 4 == 0) && al16(dy, x, y, dx);
+    if ((long)N * HW <= BN_SMALL_MAX) {
+        if (v4) hipLaunchKernelGGL(bn_bwd_small_kernel<4>, dim3(C), dim3(256), 0, s, dy, x, y, stats, weight, dx, dweight, dbias, N, C, HW,
+                                   act, slope, training, accumulate);
+        else hipLaunchKernelGGL(bn_bwd_small_kernel<1>, dim3(C), dim3(256), 0, s, dy, x, y, stats, weight, dx, dweight, dbias, N, C, HW,
+                                act, slope, training, accumulate);
+        return jaf_launch_status();
+    }
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * C, s);
     if (e != hipSuccess) return (int)e;
-    const bool v4 = (HW % 4 == 0) && al16(dy, x, y, dx);
     const int ns = bn_nsplit(C, N, HW);
     if (v4) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(C, ns), dim3(256), 0, s, dy, x, y, stats, workspace, N, C, HW, act, slope);
     else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(C, ns), dim3(256), 0, s, dy, x, y, stats, workspace, N, C, HW, act, slope);

@@ -1477,11 +1477,10 @@ class _BatchNormActFn(Function):
         L = lib()
         stats = torch.empty(2 * C, device=x.device, dtype=torch.float32)
         ws = torch.empty(2 * C, device=x.device, dtype=torch.float64)
-        check(L.jaf_batchnorm_stats(_s(), _p(x), N, C, H * W, eps, momentum, _p(running_mean), _p(running_var),
-                                    _p(stats), 1 if training else 0, _p(ws)), "jaf_batchnorm_stats")
         y = torch.empty_like(x)
-        check(L.jaf_batchnorm_act_fwd(_s(), _p(x), _p(stats), _p(weight), _p(bias), _p(residual), _p(y), N, C, H * W,
-                                      act, slope), "jaf_batchnorm_act_fwd")
+        check(L.jaf_batchnorm_act_fwd_fused(_s(), _p(x), N, C, H * W, eps, momentum, _p(running_mean), _p(running_var),
+                                            _p(stats), 1 if training else 0, _p(ws), _p(weight), _p(bias), _p(residual), _p(y),
+                                            act, slope), "jaf_batchnorm_act_fwd_fused")
         ctx.cfg = (training, act, slope, residual is not None)
         ctx.bias_ref = bias
         ctx.save_for_backward(x, y, weight, stats)

@@ -274,15 +274,20 @@ def test_layernorm_backward_hands_packed_dz_to_its_convolution(N, Cin, C, H, W):
             assert d.max().item() <= 2e-2 * scale, (name, d.max().item(), scale)               # a flipped bf16 ulp of one dz element
             assert (d > 1e-6 * scale).float().mean().item() <= 2e-2, (name, (d > 1e-6 * scale).float().mean().item())
         assert maxerr(a[3], r[3].cpu()) <= 2e-5 * max(1.0, r[3].abs().max().item()), "conv bias gradient"
-        assert torch.equal(a[4], r[4]) and torch.equal(a[5], r[5])                            # gamma / beta: the same reduce pass
+        for k in (4, 5):         # gamma / beta: the same reduce pass (fp32 atomics over the images: summation order only)
+            assert maxerr(a[k], r[k].cpu()) <= 1e-5 * max(1.0, r[k].abs().max().item())
     finally:
         ops.set_precision(prev)
 
 
+@pytest.mark.parametrize("shape", [(3, 6, 11, 7), (2, 8, 16, 12), (2, 4, 200, 180)],
+                         ids=["one-launch-scalar", "one-launch-16B", "three-kernel"])
 @pytest.mark.parametrize("act,res,training", [(2, False, True), (0, True, True), (1, False, True), (2, False, False)])
-def test_batchnorm_act(act, res, training):
+def test_batchnorm_act(act, res, training, shape):
+    """(feature maps of at most 65536 elements per channel take the statistics and apply them in one launch, forward and
+    backward: jaf_batchnorm_act_fwd_fused / jaf_batchnorm_act_bwd; the third shape runs the multi-kernel path)"""
     ops = _ops()
-    N, C, H, W = 3, 6, 11, 7
+    N, C, H, W = shape
     x, w, b = R(1, N, C, H, W, lo=-2, hi=2), R(2, C, lo=0.5, hi=1.5), R(3, C, lo=-0.3, hi=0.3)
     rm, rv = R(4, C, lo=-0.1, hi=0.1), R(5, C, lo=0.8, hi=1.2)
     rsd = R(6, N, C, H, W)
@@ -302,8 +307,9 @@ def test_batchnorm_act(act, res, training):
     assert maxerr(y, y_ref) <= 5e-6 * max(1.0, y_ref.abs().max().item())
     assert maxerr(rm_d, rm_r) <= 1e-6 and maxerr(rv_d, rv_r) <= 1e-6
     (y * dev(proj)).sum().backward()
-    assert maxerr(xd.grad, xr.grad) <= 2e-5
-    assert maxerr(wd.grad, wr.grad) <= 1e-4 and maxerr(bd.grad, br.grad) <= 1e-4
+    sc = lambda t: max(1.0, t.abs().max().item())
+    assert maxerr(xd.grad, xr.grad) <= 2e-5 * sc(xr.grad)
+    assert maxerr(wd.grad, wr.grad) <= 1e-4 * sc(wr.grad) and maxerr(bd.grad, br.grad) <= 1e-4 * sc(br.grad)
     if res:
         assert maxerr(rd.grad, rr.grad) <= 1e-6
 
