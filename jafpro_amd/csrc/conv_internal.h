@@ -50,6 +50,26 @@ static inline long jaf_wgrad_nsplit_rounds(long items, long outblocks, long dw_f
     return best;
 }
 
+// Workgroups of `kernel` (256 threads, `lds` bytes) the device holds at once, asked of the runtime once per
+// (instantiation, LDS size, device): registers decide it for the 3 x 3 kernels (2 per CU at 16*3 and 16*4 rows, 3 at 16*2,
+// 4 at 16), LDS for the stride-2 and double-buffered ones.
+struct JafOcc { int lds, slots; };
+static inline int jaf_kernel_slots(const void* kernel, int lds, JafOcc (*cache)[8]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= JAF_MAX_DEVICES) return 512;
+    JafOcc* c = cache[dev];
+    for (int i = 0; i < 8; ++i)
+        if (c[i].lds == lds && c[i].slots > 0) return c[i].slots;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, (size_t)lds) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int slots = per_cu * cus;
+    for (int i = 0; i < 8; ++i)
+        if (c[i].slots == 0) { c[i].lds = lds; c[i].slots = slots; break; }
+    return slots;
+}
+
+
 int jafb_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
               int32_t w_rows_tot, void* packed);

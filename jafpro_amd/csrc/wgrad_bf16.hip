@@ -398,18 +398,20 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
     JAF_REQUIRE(lds <= 160 * 1024);
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
-    const long nsplit = jaf_wgrad_nsplit(items, outblocks, (long)d->G * d->Cout * d->Cin * 9, 5e-6);   // fp32-input staging: slower items
-    a.nsplit = (int)nsplit;
-    const long nblk = outblocks * nsplit;
-    JAF_REQUIRE(nblk <= 0x7fffffffL);
+    // pixel splits from the kernel's true residency, in whole rounds (jaf_wgrad_nsplit_rounds; fp32-input staging: slower items)
 #define JAF_WGB(MT_, SP_)                                                                              \
     do {                                                                                               \
         auto k = conv_wgrad_bf16_kernel<MT_, SP_>;                                                     \
         static int optin[JAF_MAX_DEVICES];                                                             \
+        static JafOcc occ[JAF_MAX_DEVICES][8];                                                         \
         if (lds > 48 * 1024) {                                                                         \
             const int e = jaf_lds_optin((const void*)k, optin);                                        \
             if (e) return e;                                                                           \
         }                                                                                              \
+        a.nsplit = (int)jaf_wgrad_nsplit_rounds(items, outblocks, (long)d->G * d->Cout * d->Cin * 9,    \
+                                                (double)jaf_kernel_slots((const void*)k, lds, occ), 5e-6); \
+        const long nblk = outblocks * a.nsplit;                                                        \
+        if (nblk > 0x7fffffffL) return JAF_EINVAL;                                                     \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)
     if (split) switch (MTW) {

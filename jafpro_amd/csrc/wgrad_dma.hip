@@ -329,30 +329,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
 static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 
-// Workgroups of `kernel` (256 threads, `lds` bytes) the device holds at once, asked of the runtime once per
-// (instantiation, LDS size, device): registers decide it for the 3 x 3 kernels (2 per CU at 16*3 and 16*4 rows, 3 at 16*2,
-// 4 at 16), LDS for the stride-2 and double-buffered ones.
-struct WgdOcc { int lds, slots; };
-static int wgd_slots(const void* kernel, int lds, WgdOcc (*cache)[8]) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= JAF_MAX_DEVICES) return 512;
-    WgdOcc* c = cache[dev];
-    for (int i = 0; i < 8; ++i)
-        if (c[i].lds == lds && c[i].slots > 0) return c[i].slots;
-    int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, (size_t)lds) != hipSuccess || per_cu < 1) per_cu = 2;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-    const int slots = per_cu * cus;
-    for (int i = 0; i < 8; ++i)
-        if (c[i].slots == 0) { c[i].lds = lds; c[i].slots = slots; break; }
-    return slots;
-}
-
 template <int MTW, int KS, bool PAIR, bool DB>
 static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
     auto k = conv_wgrad_dma_kernel<MTW, KS, PAIR, DB>;
     static int optin[JAF_MAX_DEVICES];
-    static WgdOcc occ[JAF_MAX_DEVICES][8];
+    static JafOcc occ[JAF_MAX_DEVICES][8];
     if (lds > 48 * 1024) {
         const int e = jaf_lds_optin((const void*)k, optin);
         if (e) return e;
@@ -360,7 +341,7 @@ static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_f
     // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of atomic
     // traffic per launch at 1536 workgroups) and contends for the same addresses: see jaf_wgrad_nsplit
     static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
-    const double slots = slots_env > 0.0 ? slots_env : (double)wgd_slots((const void*)k, lds, occ);
+    const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
     a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
     const long nblk = outblocks * a.nsplit;
