@@ -159,7 +159,8 @@ int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const
                           void* packed, float* dz, float* dbias);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
  * [N][G][4C/8][H*W][8] (order i,f,o,g per group) and their per-channel sums ADDED to dbias[G*4C];
- * `gates` (fp32 or bf16, as the forward cell wrote them) is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0.                                   */
+ * `gates` (as the forward cell wrote them: fp32 planes [N][G][gate][C][H*W], or bf16 gate-innermost
+ * [N][G][C][H*W][i, f, o, g] from jaf_convlstm_cell_fwd_packed*) is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0. */
 int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
                                   const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                   const float* c_cur, float* dc_prev, void* packed, float* dbias);
@@ -225,7 +226,9 @@ int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_c
                              const void* packed_in, const void* packed_w, const float* bias, float* out,
                              double* stats, int32_t stat_slots, const jaf_packed_io* io);
 /* ConvLSTM cell: `io->dst` receives h_t (4 * hidden = Cout rows -> hidden channels); skip_f32 drops the fp32 h_out
- * (c_out and the saved gates are always written). */
+ * (c_out and the saved gates are always written).  gates_bf16: the saved gates are bf16 and gate-innermost,
+ * [N][G][hidden][H*W][i, f, o, g] (a lane's pixels x 4 gates are contiguous: 16-byte stores here, one 16-byte load per pixel
+ * pair in jaf_convlstm_gates_bwd_packed); fp32 gates keep the planes [N][G][gate][hidden][H*W]. */
 int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                                     const void* packed_in, const void* packed_w, const float* bias,
                                     const float* c_prev, float* h_out, float* c_out, void* gates_out,
@@ -233,7 +236,7 @@ int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, cons
 
 /* 3x3 weight gradient from the packed input of the forward conv and the packed dz of the data
  * gradient (csrc/wgrad_dma.hip).  Returns JAF_EUNSUPPORTED for shapes it does not cover (stride-2
- * layers with more than 16 input channels): use jaf_conv2d_wgrad there.                          */
+ * layers whose patch does not fit: none of the 1x1 / 3x3 / 5x5 shapes today); jaf_conv2d_wgrad covers 7x7.   */
 int jaf_conv2d_wgrad_packed(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x,
                             const void* packed_dz, float* dw, int accumulate);
 /* Same with packed_x an image of x_ng8_tot >= ceil(Cin/8) planes per (image, group) (see jaf_packed_io). */

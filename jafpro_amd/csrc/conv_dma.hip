@@ -690,18 +690,32 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
             const long e = (ng * C + c) * (long)HW + pix;
             const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
             float gi[V], gf[V], go[V], gg[V], cc[V], dhv[V], dcn[V], cp[V];
-            if (V > 1) {
-                typedef GT gv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
-                const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
+            if constexpr (sizeof(GT) == 2) {
+                // bf16 gates are gate-innermost ([c][pixel][i, f, o, g], written by the cell kernel's epilogue)
+                typedef GT g4 __attribute__((ext_vector_type(4)));
+                const GT* gq = gates + ng * 4 * C * (long)HW + ((long)c * HW + pix) * 4;
 #pragma unroll
                 for (int k = 0; k < V; ++k) {
-                    gi[k] = (float)ti[k]; gf[k] = (float)tf[k]; go[k] = (float)to[k]; gg[k] = (float)tg[k];
+                    const g4 t = *(const g4*)(gq + 4 * k);
+                    gi[k] = (float)t[0]; gf[k] = (float)t[1]; go[k] = (float)t[2]; gg[k] = (float)t[3];
+                }
+            }
+            if (V > 1) {
+                if constexpr (sizeof(GT) != 2) {
+                    typedef GT gv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
+                    const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) {
+                        gi[k] = (float)ti[k]; gf[k] = (float)tf[k]; go[k] = (float)to[k]; gg[k] = (float)tg[k];
+                    }
                 }
                 *(fv*)cc = *(const fv*)(c_cur + e); *(fv*)dhv = *(const fv*)(dh + e);
                 if (dc_next) *(fv*)dcn = *(const fv*)(dc_next + e);
                 if (c_prev) *(fv*)cp = *(const fv*)(c_prev + e);
             } else {
-                gi[0] = (float)gp[0]; gf[0] = (float)gp[cs]; go[0] = (float)gp[2 * cs]; gg[0] = (float)gp[3 * cs];
+                if constexpr (sizeof(GT) != 2) {
+                    gi[0] = (float)gp[0]; gf[0] = (float)gp[cs]; go[0] = (float)gp[2 * cs]; gg[0] = (float)gp[3 * cs];
+                }
                 cc[0] = c_cur[e]; dhv[0] = dh[e];
                 if (dc_next) dcn[0] = dc_next[e];
                 if (c_prev) cp[0] = c_prev[e];
@@ -796,8 +810,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void l
                 if (live) {
                     const int c = cb + 2 * j2 + h;
                     const long e = (ng * C + c) * (long)HW + pix;
-                    const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
-                    const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
+                    gv ti, tf, to, tg;
+                    if constexpr (sizeof(GT) == 2) {          // gate-innermost bf16: V pixels x 4 gates in one load
+                        typedef GT g4v __attribute__((ext_vector_type(4 * V)));
+                        const g4v t = *(const g4v*)(gates + ng * 4 * C * (long)HW + ((long)c * HW + pix) * 4);
+#pragma unroll
+                        for (int k = 0; k < V; ++k) { ti[k] = t[4 * k]; tf[k] = t[4 * k + 1]; to[k] = t[4 * k + 2]; tg[k] = t[4 * k + 3]; }
+                    } else {
+                        const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
+                        ti = *(const gv*)gp; tf = *(const gv*)(gp + cs); to = *(const gv*)(gp + 2 * cs); tg = *(const gv*)(gp + 3 * cs);
+                    }
                     const fv cc = *(const fv*)(c_cur + e), dhv = *(const fv*)(dh + e);
                     fv dcn, cp;
                     if (dc_next) dcn = *(const fv*)(dc_next + e);
@@ -1176,11 +1198,17 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 }
                 if (a.gates_out) {
                     if (a.gates_bf16) {
-                        __bf16* gp = (__bf16*)a.gates_out + gc + opix[0];
-                        *(hvec*)(gp + (long)(ch)*OHW) = __builtin_convertvector(vi, hvec);
-                        *(hvec*)(gp + (long)(C + ch) * OHW) = __builtin_convertvector(vf, hvec);
-                        *(hvec*)(gp + (long)(2 * C + ch) * OHW) = __builtin_convertvector(vo, hvec);
-                        *(hvec*)(gp + (long)(3 * C + ch) * OHW) = __builtin_convertvector(vg, hvec);
+                        // bf16 gates are kept gate-innermost, [n][g][c][pixel][i, f, o, g]: the lane's NT pixels x 4 gates are
+                        // 8 NT contiguous bytes (two 16-byte stores at NT = 4 instead of four 8-byte ones; the epilogue is
+                        // store-issue bound) and the gate backward fetches a pixel pair's four gates with one 16-byte load
+                        typedef __bf16 g4vec __attribute__((ext_vector_type(NT == 1 ? 8 : 4 * NT)));
+                        typedef float f4vec __attribute__((ext_vector_type(NT == 1 ? 8 : 4 * NT)));
+                        f4vec gv;
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            gv[4 * nt] = vi[nt]; gv[4 * nt + 1] = vf[nt]; gv[4 * nt + 2] = vo[nt]; gv[4 * nt + 3] = vg[nt];
+                        }
+                        *(g4vec*)((__bf16*)a.gates_out + gc + ((long)ch * OHW + opix[0]) * 4) = __builtin_convertvector(gv, g4vec);
                     } else {
                         float* gp = a.gates_out + gc + opix[0];
                         *(fvec*)(gp + (long)(ch)*OHW) = vi;
@@ -1206,11 +1234,11 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         *(__bf16*)cd_dst_ptr(a.dst, ((long)(n + a.dst_img_off)) * d.G + g, a.dst_ng8, a.dst_coff + ch, OHW, opix[nt]) = (__bf16)hv;
                     if (a.gates_out) {
                         if (a.gates_bf16) {
-                            __bf16* gp = (__bf16*)a.gates_out + gc + opix[nt];
-                            gp[(long)(ch)*OHW] = (__bf16)gi;
-                            gp[(long)(C + ch) * OHW] = (__bf16)gf;
-                            gp[(long)(2 * C + ch) * OHW] = (__bf16)go;
-                            gp[(long)(3 * C + ch) * OHW] = (__bf16)gg;
+                            __bf16* gp = (__bf16*)a.gates_out + gc + ((long)ch * OHW + opix[nt]) * 4;
+                            gp[0] = (__bf16)gi;
+                            gp[1] = (__bf16)gf;
+                            gp[2] = (__bf16)go;
+                            gp[3] = (__bf16)gg;
                         } else {
                             float* gp = a.gates_out + gc + opix[nt];
                             gp[(long)(ch)*OHW] = gi;

@@ -574,7 +574,8 @@ def test_lstm_gates_bwd_packed_direct(C, H, W, g16, first):
     dcp_ref = dc * f
     db_ref = dgates.sum((0, 4, 5)).reshape(-1)
     d = {k: dev(v.contiguous()) for k, v in dict(dh=dh, dcn=dcn, cp=cp, cc=cc).items()}
-    gd = gates.reshape(N, G * 4 * C, H, W).contiguous().cuda()
+    # fp32 gates: planes [n][g][gate][c][px]; bf16 gates (what the packed cell kernel saves): gate-innermost [n][g][c][px][gate]
+    gd = (gates.permute(0, 1, 3, 4, 5, 2) if g16 else gates.reshape(N, G * 4 * C, H, W)).contiguous().cuda()
     dcp = torch.empty(N, G * C, H, W, device="cuda")
     ng8 = 4 * C // 8
     packed = torch.zeros(N * G * ng8 * HW * 8, device="cuda", dtype=torch.bfloat16)
