@@ -1539,7 +1539,14 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 const double stage = 600.0 + ((double)npos * NG * 16.0 + (double)nsteps * MT * 1024.0) / 48.0;
                 const int blocks_cu = (int)(160 * 1024 / lds);
                 const int bl = blocks_cu > 6 ? 6 : blocks_cu;
-                const double occ_pen = bl >= 3 ? 1.0 : (bl == 2 ? 1.1 : 1.4);
+                // two resident workgroups do not overlap each other's phases (DMA, matrix cores and epilogue of
+                // the 256 -> 256 layer add up): where a launch has at least 4 workgroups per CU to run, 4 resident ones on half-size
+                // chunks beat 2 on full-size chunks by 2-11 % in spite of 10 % of padded k-steps (measured, 64 x 64 .. 256 x 256
+                // layers); with fewer workgroups than that the larger chunks win by 15-19 % (32 x 32 layers)
+                static const double pen2 = getenv("JAF_PLAN_PEN2") ? atof(getenv("JAF_PLAN_PEN2")) : 1.25;
+                const double nblocks0 = (double)tiles_x * tiles_p * jaf_cdiv(M, 16 * MT) * d->N * d->G;
+                const bool big = nblocks0 >= 1024.0;
+                const double occ_pen = bl >= 4 ? 1.0 : (bl == 3 ? (big ? 0.5 * (1.0 + pen2) : 1.0) : (bl == 2 ? (big ? pen2 : 1.1) : 1.4));
                 const double fixed = 2500.0 + 60.0 * MT * NT;
                 // whole-launch cost: workgroups / 256 CUs, but never less than one workgroup's own
                 // latency (deep 4x4 .. 16x16 layers launch fewer workgroups than there are CUs, and
