@@ -55,7 +55,10 @@ struct WgDArgs {
 // under tile i's matrix-core pass, so a workgroup keeps two tiles' worth of bytes in flight instead of alternating between
 // "waiting for a tile" and "multiplying it"; one barrier per tile instead of two.  The wide layers (46 KB tiles) stay
 // single-buffered: a second buffer would halve their residency (2 -> 1 workgroups per CU), which measured slower.
-template <int MTW, int KS, bool PAIR, bool DB>
+// XI: patch DMA instructions per wave and tile this instantiation provides for (4: stride 1 with up to 32 input channels per
+// workgroup, 8: stride 1 with 64, 11: stride 2).  Their per-lane constants (x_rc, x_goff) stay live across the whole loop: at
+// 11 for everybody the 48-row kernel took 175-181 registers (2 workgroups per CU), at 4 it fits 3.
+template <int MTW, int KS, bool PAIR, bool DB, int XI>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
     constexpr int NTAP = KS * KS;
     constexpr int NACC = PAIR ? (NTAP + 1) / 2 : NTAP;
@@ -96,9 +99,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     // ---- DMA lane constants.  Patch: instruction i = wave + 4*j covers slots [64*(i % nx), +64) of ci
     // tile i / nx; a slot is 16 bytes: (position, half) after undoing the bit-7 swizzle. ----
     const int nxi = WC * a.nx;                 // patch DMA instructions per tile
-    int x_rc[WD_XI], x_goff[WD_XI];
+    int x_rc[WD_XI], x_goff[WD_XI];        // (only the first XI entries are used)
 #pragma unroll
-    for (int j = 0; j < WD_XI; ++j) {
+    for (int j = 0; j < XI; ++j) {
         const int i = wave + 4 * j;
         const int tci = i / a.nx;
         const int slot = (i - tci * a.nx) * 64 + lane;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         const jaf_u32x4 rxa = jaf_make_rsrc(a.xp + ((long)n * d.G + g) * (long)xbytes, (unsigned)xbytes);
         const int tbase = (iy0 * d.W + ix0) * 16;
 #pragma unroll
-        for (int j = 0; j < WD_XI; ++j) {
+        for (int j = 0; j < XI; ++j) {
             const int i = wave + 4 * j;
             if (i < nxi) {
                 const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
@@ -329,9 +332,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
 static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int MTW, int KS, bool PAIR, bool DB>
-static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
-    auto k = conv_wgrad_dma_kernel<MTW, KS, PAIR, DB>;
+template <int MTW, int KS, bool PAIR, bool DB, int XI>
+static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
+    auto k = conv_wgrad_dma_kernel<MTW, KS, PAIR, DB, XI>;
     static int optin[JAF_MAX_DEVICES];
     static JafOcc occ[JAF_MAX_DEVICES][8];
     if (lds > 48 * 1024) {
@@ -348,6 +351,14 @@ static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_f
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
+}
+
+template <int MTW, int KS, bool PAIR, bool DB>
+static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
+    const int need = jaf_cdiv(a.WC * a.nx, 4);
+    if (need <= 4) return wgd_launch_xi<MTW, KS, PAIR, DB, 4>(a, lds, items, outblocks, dw_floats, s);
+    if (need <= 8) return wgd_launch_xi<MTW, KS, PAIR, DB, 8>(a, lds, items, outblocks, dw_floats, s);
+    return wgd_launch_xi<MTW, KS, PAIR, DB, WD_XI>(a, lds, items, outblocks, dw_floats, s);
 }
 
 extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x,
