@@ -1005,6 +1005,23 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bv[j] = (a.bias && co0 + j < d.Cout) ? a.bias[g * d.Cout + co0 + j] : 0.f;
                 float bsum[4] = {0.f, 0.f, 0.f, 0.f};     // dz mode: this lane's share of the producer's bias gradient
+                // dz mode: the sign masks of the lane's NT pixels, requested together and ahead of the first consumer's gradient
+                // (inside the pixel loop each 8-byte load sat behind the previous pixel's store: the compiler cannot move a
+                // load above a store to a pointer that may alias it)
+                unsigned int mk[NT][2];
+                if (DZ) {
+                    const long ngm = ((long)n) * d.G + g;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        mk[nt][0] = mk[nt][1] = 0u;
+                        if (opix[nt] >= 0) {
+                            const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
+                                                                                      a.dz_mask_coff + co0, OHW, opix[nt]);
+                            mk[nt][0] = xp2[0];
+                            mk[nt][1] = xp2[1];
+                        }
+                    }
+                }
                 // dz mode, second of two consumers: the first one's gradient, 4 channels x NT pixels (one vector load per
                 // channel when the lane's pixels are consecutive)
                 float part[4][NT];
@@ -1037,10 +1054,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     if (DZ) {
                         // producer's dz: (this data gradient [+ the first consumer's]) * act'(x), x from the packed image the
                         // consumer layer read (4 consecutive channels = 8 bytes of a 16-byte item)
-                        const long ngm = ((long)n) * d.G + g;
-                        const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
-                                                                                  a.dz_mask_coff + co0, OHW, opix[nt]);
-                        const unsigned int x01 = xp2[0], x23 = xp2[1];
+                        const unsigned int x01 = mk[nt][0], x23 = mk[nt][1];
                         const float xs[4] = {__builtin_bit_cast(float, x01 << 16), __builtin_bit_cast(float, x01 & 0xffff0000u),
                                              __builtin_bit_cast(float, x23 << 16), __builtin_bit_cast(float, x23 & 0xffff0000u)};
 #pragma unroll
