@@ -150,7 +150,10 @@ def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, O
         wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
     # two tile buffers when a (patch, dz) tile is at most 40 KB
     db = (wc * xplane + mt_best * 4096 <= 40 * 1024) and not _WGRAD_NO_DB
-    return "conv_wgrad_dma_kernel<%d, %d, %s, %s>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false", "true" if db else "false")
+    need = -(-(wc * nx) // 4)                # patch DMA pieces per wave: the XI template argument
+    xi = 4 if need <= 4 else (8 if need <= 8 else 11)
+    return "conv_wgrad_dma_kernel<%d, %d, %s, %s, %d>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false",
+                                                          "true" if db else "false", xi)
 
 
 def _wgrad_name(KH, KW) -> str:
