@@ -1182,8 +1182,14 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             const long hc = (((long)n * d.G + g) * C + ch) * OHW;
             const long gc = ((long)n * d.G + g) * d.Cout * (long)OHW;
             if (vec) {
-                if (opix[0] < 0) continue;
+                // NT == 4 with a packed destination: no lane leaves before the 4 x 4 lane transpose of h below (a lane group's 4
+                // consecutive pixels are valid or invalid together; dead lanes compute on zeros and store nothing).  Hidden channels
+                // in whole groups of 4 (every real layer): the `ch >= C` exit above is then uniform over the four row groups.
+                const bool live = opix[0] >= 0;
+                const bool xpose = (NT == 4) && a.dst && (C & 3) == 0;
+                if (!live && !xpose) continue;
                 fvec cp, vi, vf, vo, vg, vc, vh;
+                float hs4[4] = {0.f, 0.f, 0.f, 0.f};     // h of the lane's pixels as scalars (see the transpose below)
                 if (a.c_prev) {
                     if (NT == 4) {                      // fetched before the matrix-core loop (conv_dma_kernel): no exposed latency here
 #pragma unroll
@@ -1201,16 +1207,39 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     const float c_old = a.c_prev ? cp[nt] : 0.f;
                     vc[nt] = vf[nt] * c_old + vi[nt] * vg[nt];
                     vh[nt] = vo[nt] * jaf_tanh(vc[nt]);
+                    hs4[nt & 3] = vh[nt];
                 }
-                *(fvec*)(a.c_out + hc + opix[0]) = vc;
-                if (!a.skip_f32) *(fvec*)(a.h_out + hc + opix[0]) = vh;
+                if (live) {
+                    *(fvec*)(a.c_out + hc + opix[0]) = vc;
+                    if (!a.skip_f32) *(fvec*)(a.h_out + hc + opix[0]) = vh;
+                }
                 if (a.dst) {     // h_t straight into the consumer's packed image (next step's [x, h] / the decoder's skip)
                     const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
+                    if (xpose) {
+                        // the 4 row groups (q) of a lane column hold channels cb .. cb+3 of the same 4 pixels: a 4 x 4 transpose over
+                        // (q, pixel) -- two v_permlane32_swap + two v_permlane16_swap -- gives every lane 4 consecutive channels of
+                        // ONE pixel = 8 contiguous bytes of its packed item: 1 store instead of 4 two-byte ones (12 -> 3 per lane).
+                        // From assembly and from scalar copies of h: fed with elements of the float4 `vh`, this compiler passed ONE
+                        // register as all four operands (builtins and assembly alike; the sequence itself is verified in
+                        // scratch/t/swap_test*.hip).
+                        unsigned t0 = __builtin_bit_cast(unsigned, hs4[0]), t1 = __builtin_bit_cast(unsigned, hs4[1]);
+                        unsigned t2 = __builtin_bit_cast(unsigned, hs4[2]), t3 = __builtin_bit_cast(unsigned, hs4[3]);
+                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
+                                     "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                        if (live) {
+                            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                            const u32x2 w = {cd_pack2(__builtin_bit_cast(float, t0), __builtin_bit_cast(float, t1)),
+                                             cd_pack2(__builtin_bit_cast(float, t2), __builtin_bit_cast(float, t3))};
+                            *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + (ch - q), OHW, opix[0] + q) = w;
+                        }
+                    } else {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        *(__bf16*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt) = (__bf16)vh[nt];
+                        for (int nt = 0; nt < NT; ++nt)
+                            *(__bf16*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt) = (__bf16)vh[nt];
+                    }
                 }
-                if (a.gates_out) {
+                if (a.gates_out && live) {
                     if (a.gates_bf16) {
                         // bf16 gates are kept gate-innermost, [n][g][c][pixel][i, f, o, g]: the lane's NT pixels x 4 gates are
                         // 8 NT contiguous bytes (two 16-byte stores at NT = 4 instead of four 8-byte ones; the epilogue is

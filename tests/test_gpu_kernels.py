@@ -549,6 +549,32 @@ def test_rasterizer_small_cases():
         assert (fr[0] == -1).all() and (fr[2] == -1).all() and (fr[1] == 2).any() and not (fr[1] == 3).any()
 
 
+@pytest.mark.parametrize("T,N,G,C,H,W", [(2, 2, 4, 12, 72, 40), (2, 2, 3, 24, 100, 100), (1, 2, 3, 12, 50, 50), (2, 1, 2, 12, 64, 48)])
+def test_convlstm_h_in_packed_image(T, N, G, C, H, W):
+    """bf16 path: the cell kernel writes h_T straight into a channel slot of the consumer's packed image
+    (jaf_packed_io.dst).  With 4 pixels per lane (widths that are multiples of the 16-pixel tile rows) the four row groups of
+    a wave exchange their values with v_permlane{32,16}_swap so that each lane stores 4 channels of one pixel: the image must
+    hold exactly RNE-bf16(h), nothing outside the slot may be touched.  (72 x 40: ragged tiles, dead lanes take part in the
+    exchange; 50 x 50 and 64 x 48: the scalar store path.)"""
+    ops = _ops()
+    prev = ops.set_precision("bf16")
+    try:
+        x = dev(R(1, T, N, G * C, H, W, lo=-1, hi=1))
+        w = dev(R(2, G * 4 * C, 2 * C, 3, 3, lo=-0.15, hi=0.15))
+        b = dev(R(3, G * 4 * C, lo=-0.1, hi=0.1))
+        img = ops.PackedImage(2 * N, G, 2 * C, H, W, "cuda", zero=True)
+        with torch.no_grad():
+            h, c = ops.convlstm(x, w, b, groups=G, final_dst=img.slot(C, N))
+        buf = img.buf.view(torch.bfloat16).float().reshape(2 * N, G, img.ng8, H * W, 8)
+        full = buf.permute(0, 1, 2, 4, 3).reshape(2 * N, G, img.ng8 * 8, H, W)
+        ref = h.reshape(N, G, C, H, W).to(torch.bfloat16).float()
+        assert torch.equal(full[N:, :, C:2 * C], ref)
+        assert full[:N].abs().max().item() == 0.0 and full[N:, :, :C].abs().max().item() == 0.0
+        assert full[N:, :, 2 * C:].numel() == 0 or full[N:, :, 2 * C:].abs().max().item() == 0.0
+    finally:
+        ops.set_precision(prev)
+
+
 @pytest.mark.parametrize("C,H,W,g16,first", [(12, 20, 20, True, False), (12, 10, 14, True, True), (24, 10, 10, True, False),
                                              (24, 6, 6, False, False), (48, 5, 5, True, False), (12, 5, 5, True, False),
                                              (4, 6, 6, True, False), (12, 20, 20, False, False)])
