@@ -1047,9 +1047,18 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         }
                     }
                 }
+                // Whole 16-byte items: row groups q and q^1 hold the two halves (channels +0..3 / +4..7) of the same item for the same
+                // NT pixels.  With 4 pixels per lane they exchange halves -- v_permlane16_swap: the even group keeps pixels 0, 1, the odd
+                // one takes pixels 2, 3 -- and every lane issues two 16-byte stores instead of four 8-byte ones (the epilogue is
+                // store-issue bound; measured on the fused-dz launches: the 8-byte stores were 8-25 % of the kernel).  Needs the
+                // pair's 8 channels inside the written range and the slot on an item boundary; no lane of the pair may leave early.
+                const bool pair_ok = (NT == 4) && ((a.dst_coff & 7) == 0) && ((co0 & ~4) + 8 <= cpad);
+                unsigned int wl[NT], wh[NT];       // the lane's 8 bytes per pixel, as scalars (see the ConvLSTM transpose below)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    if (opix[nt] < 0) continue;
+                    wl[nt] = wh[nt] = 0u;
+                    const bool pv = opix[nt] >= 0;
+                    if (!pv && !pair_ok) continue;
                     float v[4];
                     if (DZ) {
                         // producer's dz: (this data gradient [+ the first consumer's]) * act'(x), x from the packed image the
@@ -1060,7 +1069,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float t = 0.f;
-                            if (co0 + j < dC) {
+                            if (pv && co0 + j < dC) {
                                 t = acc[mt][nt][j];
                                 if (a.acc_out) t += part[j][nt];
                                 t *= (xs[j] > 0.f) ? 1.f : a.dz_slope;
@@ -1072,15 +1081,37 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = (co0 + j < d.Cout) ? jaf_act(acc[mt][nt][j] + bv[j], d.act, d.slope) : 0.f;
                     }
-                    u32x2 w = {cd_pack2(v[0], v[1]), cd_pack2(v[2], v[3])};
+                    wl[nt] = cd_pack2(v[0], v[1]);
+                    wh[nt] = cd_pack2(v[2], v[3]);
+                    if (pair_ok) continue;
                     if (co0 + 4 <= cpad || a.dst_pad_tail) {
+                        const u32x2 w = {wl[nt], wh[nt]};
                         *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]) = w;
                     } else {           // a 4-group that straddles the end of this source: channel by channel
                         unsigned short* hp = (unsigned short*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]);
-                        const unsigned int ww[2] = {w[0], w[1]};
+                        const unsigned int ww[2] = {wl[nt], wh[nt]};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             if (co0 + j < dC) hp[j] = (unsigned short)(ww[j >> 1] >> ((j & 1) * 16));
+                    }
+                }
+                if (pair_ok) {
+                    // (A, B) = (pixel 0, pixel 2) and (C, D) = (pixel 1, pixel 3): after the swaps an even group holds {own, partner's}
+                    // halves of pixels 0 and 1, an odd group {partner's, own} halves of pixels 2 and 3
+                    unsigned int a0 = wl[0], a1 = wh[0], b0 = wl[2 % NT], b1 = wh[2 % NT];
+                    unsigned int c0 = wl[1 % NT], c1 = wh[1 % NT], e0 = wl[3 % NT], e1 = wh[3 % NT];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\t"
+                                 "v_permlane16_swap_b32 %4, %6\n\tv_permlane16_swap_b32 %5, %7\n\ts_nop 1"
+                                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(e0), "+v"(e1));
+                    const int pA = (q & 1) ? opix[2 % NT] : opix[0], pB = (q & 1) ? opix[3 % NT] : opix[1 % NT];
+                    const int cbase = a.dst_coff + (co0 & ~4);
+                    if (pA >= 0) {
+                        const u32x4 w = {a0, a1, b0, b1};
+                        *(u32x4*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, cbase, OHW, pA) = w;
+                    }
+                    if (pB >= 0) {
+                        const u32x4 w = {c0, c1, e0, e1};
+                        *(u32x4*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, cbase, OHW, pB) = w;
                     }
                 }
                 if (DZ && a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
