@@ -96,13 +96,15 @@ typedef struct jaf_conv_plan {
     int32_t pf;                 /* reserved */
 } jaf_conv_plan;
 
-enum { JAF_PACK_FWD = 0, JAF_PACK_DGRAD = 1, JAF_PACK_LSTM = 2 };
+enum { JAF_PACK_FWD = 0, JAF_PACK_DGRAD = 1, JAF_PACK_LSTM = 2, JAF_PACK_DGRAD_LSTM = 3 };
 
 int jaf_conv2d_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 
 /* Re-lays a weight tensor out in the LDS image order of the plan ([G][mblock][chunk][tap][c][row]).
  * JAF_PACK_FWD: rows = Cout.  JAF_PACK_LSTM: rows = 4*hidden, gate-interleaved so that one
  * accumulator tile holds i,f,o,g of a channel (src/convLSTM.py:46 split order i,f,o,g).
+ * JAF_PACK_DGRAD_LSTM (bf16 plans): JAF_PACK_DGRAD for the ConvLSTM's gate gradients as jaf_convlstm_gates_bwd_packed
+ * writes them, channel-major (reduction channel 4*c + gate reads weight row gate*hidden + c).
  * JAF_PACK_DGRAD: rows = forward input channels [w_cin_off, +Cout of the dgrad desc), reduction
  * over forward output channels, taps flipped (the transposed convolution).                     */
 int jaf_conv2d_pack(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode,
@@ -158,7 +160,9 @@ int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const
                           int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                           void* packed, float* dz, float* dbias);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
- * [N][G][4C/8][H*W][8] (order i,f,o,g per group) and their per-channel sums ADDED to dbias[G*4C];
+ * [N][G][4C/8][H*W][8], CHANNEL-MAJOR: packed channel 4*c + gate (one item = 2 hidden channels x i,f,o,g; its consumers:
+ * jaf_conv2d_pack(JAF_PACK_DGRAD_LSTM) + jaf_conv2d_fwd_packed_io for d[x, h], jaf_conv2d_wgrad_packed_lstm for dW), and
+ * their per-channel sums ADDED to dbias[G*4C] (reference order gate*C + c);
  * `gates` (as the forward cell wrote them: fp32 planes [N][G][gate][C][H*W], or bf16 gate-innermost
  * [N][G][C][H*W][i, f, o, g] from jaf_convlstm_cell_fwd_packed*) is read-only here.  JAF_EUNSUPPORTED when C % 4 != 0. */
 int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
@@ -242,6 +246,10 @@ int jaf_conv2d_wgrad_packed(jaf_stream_t s, const jaf_conv_desc* d, const void* 
 /* Same with packed_x an image of x_ng8_tot >= ceil(Cin/8) planes per (image, group) (see jaf_packed_io). */
 int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
                                const void* packed_dz, float* dw, int accumulate);
+/* The same for the ConvLSTM's weight gradient, with packed_dz = the gate gradients as jaf_convlstm_gates_bwd_packed writes
+ * them (channel 4*c + gate): row gate*hidden + c of dW receives channel 4*c + gate (hidden = 0: jaf_conv2d_wgrad_packed_ex). */
+int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
+                                 const void* packed_dz, float* dw, int accumulate, int32_t hidden);
 
 /* dW[G][Cout][w_cin_tot][KH][KW] (+)= sum over n,pixels of dz * input patch; dz is laid out as
  * the forward output (out_ctot/out_coff).  accumulate=0 zeroes the touched slice first.        */

@@ -87,7 +87,7 @@ class PackedIO(ctypes.Structure):
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
-PACK_FWD, PACK_DGRAD, PACK_LSTM = 0, 1, 2
+PACK_FWD, PACK_DGRAD, PACK_LSTM, PACK_DGRAD_LSTM = 0, 1, 2, 3
 PREC_F32, PREC_BF16, PREC_BF16X3 = 0, 1, 2
 
 _LIB = None

@@ -476,6 +476,7 @@ struct PackBArgs {
     int G, M, Cred, taps, NG, ng_last, MT, nsteps, nchunks, mblocks, nimg;
     long sg, srow, sch, base;
     int flip, lstmC;
+    int redC;              // JAF_PACK_DGRAD_LSTM: reduction channel 4 c + gate -> weight row gate * redC + c
 };
 
 __global__ void conv_pack_bf16_kernel(const PackBArgs a) {
@@ -500,8 +501,9 @@ __global__ void conv_pack_bf16_kernel(const PackBArgs a) {
             if (r < a.M && ch < a.Cred) {
                 int srow = r;
                 if (a.lstmC > 0) srow = (r & 3) * a.lstmC + (r >> 2);
+                const int chs = a.redC > 0 ? (ch & 3) * a.redC + (ch >> 2) : ch;
                 const int stap = a.flip ? (a.taps - 1 - tap) : tap;
-                v = a.w[a.base + g * a.sg + srow * a.srow + ch * a.sch + stap];
+                v = a.w[a.base + g * a.sg + srow * a.srow + chs * a.sch + stap];
             }
         }
         __bf16 h = (__bf16)v;
@@ -547,8 +549,9 @@ __global__ void conv_pack_bf16_batch_kernel(const PackBArgs* __restrict__ table)
             if (r < a.M && ch < a.Cred) {
                 int srow = r;
                 if (a.lstmC > 0) srow = (r & 3) * a.lstmC + (r >> 2);
+                const int chs = a.redC > 0 ? (ch & 3) * a.redC + (ch >> 2) : ch;
                 const int stap = a.flip ? (a.taps - 1 - tap) : tap;
-                v = a.w[a.base + g * a.sg + srow * a.srow + ch * a.sch + stap];
+                v = a.w[a.base + g * a.sg + srow * a.srow + chs * a.sch + stap];
             }
         }
         __bf16 h = (__bf16)v;
@@ -603,6 +606,7 @@ static int jafb_pack_args(const jaf_conv_desc* d, const jaf_conv_plan* plan, int
     a.total = plan->packed_floats * 2;
     a.flip = 0;
     a.lstmC = 0;
+    a.redC = 0;
     const long khw = a.taps;
     if (mode == JAF_PACK_FWD || mode == JAF_PACK_LSTM) {
         JAF_REQUIRE(w_rows_tot >= d->Cout && d->w_cin_off + d->Cin <= d->w_cin_tot);
@@ -611,8 +615,9 @@ static int jafb_pack_args(const jaf_conv_desc* d, const jaf_conv_plan* plan, int
         a.sch = khw;
         a.base = (long)d->w_cin_off * khw;
         if (mode == JAF_PACK_LSTM) { JAF_REQUIRE((d->Cout & 3) == 0); a.lstmC = d->Cout >> 2; }
-    } else if (mode == JAF_PACK_DGRAD) {
+    } else if (mode == JAF_PACK_DGRAD || mode == JAF_PACK_DGRAD_LSTM) {
         JAF_REQUIRE(w_rows_tot >= d->Cin && d->w_cin_off + d->Cout <= d->w_cin_tot);
+        if (mode == JAF_PACK_DGRAD_LSTM) { JAF_REQUIRE((d->Cin & 3) == 0 && d->precision == JAF_PREC_BF16); a.redC = d->Cin >> 2; }
         a.sg = (long)w_rows_tot * d->w_cin_tot * khw;
         a.srow = khw;
         a.sch = (long)d->w_cin_tot * khw;

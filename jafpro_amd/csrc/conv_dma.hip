@@ -660,62 +660,64 @@ extern "C" int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const floa
 // ---------------------------------------------------------------------------------------------
 // ConvLSTM gate backward straight into the packed image (src/convLSTM.py:48-54 adjoint): reads the
 // saved gates i,f,o,g, c_{t-1}, c_t, dh, dc_{t+1}; writes dc_{t-1} (fp32), the PRE-activation gate
-// gradients as packed bf16 [n][g][4C/8][y][x][8] for the data / weight gradient kernels, and adds their
+// gradients as a packed bf16 image for the data / weight gradient kernels, and adds their
 // per-channel sums to the bias gradient.  The fp32 gate-gradient tensor (4C channels) is never
 // written, re-read for packing, or re-read for the bias sum.
-// A lane owns 4 consecutive hidden channels x V pixels: its 4 values of one gate are half of a
-// 16-byte packed item (C % 4 == 0 puts every gate's channel block on a 4-channel boundary).
-// grid (pixel blocks, C/4, N*G), block 256.
+//
+// The packed gate gradients are CHANNEL-MAJOR: packed channel 4 c + gate, so that one 16-byte item = 2 hidden channels x
+// (i, f, o, g).  A lane then owns 2 hidden channels x V pixels and everything it touches is whole: 16-byte loads of the five
+// fp32 planes and of the (gate-innermost) saved gates at V = 4, one 16-byte item store per pixel.  (Rounds 1-3 kept the
+// gradients gate-major, gate * C + c: a whole item then needs 8 -- or, at C = 12, all 12 -- hidden channels in one lane, which
+// left room for only 2 pixels, i.e. 8-byte accesses on every fp32 plane: 5.0 TB/s.)  The consumers follow the order:
+// jaf_conv2d_pack(JAF_PACK_DGRAD_LSTM) permutes the reduction channels of the data gradient's weight image,
+// jaf_conv2d_wgrad_packed_lstm the rows of dW.
+// grid (pixel blocks, C/2, N*G), block 256.
 // ---------------------------------------------------------------------------------------------
 template <int V, typename GT>
-__global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, int HW, const float* dh, const float* dc_next,
-                                                                   const GT* gates, const float* c_prev, const float* c_cur,
-                                                                   float* dc_prev, unsigned char* packed, float* dbias, int iters) {
-    typedef float fv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
-    const int cb = blockIdx.y * 4;                 // first hidden channel of this lane's block
+__global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C, int HW, const float* __restrict__ dh,
+                                                                    const float* __restrict__ dc_next, const GT* __restrict__ gates,
+                                                                    const float* __restrict__ c_prev, const float* __restrict__ c_cur,
+                                                                    float* __restrict__ dc_prev, unsigned char* __restrict__ packed,
+                                                                    float* __restrict__ dbias, int iters) {
+    const int kp = blockIdx.y;                     // hidden-channel pair 2 kp, 2 kp + 1 = item kp of every pixel
     const long ng = blockIdx.z;
     const int g = (int)(ng % G);
-    const int ng8 = (4 * C + 7) >> 3;
+    const int ng8 = C >> 1;
     const long cs = (long)C * HW;
-    float sums[16];
+    __shared__ float red[8];
+    if (threadIdx.x < 8) red[threadIdx.x] = 0.f;
+    __syncthreads();
+    float sums[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sums[k] = 0.f;
+    for (int k = 0; k < 8; ++k) sums[k] = 0.f;
     for (int it = 0; it < iters; ++it) {
-        const int pix = ((blockIdx.x * iters + it) * blockDim.x + threadIdx.x) * V;
-        if (pix >= HW) break;
-        float o[4][4][V];                          // [gate][channel][pixel]
+        const int pix0 = (blockIdx.x * iters + it) * 256 * V;          // workgroup-uniform
+        if (pix0 >= HW) break;
+        const int pix = pix0 + threadIdx.x * V;
+        if (pix >= HW) continue;
+        float o[4][2][V];                                               // [gate][channel of the pair][pixel]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = cb + j;
+        for (int h = 0; h < 2; ++h) {
+            const int c = 2 * kp + h;
             const long e = (ng * C + c) * (long)HW + pix;
-            const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
             float gi[V], gf[V], go[V], gg[V], cc[V], dhv[V], dcn[V], cp[V];
-            if constexpr (sizeof(GT) == 2) {
-                // bf16 gates are gate-innermost ([c][pixel][i, f, o, g], written by the cell kernel's epilogue)
-                typedef GT g4 __attribute__((ext_vector_type(4)));
-                const GT* gq = gates + ng * 4 * C * (long)HW + ((long)c * HW + pix) * 4;
+            if constexpr (sizeof(GT) == 2) {                            // saved gates gate-innermost: [c][pixel][i, f, o, g]
+                typedef GT g4v __attribute__((ext_vector_type(4 * V)));
+                const g4v t = *(const g4v*)(gates + ng * 4 * cs + ((long)c * HW + pix) * 4);
 #pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    const g4 t = *(const g4*)(gq + 4 * k);
-                    gi[k] = (float)t[0]; gf[k] = (float)t[1]; go[k] = (float)t[2]; gg[k] = (float)t[3];
-                }
+                for (int k = 0; k < V; ++k) { gi[k] = (float)t[4 * k]; gf[k] = (float)t[4 * k + 1]; go[k] = (float)t[4 * k + 2]; gg[k] = (float)t[4 * k + 3]; }
+            } else {                                                    // fp32 gates: planes [gate][c][pixel]
+                const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
+#pragma unroll
+                for (int k = 0; k < V; ++k) { gi[k] = (float)gp[k]; gf[k] = (float)gp[cs + k]; go[k] = (float)gp[2 * cs + k]; gg[k] = (float)gp[3 * cs + k]; }
             }
-            if (V > 1) {
-                if constexpr (sizeof(GT) != 2) {
-                    typedef GT gv __attribute__((ext_vector_type(V == 1 ? 2 : V)));
-                    const gv ti = *(const gv*)gp, tf = *(const gv*)(gp + cs), to = *(const gv*)(gp + 2 * cs), tg = *(const gv*)(gp + 3 * cs);
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        gi[k] = (float)ti[k]; gf[k] = (float)tf[k]; go[k] = (float)to[k]; gg[k] = (float)tg[k];
-                    }
-                }
-                *(fv*)cc = *(const fv*)(c_cur + e); *(fv*)dhv = *(const fv*)(dh + e);
+            if constexpr (V > 1) {
+                typedef float fv __attribute__((ext_vector_type(V)));
+                *(fv*)cc = *(const fv*)(c_cur + e);
+                *(fv*)dhv = *(const fv*)(dh + e);
                 if (dc_next) *(fv*)dcn = *(const fv*)(dc_next + e);
                 if (c_prev) *(fv*)cp = *(const fv*)(c_prev + e);
             } else {
-                if constexpr (sizeof(GT) != 2) {
-                    gi[0] = (float)gp[0]; gf[0] = (float)gp[cs]; go[0] = (float)gp[2 * cs]; gg[0] = (float)gp[3 * cs];
-                }
                 cc[0] = c_cur[e]; dhv[0] = dh[e];
                 if (dc_next) dcn[0] = dc_next[e];
                 if (c_prev) cp[0] = c_prev[e];
@@ -727,165 +729,43 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_pack_kernel(int G, int C, 
                 float dc = dhv[k] * go[k] * (1.f - tc * tc);
                 if (dc_next) dc += dcn[k];
                 const float cpv = c_prev ? cp[k] : 0.f;
-                o[0][j][k] = dc * gg[k] * gi[k] * (1.f - gi[k]);
-                o[1][j][k] = dc * cpv * gf[k] * (1.f - gf[k]);
-                o[2][j][k] = dhv[k] * tc * go[k] * (1.f - go[k]);
-                o[3][j][k] = dc * gi[k] * (1.f - gg[k] * gg[k]);
+                o[0][h][k] = dc * gg[k] * gi[k] * (1.f - gi[k]);
+                o[1][h][k] = dc * cpv * gf[k] * (1.f - gf[k]);
+                o[2][h][k] = dhv[k] * tc * go[k] * (1.f - go[k]);
+                o[3][h][k] = dc * gi[k] * (1.f - gg[k] * gg[k]);
                 dcp[k] = dc * gf[k];
             }
-            if (V > 1) *(fv*)(dc_prev + e) = *(fv*)dcp;
-            else dc_prev[e] = dcp[0];
-        }
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate) {
-            const int ch = gate * C + cb;              // first of this lane's 4 gate channels (multiple of 4)
-            unsigned char* op = packed + ((ng * ng8 + (ch >> 3)) * (long)HW + pix) * 16 + ((ch >> 2) & 1) * 8;
-#pragma unroll
-            for (int k = 0; k < V; ++k) {
-                unsigned int w0 = cd_pack2(o[gate][0][k], o[gate][1][k]);
-                unsigned int w1 = cd_pack2(o[gate][2][k], o[gate][3][k]);
-                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 w = {w0, w1};
-                *(u32x2*)(op + k * 16) = w;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sums[gate * 4 + j] += o[gate][j][k];
+            if constexpr (V > 1) {
+                typedef float fv __attribute__((ext_vector_type(V)));
+                *(fv*)(dc_prev + e) = *(fv*)dcp;
+            } else {
+                dc_prev[e] = dcp[0];
             }
         }
-    }
-    // bias gradient: 16 gate channels per workgroup
-    __shared__ float red[4][16];
+        unsigned char* op = packed + ((ng * ng8 + kp) * (long)HW + pix) * 16;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sums[k] = jaf_wave_sum(sums[k]);
+        for (int k = 0; k < V; ++k) {
+            u32x4 w;
+            w[0] = cd_pack2(o[0][0][k], o[1][0][k]);
+            w[1] = cd_pack2(o[2][0][k], o[3][0][k]);
+            w[2] = cd_pack2(o[0][1][k], o[1][1][k]);
+            w[3] = cd_pack2(o[2][1][k], o[3][1][k]);
+            *(u32x4*)(op + k * 16) = w;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { sums[2 * a] += o[a][0][k]; sums[2 * a + 1] += o[a][1][k]; }
+        }
+    }
+    // bias gradient: 8 (gate, channel) sums per workgroup
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sums[k] = jaf_wave_sum(sums[k]);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) red[threadIdx.x >> 6][k] = sums[k];
+        for (int k = 0; k < 8; ++k) atomicAdd(&red[k], sums[k]);
     }
     __syncthreads();
-    if (threadIdx.x < 16) {
-        const int gate = threadIdx.x >> 2, j = threadIdx.x & 3;
-        atomicAdd(&dbias[g * 4 * C + gate * C + cb + j],
-                  (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
-    }
-}
-
-// Whole-item variant: a lane owns CB hidden channels x V pixels so that every 16-byte packed item it
-// touches is complete in its own registers (the 4-channel variant above writes 8-byte halves of items
-// whose other half belongs to a different workgroup: partial-line writes, 3.6 TB/s measured).
-//   CB == 8  : C % 8 == 0, channels cb .. cb+7 -> one full item per gate;
-//   CB == 12 : C == 12 (the 200x200 level, the most expensive launch), all 48 gate channels = 6 items.
-// Same arithmetic in the same order as the kernel above: packed image and dc_prev are bit-identical.
-// grid (pixel blocks, C/CB, N*G), block 256.
-template <int V, int CB, typename GT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void lstm_gates_bwd_pack_full_kernel(
-        int G, int C, int HW, const float* __restrict__ dh, const float* __restrict__ dc_next, const GT* __restrict__ gates,
-        const float* __restrict__ c_prev, const float* __restrict__ c_cur, float* __restrict__ dc_prev,
-        unsigned char* __restrict__ packed, float* __restrict__ dbias, int iters) {
-    typedef float fv __attribute__((ext_vector_type(V)));
-    typedef GT gv __attribute__((ext_vector_type(V)));
-    const int cb = blockIdx.y * CB;
-    const long ng = blockIdx.z;
-    const int g = (int)(ng % G);
-    const int ng8 = (4 * C) >> 3;
-    const long cs = (long)C * HW;
-    // bias gradient: every channel pair's 8 per-lane sums are wave-reduced at once and added to LDS by
-    // lane 0 (4*CB running sums per lane would cost 48 registers and the occupancy with them)
-    __shared__ float red[4 * CB];
-    if (threadIdx.x < 4 * CB) red[threadIdx.x] = 0.f;
-    __syncthreads();
-    for (int it = 0; it < iters; ++it) {
-        const int pix0 = (blockIdx.x * iters + it) * blockDim.x * V;      // workgroup-uniform
-        if (pix0 >= HW) break;
-        const int pix = pix0 + threadIdx.x * V;
-        const bool live = pix < HW;
-        unsigned int wp[4][CB / 2][V];             // [gate][channel pair][pixel] bf16x2
-#pragma unroll
-        for (int j2 = 0; j2 < CB / 2; ++j2) {
-            float o[4][2][V];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int k = 0; k < V; ++k) o[a][h][k] = 0.f;
-                if (live) {
-                    const int c = cb + 2 * j2 + h;
-                    const long e = (ng * C + c) * (long)HW + pix;
-                    gv ti, tf, to, tg;
-                    if constexpr (sizeof(GT) == 2) {          // gate-innermost bf16: V pixels x 4 gates in one load
-                        typedef GT g4v __attribute__((ext_vector_type(4 * V)));
-                        const g4v t = *(const g4v*)(gates + ng * 4 * C * (long)HW + ((long)c * HW + pix) * 4);
-#pragma unroll
-                        for (int k = 0; k < V; ++k) { ti[k] = t[4 * k]; tf[k] = t[4 * k + 1]; to[k] = t[4 * k + 2]; tg[k] = t[4 * k + 3]; }
-                    } else {
-                        const GT* gp = gates + (ng * 4 * C + c) * (long)HW + pix;
-                        ti = *(const gv*)gp; tf = *(const gv*)(gp + cs); to = *(const gv*)(gp + 2 * cs); tg = *(const gv*)(gp + 3 * cs);
-                    }
-                    const fv cc = *(const fv*)(c_cur + e), dhv = *(const fv*)(dh + e);
-                    fv dcn, cp;
-                    if (dc_next) dcn = *(const fv*)(dc_next + e);
-                    if (c_prev) cp = *(const fv*)(c_prev + e);
-                    fv dcp;
-#pragma unroll
-                    for (int k = 0; k < V; ++k) {
-                        const float gi = (float)ti[k], gf = (float)tf[k], go = (float)to[k], gg = (float)tg[k];
-                        const float tc = jaf_tanh(cc[k]);
-                        float dc = dhv[k] * go * (1.f - tc * tc);
-                        if (dc_next) dc += dcn[k];
-                        const float cpv = c_prev ? cp[k] : 0.f;
-                        o[0][h][k] = dc * gg * gi * (1.f - gi);
-                        o[1][h][k] = dc * cpv * gf * (1.f - gf);
-                        o[2][h][k] = dhv[k] * tc * go * (1.f - go);
-                        o[3][h][k] = dc * gi * (1.f - gg * gg);
-                        dcp[k] = dc * gf;
-                    }
-                    *(fv*)(dc_prev + e) = dcp;
-                }
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    wp[a][j2][k] = cd_pack2(o[a][0][k], o[a][1][k]);
-                    s0 += o[a][0][k];
-                    s1 += o[a][1][k];
-                }
-                s0 = jaf_wave_sum(s0);
-                s1 = jaf_wave_sum(s1);
-                if ((threadIdx.x & 63) == 0) {
-                    atomicAdd(&red[a * CB + 2 * j2], s0);
-                    atomicAdd(&red[a * CB + 2 * j2 + 1], s1);
-                }
-            }
-        }
-        // items: packed channel pc = gate*C + cb + j; the lane's channels of all gates, in ascending pc,
-        // form whole 8-channel items (CB == 8: one per gate; CB == 12 == C: the 48 channels back to back)
-        if (live) {
-            constexpr int NITEM = 4 * CB / 8;
-#pragma unroll
-            for (int i = 0; i < NITEM; ++i) {
-                unsigned char* op;
-                if (CB == 8) op = packed + ((ng * ng8 + ((i * C + cb) >> 3)) * (long)HW + pix) * 16;
-                else op = packed + ((ng * ng8 + i) * (long)HW + pix) * 16;
-#pragma unroll
-                for (int k = 0; k < V; ++k) {
-                    u32x4 w;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int qn = i * 4 + u;      // pair number in ascending pc order
-                        const int gate = (CB == 8) ? i : qn / (CB / 2);
-                        const int pr = (CB == 8) ? u : qn % (CB / 2);
-                        w[u] = wp[gate][pr][k];
-                    }
-                    *(u32x4*)(op + k * 16) = w;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < 4 * CB) {
-        const int gate = threadIdx.x / CB, j = threadIdx.x % CB;
-        atomicAdd(&dbias[g * 4 * C + gate * C + cb + j], red[threadIdx.x]);
+    if (threadIdx.x < 8) {
+        const int gate = threadIdx.x >> 1, h = threadIdx.x & 1;
+        atomicAdd(&dbias[g * 4 * C + gate * C + 2 * kp + h], red[threadIdx.x]);
     }
 }
 
@@ -894,37 +774,22 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
                                              const float* c_cur, float* dc_prev, void* packed, float* dbias) {
     JAF_REQUIRE(dh && gates && c_cur && dc_prev && packed && dbias && N >= 1 && G >= 1 && C >= 4 && HW >= 1);
     if (C % 4) return JAF_EUNSUPPORTED;
-    JAF_REQUIRE(C / 4 <= 65535 && (long)N * G <= 65535);
+    JAF_REQUIRE(C / 2 <= 65535 && (long)N * G <= 65535);
     const uintptr_t al = ((uintptr_t)dh) | ((uintptr_t)gates) | ((uintptr_t)c_cur) | ((uintptr_t)dc_prev) |
                          ((uintptr_t)dc_next) | ((uintptr_t)c_prev);
     const bool v4 = (HW % 4 == 0) && (al & 15) == 0;
     const bool v2 = (HW % 2 == 0) && (al & 7) == 0;
     const int V = v4 ? 4 : (v2 ? 2 : 1);
-    const int CBF = (C == 12) ? 12 : ((C % 8 == 0) ? 8 : 0);
-    if (CBF && v2) {
-        // whole-item kernel, 2 pixels per lane (4 per lane does not fit 128 registers)
-        const int per_block = 256 * 2;
-        int iters = 8;
-        while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
-        const dim3 grid(jaf_cdiv(HW, per_block * iters), C / CBF, N * G);
-#define JAF_LGF(CB_, T_)                                                                                        \
-    hipLaunchKernelGGL((lstm_gates_bwd_pack_full_kernel<2, CB_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
-                       (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters)
-        if (gates_bf16) { if (CBF == 12) JAF_LGF(12, __bf16); else JAF_LGF(8, __bf16); }
-        else { if (CBF == 12) JAF_LGF(12, float); else JAF_LGF(8, float); }
-#undef JAF_LGF
-        return jaf_launch_status();
-    }
     const int per_block = 256 * V;
     int iters = 8;
     while (iters > 1 && (long)per_block * (iters / 2) >= HW) iters /= 2;
-    const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 4, N * G);
-#define JAF_LGB(V_, T_)                                                                                         \
-    hipLaunchKernelGGL((lstm_gates_bwd_pack_kernel<V_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
+    const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 2, N * G);
+#define JAF_LGC(V_, T_)                                                                                          \
+    hipLaunchKernelGGL((lstm_gates_bwd_cmajor_kernel<V_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
                        (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters)
-    if (gates_bf16) { if (v4) JAF_LGB(4, __bf16); else if (v2) JAF_LGB(2, __bf16); else JAF_LGB(1, __bf16); }
-    else { if (v4) JAF_LGB(4, float); else if (v2) JAF_LGB(2, float); else JAF_LGB(1, float); }
-#undef JAF_LGB
+    if (gates_bf16) { if (v4) JAF_LGC(4, __bf16); else if (v2) JAF_LGC(2, __bf16); else JAF_LGC(1, __bf16); }
+    else { if (v4) JAF_LGC(4, float); else if (v2) JAF_LGC(2, float); else JAF_LGC(1, float); }
+#undef JAF_LGC
     return jaf_launch_status();
 }
 

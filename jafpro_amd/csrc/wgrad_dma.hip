@@ -44,6 +44,7 @@ struct WgDArgs {
     int ngin8, ngout8;
     int xng8;              // planes per (image, group) of the packed input image (>= ngin8)
     float inv_pwp;
+    int lstmC;             // > 0: dz channels are the ConvLSTM's gate gradients, channel-major (4 c + gate): dW row gate * lstmC + c
 };
 
 // PAIR (Cin <= 8, i.e. one packed item per position): the 16 columns of an MFMA are TWO taps x 8 channels instead of one
@@ -291,7 +292,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 const int rem = e - row * 144;
                 const int co = co0 + mt * 16 + row;
                 if (co < d.Cout && rem < nrem) {
-                    float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
+                    const int cod = a.lstmC > 0 ? (co & 3) * a.lstmC + (co >> 2) : co;
+                    float* p = a.dw + (((long)(g * d.Cout + cod) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
                     atomicAdd(p, s_ep[row * WD_EP + rem]);
                 }
             }
@@ -368,7 +370,13 @@ extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, 
 
 extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
                                           const void* packed_dz, float* dw, int accumulate) {
+    return jaf_conv2d_wgrad_packed_lstm(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, 0);
+}
+
+extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
+                                            const void* packed_dz, float* dw, int accumulate, int32_t hidden) {
     JAF_REQUIRE(d && packed_x && packed_dz && dw);
+    JAF_REQUIRE(hidden == 0 || (hidden > 0 && d->KH == 3 && d->Cout == 4 * hidden));
     JAF_REQUIRE(x_ng8_tot == 0 || x_ng8_tot >= jaf_cdiv(d->Cin, 8));
     JAF_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5) && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
     const int KS = d->KH;
@@ -383,6 +391,7 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     a.dzp = (const unsigned char*)packed_dz;
     a.dw = dw;
     a.d = *d;
+    a.lstmC = hidden;
     int MTW = 1;
     long bestPad = 1L << 60;
     for (int mt = (KS == 5 ? 1 : 4); mt >= 1; --mt) {

@@ -16,7 +16,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch.autograd import Function
 
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DGRAD, PACK_FWD,
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DGRAD, PACK_DGRAD_LSTM, PACK_FWD,
                    PACK_LSTM, PREC_BF16, PREC_BF16X3, PREC_F32, ConvDesc, ConvPlan, PackedIO, check, lib)
 
 __all__ = ["set_precision", "get_precision", "conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
@@ -1297,8 +1297,9 @@ class _ConvLSTMFn(Function):
                     wst.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(wst if wst is not None else torch.cuda.current_stream()):
                     ev = _PROF.begin() if _PROF is not None else None
-                    check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
-                                                       1 if w_inplace else acc), "jaf_conv2d_wgrad_packed_ex")
+                    # (the packed gate gradients are channel-major, 4 c + gate: the kernel permutes the rows of dW)
+                    check(L.jaf_conv2d_wgrad_packed_lstm(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
+                                                         1 if w_inplace else acc, C), "jaf_conv2d_wgrad_packed_lstm")
                     if ev is not None:
                         _PROF.end(_wgrad_dma_name(4 * C, 3, Cin, G, N, H, W), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:
@@ -1324,24 +1325,25 @@ class _ConvLSTMFn(Function):
                     _PROF.end(wname, 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
                       "jaf_channel_sum")
+            dmode = PACK_DGRAD_LSTM if fused else PACK_DGRAD       # (fused: gtp is channel-major, see jaf_convlstm_gates_bwd_packed)
             if dx is not None and not first and fused and 2 * C <= _LSTM_FUSED_DGRAD_MAX_ROWS:
                 # d[x_t, h_{t-1}] in one launch: 2C rows per group, the x rows into dx[t], the h rows into dh -- the packed gate
                 # gradients (4C channels) are read once instead of twice
                 dh = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
                 fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
                                                     dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
-                _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, 2 * C, H, W, H, W, 3, 3, 1, 1, 1,
+                _, gtp = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, 2 * C, H, W, H, W, 3, 3, 1, 1, 1,
                                    1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=2 * GC, out_coff=0, xp=gtp, want_xp=True,
                                    accumulate=dx_first is not None, out2=dh, split=C, **(fz or {}))
             else:
                 if dx is not None:
                     fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
                                                         dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
-                    _, gtp = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
+                    _, gtp = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                        1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True,
                                        accumulate=dx_first is not None, **(fz or {}))
                 if not first:
-                    dh = _conv_raw([gt], gspec, weight, 4 * C, PACK_DGRAD, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
+                    dh = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                    1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
             dc = dc_prev
         dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None

@@ -580,8 +580,8 @@ def test_convlstm_h_in_packed_image(T, N, G, C, H, W):
                                              (4, 6, 6, True, False), (12, 20, 20, False, False)])
 def test_lstm_gates_bwd_packed_direct(C, H, W, g16, first):
     """jaf_convlstm_gates_bwd_packed (src/convLSTM.py:48-54 adjoint) against the closed form: dc_prev,
-    the packed bf16 pre-activation gate gradients [n][g][4C/8][px][8] and the bias gradient.  Covers the
-    whole-item kernels (C == 12, C % 8 == 0 at even H*W) and the 4-channel fallback (odd H*W, C == 4)."""
+    the packed bf16 pre-activation gate gradients [n][g][4C/8][px][8] (channel 4 c + gate) and the bias gradient.  Covers 4,
+    2 and 1 pixels per lane (H*W % 4 == 0, even, odd)."""
     import ctypes
     ops = _ops()
     from jafpro_amd._lib import lib
@@ -611,7 +611,8 @@ def test_lstm_gates_bwd_packed_direct(C, H, W, g16, first):
     assert rc == 0
     torch.cuda.synchronize()
     assert maxerr(dcp.reshape(N, G, C, H, W), dcp_ref) <= 2e-6
-    got = packed.float().cpu().reshape(N, G, ng8, HW, 8).permute(0, 1, 2, 4, 3).reshape(N, G, 4, C, H, W)
+    # packed channels are channel-major: 4 * c + gate (one 16-byte item = 2 hidden channels x i, f, o, g)
+    got = packed.float().cpu().reshape(N, G, ng8, HW, 8).permute(0, 1, 2, 4, 3).reshape(N, G, C, 4, H, W).permute(0, 1, 3, 2, 4, 5)
     # bf16 rounding of values up to ~1: half an ulp is 2^-9 relative
     assert (got - dgates).abs().max().item() <= 2.0 ** -8 * max(1.0, dgates.abs().max().item())
     assert maxerr(db, db_ref) <= 1e-4 * max(1.0, db_ref.abs().max().item())
