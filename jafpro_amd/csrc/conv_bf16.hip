@@ -479,36 +479,61 @@ struct PackBArgs {
     int redC;              // JAF_PACK_DGRAD_LSTM: reduction channel 4 c + gate -> weight row gate * redC + c
 };
 
-__global__ void conv_pack_bf16_kernel(const PackBArgs a) {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.total; e += (long)gridDim.x * blockDim.x) {
-        long t = e;
-        const int j = (int)(t & 7); t >>= 3;
-        const int row = (int)(t & 15); t >>= 4;
-        const int q = (int)(t & 3); t >>= 2;
-        const int mt = (int)(t % a.MT); t /= a.MT;
-        const int st = (int)(t % a.nsteps); t /= a.nsteps;
-        const int img = (int)(t % a.nimg); t /= a.nimg;
-        const int chunk = (int)(t % a.nchunks); t /= a.nchunks;
-        const int mb = (int)(t % a.mblocks); t /= a.mblocks;
-        const int g = (int)t;
-        const int ngc = (chunk == a.nchunks - 1) ? a.ng_last : a.NG;
-        const int s = 4 * st + q;
-        float v = 0.f;
-        if (s < a.taps * ngc) {
-            const int tap = s / ngc, grp = s - tap * ngc;
-            const int ch = (chunk * a.NG + grp) * 8 + j;
-            const int r = mb * 16 * a.MT + mt * 16 + row;
-            if (r < a.M && ch < a.Cred) {
-                int srow = r;
-                if (a.lstmC > 0) srow = (r & 3) * a.lstmC + (r >> 2);
+// One 16-byte item (8 reduction channels of one (k-step, k-group, row)) per thread: the index decode -- eight integer
+// divisions -- is paid once per item instead of once per element (element-wise the re-packing of a module's images after its
+// optimiser step ran at 0.3 TB/s: 0.9 ms per train step).
+__device__ __forceinline__ void jafb_pack_item8(const PackBArgs& a, long item) {
+    long t = item;
+    const int row = (int)(t & 15); t >>= 4;
+    const int q = (int)(t & 3); t >>= 2;
+    const int mt = (int)(t % a.MT); t /= a.MT;
+    const int st = (int)(t % a.nsteps); t /= a.nsteps;
+    const int img = (int)(t % a.nimg); t /= a.nimg;
+    const int chunk = (int)(t % a.nchunks); t /= a.nchunks;
+    const int mb = (int)(t % a.mblocks); t /= a.mblocks;
+    const int g = (int)t;
+    const int ngc = (chunk == a.nchunks - 1) ? a.ng_last : a.NG;
+    const int s = 4 * st + q;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    const int r = mb * 16 * a.MT + mt * 16 + row;
+    if (s < a.taps * ngc && r < a.M) {
+        const int tap = s / ngc, grp = s - tap * ngc;
+        int srow = r;
+        if (a.lstmC > 0) srow = (r & 3) * a.lstmC + (r >> 2);
+        const int stap = a.flip ? (a.taps - 1 - tap) : tap;
+        const float* wp = a.w + a.base + g * a.sg + srow * a.srow + stap;
+        const int ch0 = (chunk * a.NG + grp) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = ch0 + j;
+            if (ch < a.Cred) {
                 const int chs = a.redC > 0 ? (ch & 3) * a.redC + (ch >> 2) : ch;
-                const int stap = a.flip ? (a.taps - 1 - tap) : tap;
-                v = a.w[a.base + g * a.sg + srow * a.srow + chs * a.sch + stap];
+                v[j] = wp[chs * a.sch];
             }
         }
-        __bf16 h = (__bf16)v;
-        if (img == 1) h = (__bf16)(v - (float)h);
-        a.out[e] = __builtin_bit_cast(unsigned short, h);
+    }
+    typedef unsigned int pk_u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    pk_u32x4 w;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float x0 = v[2 * u], x1 = v[2 * u + 1];
+        if (img == 1) {          // residual image of the split-bf16 mode: v - bf16(v)
+            x0 = x0 - (float)(__bf16)x0;
+            x1 = x1 - (float)(__bf16)x1;
+        }
+        const pk_f32x2 p2 = {x0, x1};
+        w[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, pk_bf16x2));
+    }
+    *(pk_u32x4*)(a.out + item * 8) = w;
+}
+
+__global__ void conv_pack_bf16_kernel(const PackBArgs a) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (a.total >> 3); e += (long)gridDim.x * blockDim.x) {
+        jafb_pack_item8(a, e);
     }
 }
 
@@ -520,7 +545,7 @@ int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, 
     PackBArgs a;
     const int e = jafb_pack_args(d, plan, mode, w, w_rows_tot, packed, a);
     if (e) return e;
-    hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(jaf_ew_grid(a.total)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(conv_pack_bf16_kernel, dim3(jaf_ew_grid(a.total >> 3)), dim3(256), 0, s, a);
     return jaf_launch_status();
 }
 
@@ -528,35 +553,8 @@ int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, 
 // the image's argument block out of a device-resident table.
 __global__ void conv_pack_bf16_batch_kernel(const PackBArgs* __restrict__ table) {
     const PackBArgs a = table[blockIdx.y];
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < a.total; e += (long)gridDim.x * blockDim.x) {
-        long t = e;
-        const int j = (int)(t & 7); t >>= 3;
-        const int row = (int)(t & 15); t >>= 4;
-        const int q = (int)(t & 3); t >>= 2;
-        const int mt = (int)(t % a.MT); t /= a.MT;
-        const int st = (int)(t % a.nsteps); t /= a.nsteps;
-        const int img = (int)(t % a.nimg); t /= a.nimg;
-        const int chunk = (int)(t % a.nchunks); t /= a.nchunks;
-        const int mb = (int)(t % a.mblocks); t /= a.mblocks;
-        const int g = (int)t;
-        const int ngc = (chunk == a.nchunks - 1) ? a.ng_last : a.NG;
-        const int s = 4 * st + q;
-        float v = 0.f;
-        if (s < a.taps * ngc) {
-            const int tap = s / ngc, grp = s - tap * ngc;
-            const int ch = (chunk * a.NG + grp) * 8 + j;
-            const int r = mb * 16 * a.MT + mt * 16 + row;
-            if (r < a.M && ch < a.Cred) {
-                int srow = r;
-                if (a.lstmC > 0) srow = (r & 3) * a.lstmC + (r >> 2);
-                const int chs = a.redC > 0 ? (ch & 3) * a.redC + (ch >> 2) : ch;
-                const int stap = a.flip ? (a.taps - 1 - tap) : tap;
-                v = a.w[a.base + g * a.sg + srow * a.srow + chs * a.sch + stap];
-            }
-        }
-        __bf16 h = (__bf16)v;
-        if (img == 1) h = (__bf16)(v - (float)h);
-        a.out[e] = __builtin_bit_cast(unsigned short, h);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (a.total >> 3); e += (long)gridDim.x * blockDim.x) {
+        jafb_pack_item8(a, e);
     }
 }
 
