@@ -10,7 +10,7 @@
 //
 // In the kernel a patch plane is filled by 16-byte-per-lane buffer loads that land directly in LDS:
 // lane l of round r supplies slot 64*r + l, its source offset (or an out-of-range offset for
-// padding, which the buffer unit turns into zeros -- measured, scratch/t/dma_test.hip) is chunk
+// padding, which the buffer unit turns into zeros -- measured, profiles/experiments/dma_test.hip) is chunk
 // invariant, and the plane (wave-uniform) is a scalar buffer resource.  Per 32-channel chunk a wave
 // issues <= 8 patch DMAs and <= 3 weight DMAs and no VALU staging work at all; the previous
 // kernel spent ~800 of its ~1100 instructions per chunk there.
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         // ONE pixel = 8 contiguous bytes of its packed item: 1 store instead of 4 two-byte ones (12 -> 3 per lane).
                         // From assembly and from scalar copies of h: fed with elements of the float4 `vh`, this compiler passed ONE
                         // register as all four operands (builtins and assembly alike; the sequence itself is verified in
-                        // scratch/t/swap_test*.hip).
+                        // profiles/experiments/swap_test*.hip).
                         unsigned t0 = __builtin_bit_cast(unsigned, hs4[0]), t1 = __builtin_bit_cast(unsigned, hs4[1]);
                         unsigned t2 = __builtin_bit_cast(unsigned, hs4[2]), t3 = __builtin_bit_cast(unsigned, hs4[3]);
                         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
