@@ -101,13 +101,14 @@ def _stage4_oracle():
     return OracleStage4(sds, fidx)
 
 
-def case_stage4(seed, B, used=(0, 1, 2, 3), prosrc=0, steps=1, params=False):
-    """One (or two consecutive) single-process train steps."""
+def case_stage4(seed, B, used=(0, 1, 2, 3), prosrc=0, steps=1, params=False, S=256):
+    """One (or two consecutive) single-process train steps.  S=512: BASELINE config 5 geometry as oracle/step_oracle.py
+    defines it (its header: the reference itself is 256-only)."""
     from jafpro_amd import synth
     orc = _stage4_oracle()
-    b = _host(synth.stage4_batch(seed, B))
+    b = _host(synth.stage4_batch(seed, B, S=S))
     out = {"meta.seed": np.int64(seed), "meta.B": np.int64(B), "meta.used": np.array(used, np.int64),
-           "meta.prosrc": np.int64(prosrc)}
+           "meta.prosrc": np.int64(prosrc), "meta.S": np.int64(S)}
     r = orc.train_step(b, used=used, prosrc=prosrc)
     out["final_output"] = r["final_output"].numpy().astype(np.float32)
     out["losses"] = _losses(r)
@@ -124,16 +125,16 @@ def case_stage4(seed, B, used=(0, 1, 2, 3), prosrc=0, steps=1, params=False):
     return out
 
 
-def case_forward(seed=300, B=1):
-    """generator_forward of the initial weights (BASELINE config 2 chain for one target frame)."""
+def case_forward(seed=300, B=1, S=256):
+    """generator_forward of the initial weights (BASELINE config 2 chain for one target frame; S=512: config 5 geometry)."""
     from jafpro_amd import synth
     orc = _stage4_oracle()
     with torch.no_grad():
-        r = orc.generator_forward(_host(synth.stage4_batch(seed, B)), (0, 1, 2, 3), 0)
-    out = {"meta.seed": np.int64(seed), "meta.B": np.int64(B)}
+        r = orc.generator_forward(_host(synth.stage4_batch(seed, B, S=S)), (0, 1, 2, 3), 0)
+    out = {"meta.seed": np.int64(seed), "meta.B": np.int64(B), "meta.S": np.int64(S)}
     for k in FWD_KEYS:
         a = r[k].numpy().astype(np.float32)
-        if a.size <= 3 * 256 * 256 * B:
+        if a.size <= 3 * 256 * 256 * B or k == "final_output":
             out["fwd." + k] = a                                   # frames: whole
         else:
             out["fwd." + k + ".strided"] = SD.strided(a, 65536)   # the 24-part tensors (11.5 MB each): strided samples
@@ -235,6 +236,8 @@ CASES = {
     "ranks2_s340": lambda: case_ranks(340, 2, (0, 1, 2, 3), 1, -1),
     "ranks2_s340_drop1": lambda: case_ranks(340, 2, (0, 1, 2, 3), 1, 1),
     "clip_s400": lambda: case_clip(400, 2, 3),
+    "fwd512_s500_b1": lambda: case_forward(500, 1, S=512),
+    "s501_b1_512": lambda: case_stage4(501, 1, S=512),
     "stage12_u0123": lambda: case_stage12((0, 1, 2, 3)),
     "stage12_u20": lambda: case_stage12((2, 0)),
     "stage3_s630_b2": lambda: case_stage3(),

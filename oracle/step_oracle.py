@@ -10,6 +10,12 @@ restated with exactly the F6 patches of SURVEY Appendix C and nothing else:
   * propagater BatchNorm in train mode; background CRN frozen, under no_grad (:319-320),
   * total = loss.sum() + 2*errG + 2*F_errG (:407), Adam lrs of :169-175.
 The random reference subset (:249-261) and the fresh background noise (:231) are inputs.
+
+Frame size: the reference is 256 x 256 only (SMPLRenderer(image_size=256), the image discriminator's Linear,
+src/networks.py:409).  BASELINE config 5 names 512 x 512 frames, which the reference cannot run; for that geometry this
+file applies the SAME restated modules at the frames' own size (every one of them is size-agnostic except that Linear)
+and hands the image discriminator 2x average-pooled images.  That extension is this build's definition of config 5, not
+the reference's: fixtures made at 512 (tests/golden/step_*512*.npz) are "parity unpinned" beyond the per-module pins.
 """
 from __future__ import annotations
 
@@ -47,7 +53,7 @@ class OracleStage4:
     # train/4...py:269-331
     def generator_forward(self, b: Dict[str, torch.Tensor], used: Sequence[int], prosrc: int, align_corners=False, sd=None):
         sd = self.sd if sd is None else sd           # a rank's view: shared parameters, own BatchNorm buffers
-        B = b["src_img"].shape[0]
+        B, S = b["src_img"].shape[0], b["src_img"].shape[-1]      # S: 256 (reference) or 512 (config 5, see the header)
         used = list(used)
         x_in = []
         for i in range(4):
@@ -59,12 +65,12 @@ class OracleStage4:
         inpaint = O.inpaint_forward(sd["inpaint"], masked)
         iuv = b["tgt_IUV255"].numpy()
         warp = torch.stack([O.texture_warp([t[i] for t in inpaint], iuv[i], align_corners) for i in range(B)])
-        refine_output, fg_mask = O.crn_smaller_forward(sd["refine"], warp, 256, True)
+        refine_output, fg_mask = O.crn_smaller_forward(sd["refine"], warp, S, True)
         src0 = b["src_img"][:, 0]
         bg_mask = 1 - b["src_mask_in_image0"]
         bg_incomplete = bg_mask * src0 + (1 - bg_mask) * b["bg_noise"]
         with torch.no_grad():
-            bg_output = O.crn_smaller_forward(sd["bg"], bg_incomplete, 256, False)
+            bg_output = O.crn_smaller_forward(sd["bg"], bg_incomplete, S, False)
         fusion = refine_output * fg_mask.repeat(1, 3, 1, 1) + bg_output * (1 - fg_mask.repeat(1, 3, 1, 1))
         with torch.no_grad():
             # prev_smpl is the SMPL pose of the chosen propagation source, smpl_vertices[:, 1 + random_prosrc] (:263-266)
@@ -75,7 +81,7 @@ class OracleStage4:
                 sv, sc = b["src_verts"], b["src_cam"]
             fs = O.project_faces(sv, sc, self.faces_idx)
             ft = O.project_faces(b["tgt_verts"], b["tgt_cam"], self.faces_idx)
-            fim, wim = raster_oracle.rasterize_fim_wim(ft.numpy(), 256)
+            fim, wim = raster_oracle.rasterize_fim_wim(ft.numpy(), S)
             tsf, _ = O.flow_warp(b["src_img"][:, prosrc], fs, torch.from_numpy(fim), torch.from_numpy(wim), align_corners)
         pro = O.propagation_forward(sd["flow"], {"fake_tgt": fusion, "tsf_image": tsf, "use_mask": True,
                                                       "tgt_smpl_mask": b["smpl_real_mask"], "tgt_IUV": b["tgt_IUV"],
@@ -168,7 +174,10 @@ class OracleStage4:
         for r in R:
             r["fw"] = r["nf"] * N / nf_tot
         FD = lambda r, x: O.discriminator_forward(r["sd"]["face"], x, True, O.FACE_D_CONVS)
-        D = lambda r, x: O.discriminator_forward(r["sd"]["D"], x, True, O.IMAGE_D_CONVS)
+        S = shards[0]["src_img"].shape[-1]
+        assert S in (256, 512), S
+        dview = (lambda x: F.avg_pool2d(x, 2, 2)) if S == 512 else (lambda x: x)          # header: config 5 only
+        D = lambda r, x: O.discriminator_forward(r["sd"]["D"], dview(x), True, O.IMAGE_D_CONVS)
         for r in R:
             if r["nf"] == 0:
                 r["F_errD_real"] = r["F_errD_fake"] = torch.zeros(())
