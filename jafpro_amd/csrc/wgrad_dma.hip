@@ -150,6 +150,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         abase[h] = ((k * 32) ^ ((k & 8) << 4)) + pp * 8;
     }
 
+    // PAIR (one input-channel tile per workgroup, so WK == 4 and a wave's k-step is always ks = wk): the 2 x NACC patch addresses of
+    // the transposed reads do not depend on the tile.  They were recomputed for every tile (146 VALU instructions per 13 MFMAs,
+    // profiles/experiments/round3_pmc_enc1.txt); now two 16-bit offsets per register, made once.
+    unsigned padr[NACC];
+    if constexpr (PAIR) {
+        const int hb = pp >> 1;                  // which tap of the pair this lane's address belongs to
+#pragma unroll
+        for (int pr = 0; pr < NACC; ++pr) {
+            const int tA = 2 * pr, tB = (2 * pr + 1 < NTAP) ? 2 * pr + 1 : 2 * pr;
+            const int ky = hb ? tB / KS : tA / KS, kx = hb ? tB % KS : tA % KS;
+            unsigned v = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c0h = (8 * (q & 1) + 4 * h + qp) * s + kx;
+                const int ad = ((((q >> 1) + 2 * wk) * s + ky) * PWp + c0h) * 32 + (pp & 1) * 8;
+                v |= (unsigned)(ad ^ ((c0h & 8) << 4)) << (16 * h);
+            }
+            padr[pr] = v;
+        }
+    }
+
     f32x4 acc[MTW][NACC];
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
@@ -236,19 +257,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
             }
             if constexpr (PAIR) {
-                const int hb = pp >> 1;                  // which tap of the pair this lane's address belongs to
 #pragma unroll
                 for (int pr = 0; pr < NACC; ++pr) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int tA = 2 * pr, tB = (2 * pr + 1 < NTAP) ? 2 * pr + 1 : 2 * pr;
-                    const int ky = hb ? tB / KS : tA / KS, kx = hb ? tB % KS : tA % KS;
                     s16x4 bb[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int c0h = (8 * (q & 1) + 4 * h + qp) * s + kx;
-                        const int ad = ((((q >> 1) + 2 * ks) * s + ky) * PWp + c0h) * 32 + (pp & 1) * 8;
-                        bb[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + (ad ^ ((c0h & 8) << 4))));
-                    }
+                    bb[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + (padr[pr] & 0xffffu)));
+                    bb[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + (padr[pr] >> 16)));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bb[0], bb[1], 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
@@ -437,6 +450,7 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     const int lds_ep = 4 * 16 * WD_EP * 4;
     if (KS == 3 && lds < lds_ep) lds = lds_ep;
     JAF_REQUIRE(lds <= 160 * 1024);
+    JAF_REQUIRE(!(KS == 5 && d->Cin <= 8) || (a.WK == 4 && a.xplane <= 65536));     // PAIR: see padr in the kernel
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
     const long dw_floats = (long)d->G * d->Cout * d->Cin * KS * KS;
