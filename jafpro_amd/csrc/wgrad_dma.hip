@@ -292,23 +292,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     if constexpr (KS == 3) {
         float* s_ep = (float*)smem + wave * (16 * WD_EP);
         const int nrem = (d.Cin - cit) * 9;
+        __syncthreads();        // every wave is done with the tile buffers; from here on a wave only touches its own staging rows
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            __syncthreads();
+            // (same-wave LDS traffic is ordered: no barrier between the staging writes, the row reads and the next tile's writes)
 #pragma unroll
             for (int t = 0; t < NTAP; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) s_ep[(q * 4 + j) * WD_EP + li * 9 + t] = acc[mt][t][j];
-            __syncthreads();
-            for (int e = lane; e < 16 * 144; e += 64) {
-                const int row = e / 144;
-                const int rem = e - row * 144;
+            // one dW row (16 input channels x 9 taps = 144 consecutive floats) at a time: the row's base address is wave-uniform
+            // (scalar arithmetic), a lane adds rem = lane, lane + 64, lane + 128.  The flat e = lane + 64 i form cost a division
+            // and a 64-bit address per element: ~40 VALU instructions per atomic, half of the kernel's VALU work on short launches
+            // (profiles/round3_k_pmc_instmix.txt).
+            for (int row = 0; row < 16; ++row) {
                 const int co = co0 + mt * 16 + row;
-                if (co < d.Cout && rem < nrem) {
-                    const int cod = a.lstmC > 0 ? (co & 3) * a.lstmC + (co >> 2) : co;
-                    float* p = a.dw + (((long)(g * d.Cout + cod) * d.w_cin_tot) + d.w_cin_off + cit) * 9 + rem;
-                    atomicAdd(p, s_ep[row * WD_EP + rem]);
-                }
+                if (co >= d.Cout) break;
+                const int cod = a.lstmC > 0 ? (co & 3) * a.lstmC + (co >> 2) : co;
+                float* prow = a.dw + (((long)(g * d.Cout + cod) * d.w_cin_tot) + d.w_cin_off + cit) * 9;
+                const float* srow = s_ep + row * WD_EP;
+#pragma unroll
+                for (int rem = lane; rem < 144; rem += 64)
+                    if (rem < nrem) atomicAdd(prow + rem, srow[rem]);
             }
         }
     } else if constexpr (PAIR) {
