@@ -232,13 +232,22 @@ def main():
         del _a
     for _ in range(args.warmup):
         step_fn(batch, next_batch=nb)
+    # the ~220 k Python objects built so far (modules, plans, caches) leave the garbage collector's scans: a full collection
+    # costs the host 36 ms (profiles/experiments/gc_probe.py), as much as enqueueing a step, and the host is only a few
+    # steps ahead of the GPU in the first timed steps
+    import gc
+    gc.collect()
+    gc.freeze()
     barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
+    host_ms = []
     for i in range(args.steps):
+        _h = time.perf_counter()
         out = step_fn(batch, next_batch=nb)
         marks[i + 1].record()           # on the main stream, no synchronisation: per-step durations for the median
+        host_ms.append((time.perf_counter() - _h) * 1e3)       # host time to ENQUEUE the step (no synchronisation inside)
     barrier()
     elapsed = time.perf_counter() - t0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -262,6 +271,7 @@ def main():
         "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "median_ms_per_step": float(np.median(step_ms)), "preheat_s": args.preheat,
         "step_ms": [round(float(t), 2) for t in step_ms],
+        "host_enqueue_step_ms": [round(float(t), 2) for t in host_ms],
         "frames_per_s_at_median": world * B / (float(np.median(step_ms)) * 1e-3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
