@@ -333,11 +333,11 @@ class _BN(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def apply_bn(self, x, act, slope, training, residual=None):
+    def apply_bn(self, x, act, slope, training, residual=None, batch_parts=1):
         if training:
-            self.num_batches_tracked += 1
+            self.num_batches_tracked += batch_parts
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, training, act,
-                                 slope, residual)
+                                 slope, residual, batch_parts=batch_parts)
 
 
 class _Linear(nn.Module):
@@ -366,7 +366,11 @@ class _DCGANDiscriminator(nn.Module):
         self.main = nn.Sequential(*layers)
         self.classifier = nn.Sequential(_Linear(feat, 100), nn.Identity(), _Linear(100, 1), nn.Identity())
 
-    def forward(self, input):
+    def forward(self, input, batch_parts: int = 1):
+        """`batch_parts` = k: the batch holds k equal chunks that the reference passes through the network in k separate calls
+        (real images, generated images: train/4...py:380-394).  Convolutions and the classifier see them as one batch (they
+        are per-sample), every BatchNorm normalises each chunk with its own statistics and updates the running statistics
+        chunk after chunk -- the result of the k calls, with half the kernel launches."""
         x = input
         for conv_idx, bn_idx in self._plan:
             conv = self.main[conv_idx]
@@ -374,7 +378,7 @@ class _DCGANDiscriminator(nn.Module):
                 x = ops.conv2d(x, conv.weight, None, stride=2, pad=1, act=ACT_LRELU, slope=0.2)
             else:
                 x = ops.conv2d(x, conv.weight, None, stride=2, pad=1, act=ACT_NONE)
-                x = self.main[bn_idx].apply_bn(x, ACT_LRELU, 0.2, self.training)
+                x = self.main[bn_idx].apply_bn(x, ACT_LRELU, 0.2, self.training, batch_parts=batch_parts)
         x = x.reshape(x.size(0), -1)
         l0, l2 = self.classifier[0], self.classifier[2]
         x = ops.linear(x, l0.weight, l0.bias, ACT_LRELU, 0.2)

@@ -1510,9 +1510,61 @@ class _BatchNormActFn(Function):
             (dy if has_res else None), None, None
 
 
+class _SplitBatchNormActFn(Function):
+    """BatchNorm (+ activation) of `parts` equal chunks of the batch, each with ITS OWN batch statistics, the running
+    statistics updated chunk after chunk: what `parts` successive calls of the module on the chunks compute (the reference
+    runs its discriminators on the real and on the generated images in separate calls, train/4...py:380-394), for a batch
+    that went through the convolutions once.  The same kernels, called per chunk."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training: bool, act: int, slope: float, eps: float,
+                momentum: float, parts: int):
+        N, C, H, W = x.shape
+        n = N // parts
+        L = lib()
+        stats = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float64)
+        y = torch.empty_like(x)
+        for k in range(parts):
+            check(L.jaf_batchnorm_act_fwd_fused(_s(), _p(x[k * n:(k + 1) * n]), n, C, H * W, eps, momentum, _p(running_mean),
+                                                _p(running_var), _p(stats[k]), 1 if training else 0, _p(ws[k]), _p(weight),
+                                                _p(bias), None, _p(y[k * n:(k + 1) * n]), act, slope),
+                  "jaf_batchnorm_act_fwd_fused")
+        ctx.cfg = (training, act, slope, parts)
+        ctx.bias_ref = bias
+        ctx.save_for_backward(x, y, weight, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, weight, stats = ctx.saved_tensors
+        training, act, slope, parts = ctx.cfg
+        N, C, H, W = x.shape
+        n = N // parts
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        bias = ctx.bias_ref
+        inplace = _grad_inplace(weight) and bias is not None and _grad_inplace(bias)
+        dw = weight.grad if inplace else torch.empty_like(weight)
+        db = bias.grad if inplace else torch.empty_like(weight)
+        ws = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float64)
+        for k in range(parts):
+            sl = slice(k * n, (k + 1) * n)
+            check(lib().jaf_batchnorm_act_bwd(_s(), _p(dy[sl]), _p(x[sl]), _p(y[sl]), _p(stats[k]), _p(weight), _p(dx[sl]), _p(dw),
+                                              _p(db), n, C, H * W, act, slope, 1 if training else 0, _p(ws[k]),
+                                              1 if (inplace or k > 0) else 0), "jaf_batchnorm_act_bwd")
+        return dx, (None if inplace else dw), (None if inplace else db), None, None, None, None, None, None, None, None
+
+
 def batchnorm_act(x, weight, bias, running_mean, running_var, training=True, act=ACT_NONE, slope=0.0, residual=None,
-                  eps=1e-5, momentum=0.1):
+                  eps=1e-5, momentum=0.1, batch_parts: int = 1):
+    """`batch_parts` > 1: see _SplitBatchNormActFn (no residual)."""
     _chk(x, "batchnorm x")
+    if batch_parts > 1:
+        if residual is not None or x.shape[0] % batch_parts:
+            raise RuntimeError("batchnorm_act: batch_parts needs a divisible batch and no residual")
+        return _SplitBatchNormActFn.apply(x, weight, bias, running_mean, running_var, training, act, slope, eps, momentum,
+                                          batch_parts)
     if residual is not None:
         _chk(residual, "residual")
     return _BatchNormActFn.apply(x, weight, bias, running_mean, running_var, training, act, slope, residual, eps,

@@ -119,6 +119,8 @@ WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradi
 # "bwd": everything right before the loss backward, where the CRN competes with the backward's own kernels.
 # Measured at B=8: 68.6 vs 70.4 ms/step.
 PREP_AT = os.environ.get("JAF_PREP_AT", "d")
+# the discriminators' real and generated passes as one batch with per-half BatchNorm statistics (train_step); 0: two passes
+D_BATCHED = os.environ.get("JAF_D_BATCHED", "1") == "1"
 # the VGG + L1 loss and its gradient w.r.t. the generated frame on side stream 3, beside the discriminator phase
 VGG_SIDE = os.environ.get("JAF_VGG_SIDE", "1") != "0"
 
@@ -402,7 +404,15 @@ class Stage4Trainer:
         if next_batch is not None and PREP_AT == "d":
             self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True, part="networks")
         # ---- face discriminator, one update (:362-374)
-        if face_pred is not None:
+        if face_pred is not None and D_BATCHED:
+            # real and generated crops through the face discriminator as ONE batch of 2n (see the image discriminator below)
+            nfc = face_real.shape[0]
+            pf = M.F_Discriminator([torch.cat([face_real, face_pred_d]), torch.cat([face_IUV, face_IUV])], batch_parts=2)
+            F_errD_real = ops.bce_loss(pf[:nfc], 1.0)
+            F_errD_fake = ops.bce_loss(pf[nfc:], 0.0)
+            fsum = F_errD_real + F_errD_fake
+            (fsum if fw == 1.0 else fsum * fw).backward()
+        elif face_pred is not None:
             F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
             (F_errD_real if fw == 1.0 else F_errD_real * fw).backward()
             F_errD_fake = ops.bce_loss(M.F_Discriminator([face_pred_d, face_IUV]), 0.0)
@@ -415,11 +425,26 @@ class Stage4Trainer:
         # ---- image discriminator, three updates on accumulating grads (:380-394, F10)
         final_d = final.detach()
         final_dd = dview(final_d)
+        if D_BATCHED:
+            # The reference runs D on (target, src) and on (generated, src) in two calls per update and backpropagates the two BCE
+            # terms one after the other into the same .grad buffers (:380-394).  Here the two pairs -- the same tensors in all three
+            # updates -- form ONE batch of 2B: convolutions and the classifier are per-sample, every BatchNorm takes the statistics
+            # of each half separately and updates its running statistics half after half (ops._SplitBatchNormActFn), and the two
+            # BCE means are summed before one backward pass: the same numbers with half the launches of a phase that consists
+            # of 5-40 us kernels (host 11.3 ms / GPU 6.2 ms for the three updates; profiles/experiments/phases2.py).
+            nb_ = target_d.shape[0]
+            d_in = [torch.cat([target_d, final_dd]), torch.cat([src0_d, src0_d])]
         for _ in range(3):
-            errD_real = ops.bce_loss(M.discriminator([target_d, src0_d]), 1.0)
-            errD_real.backward()
-            errD_fake = ops.bce_loss(M.discriminator([final_dd, src0_d]), 0.0)
-            errD_fake.backward()
+            if D_BATCHED:
+                pd = M.discriminator(d_in, batch_parts=2)
+                errD_real = ops.bce_loss(pd[:nb_], 1.0)
+                errD_fake = ops.bce_loss(pd[nb_:], 0.0)
+                (errD_real + errD_fake).backward()
+            else:
+                errD_real = ops.bce_loss(M.discriminator([target_d, src0_d]), 1.0)
+                errD_real.backward()
+                errD_fake = ops.bce_loss(M.discriminator([final_dd, src0_d]), 0.0)
+                errD_fake.backward()
             self._reduce(["D"])
             self.flat["D"].adam(self.lrs["D"])
         mark("D x3 updates")

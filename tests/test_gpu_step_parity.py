@@ -71,6 +71,37 @@ def test_train_step_parity_reference_subsets(used, prosrc):
 BF16_GRAD_BARS = {"accu": 0.30, "inpaint": 0.30, "refine": 0.16, "flow": 0.12, "D": 0.16, "face": 0.25}
 
 
+def test_batched_discriminator_passes_equal_separate_passes():
+    """step.D_BATCHED: real and generated pairs through the discriminators as one batch with per-half BatchNorm statistics
+    (ops._SplitBatchNormActFn) against the reference's two calls per update (train/4...py:362-394): after one full step
+    (one face-D update, three D updates on accumulating gradients) losses, D / face-D gradients, post-Adam parameters and
+    BatchNorm buffers agree to fp32 summation order."""
+    import jafpro_amd.step as st
+    res = {}
+    prev = st.D_BATCHED
+    try:
+        for mode in (False, True):
+            st.D_BATCHED = mode
+            M, tr, _, batch, dbatch, mods = build(2, seed=322)
+            out = tr.train_step(dbatch)
+            torch.cuda.synchronize()
+            res[mode] = (out, {n: tr.flat[n].grad.clone() for n in ("D", "face")}, {n: tr.flat[n].flat.clone() for n in ("D", "face")},
+                         {n + "." + k: v.clone() for n in ("D", "face") for k, v in mods[n].state_dict().items() if "running_" in k or "num_batches" in k})
+    finally:
+        st.D_BATCHED = prev
+    (o0, g0, p0, b0), (o1, g1, p1, b1) = res[False], res[True]
+    for k in ("errD", "F_errD", "errG", "F_errG", "total_loss"):
+        assert abs(float(o0[k].reshape(-1)[0]) - float(o1[k].reshape(-1)[0])) <= 1e-5 * max(1.0, abs(float(o0[k].reshape(-1)[0]))), k
+    for n in ("D", "face"):
+        assert rel_l2(g1[n], g0[n]) <= 2e-5, (n, rel_l2(g1[n], g0[n]))
+        assert rel_l2(p1[n], p0[n]) <= 1e-6, n
+    for k in b0:
+        if "num_batches" in k:
+            assert int(b0[k]) == int(b1[k]), k
+        else:
+            assert (b0[k] - b1[k]).abs().max().item() <= 1e-6 * max(1.0, b0[k].abs().max().item()), k
+
+
 def test_train_step_bf16_gradients():
     from jafpro_amd import ops
     M, tr, _, batch, dbatch, mods = build(2, seed=322)
