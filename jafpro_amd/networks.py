@@ -333,11 +333,40 @@ class _BN(nn.Module):
         self.register_buffer("running_var", torch.ones(c))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
+    _nbt_pending = 0        # train-mode calls not yet added to the num_batches_tracked buffer
+
     def apply_bn(self, x, act, slope, training, residual=None, batch_parts=1):
         if training:
-            self.num_batches_tracked += batch_parts
+            # The counter is bookkeeping (momentum is fixed at 0.1, nothing on the device reads it): counted on the host and added to
+            # the buffer when the state is read (55 one-element launches per step otherwise).  A hipGraph capture records the
+            # device-side increment instead, since the Python code does not run again on replay.
+            if x.is_cuda and torch.cuda.is_current_stream_capturing():
+                self.num_batches_tracked += batch_parts
+            else:
+                self._nbt_pending += batch_parts
         return ops.batchnorm_act(x, self.weight, self.bias, self.running_mean, self.running_var, training, act,
                                  slope, residual, batch_parts=batch_parts)
+
+
+def _bn_flush(self):
+    if self._nbt_pending:
+        self.num_batches_tracked += self._nbt_pending
+        self._nbt_pending = 0
+
+
+def _bn_save(self, destination, prefix, keep_vars):
+    _bn_flush(self)
+    nn.Module._save_to_state_dict(self, destination, prefix, keep_vars)
+
+
+def _bn_load(self, *args, **kwargs):
+    self._nbt_pending = 0
+    return nn.Module._load_from_state_dict(self, *args, **kwargs)
+
+
+_BN.flush_counters = _bn_flush
+_BN._save_to_state_dict = _bn_save
+_BN._load_from_state_dict = _bn_load
 
 
 class _Linear(nn.Module):
