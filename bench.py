@@ -38,10 +38,11 @@ def build_models(fidx, image_size=256):
     return M, mods
 
 
-def cpu_baseline(mods, fidx):
+def cpu_baseline(mods, fidx, size=256):
     """The oracle (CPU restatement of the reference step, SURVEY 8(d) "CPU baseline beside it") timed on this node's
     host cores on a bounded sample: B=1 -- one warm-up + three timed full train steps, median -- and B=8 (the GPU
-    workload's batch) -- one timed step."""
+    workload's batch) -- one timed step.  At 512 x 512 (config 5 geometry, this build's own extension of the oracle): B=1,
+    one warm-up + one timed step."""
     from jafpro_amd import synth
     from oracle.step_oracle import OracleStage4
     sds = {k: {kk: vv.detach().cpu().clone() for kk, vv in m.state_dict().items()} for k, m in mods.items()}
@@ -52,6 +53,16 @@ def cpu_baseline(mods, fidx):
         share = os.cpu_count() or 1
     torch.set_num_threads(max(1, min(share, 16)))
     orc = OracleStage4(sds, fidx)
+    if size != 256:
+        b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.stage4_batch(1400, 1, S=size).items()}
+        orc.train_step(b)
+        t0 = time.perf_counter()
+        orc.train_step(b)
+        dt = time.perf_counter() - t0
+        return {"value": 1.0 / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "B=1: 1 full stage-4 train step after 1 warm-up (T=4, %dx%d fp32, %.1f s); reference-equivalent CPU path "
+                          "(the oracle's size-parametrised form: the reference itself is 256-only), not optimised: torch CPU ops on "
+                          "%d threads, brute-force C rasteriser single-threaded" % (size, size, dt, torch.get_num_threads())}
     b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in synth.stage4_batch(1400, 1).items()}
     orc.train_step(b)
     ts = []
@@ -126,9 +137,12 @@ def main():
                     help="N=1 only: also time this many steps in the bf16x3 parity-grade mode (0 = skip)")
     ap.add_argument("--size", type=int, default=256, choices=[256, 512],
                     help="frame size: 256 = the BASELINE metric's configuration (configs[2]); 512 = configs[4] geometry "
-                         "(no reference implementation; throughput only, no cpu_baseline)")
+                         "(no reference implementation at that size; throughput / roofline evidence, cpu_baseline = the "
+                         "size-parametrised oracle at B=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--roofline-kernel", default=None,
+                    help="report this kernel instantiation in `roofline` instead of the one with the largest total time")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the forward-only BASELINE configs[1] figure (N=1 only)")
     ap.add_argument("--preheat", type=float, default=float(os.environ.get("JAF_BENCH_PREHEAT", "0")),
@@ -152,16 +166,17 @@ def main():
         # child process of the default run (below): the CPU oracle alone, one JSON line
         from jafpro_amd import synth as _synth
         _, _fidx = _synth.body_mesh()
-        _M, _mods = build_models(_fidx)
-        print(json.dumps(cpu_baseline(_mods, _fidx)))
+        _M, _mods = build_models(_fidx, args.size)
+        print(json.dumps(cpu_baseline(_mods, _fidx, args.size)))
         return
     # CPU baseline first (rank 0, N=1), in a CHILD process started before this one touches the GPU: the oracle's 16 OpenMP
     # threads and its ~40 GB of host memory are gone when the timed loop starts (run in-process they left 80-95 ms
     # outliers in the first ten timed steps: profiles/round3_a_bench_bf16.json `step_ms`)
     cpu_result = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.size == 256:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import subprocess
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], capture_output=True, text=True)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size)],
+                           capture_output=True, text=True)
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
         if r.returncode != 0 or not lines:
             raise SystemExit("cpu baseline failed:\n" + r.stderr[-2000:])
@@ -309,17 +324,21 @@ def main():
         # dominant kernel = the template instantiation with the largest total time, named as rocprofv3 names it
         # (profiles/*kernel_stats*.csv carries the same rows)
         name, r = max(summ.items(), key=lambda kv: kv[1]["ms"])
+        if args.roofline_kernel is not None:
+            name, r = args.roofline_kernel, summ[args.roofline_kernel]
         achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
         tot_ms = sum(v["ms"] for v in summ.values())
         tot_fl = sum(v["flops"] for v in summ.values())
         peak = MFMA_PEAK_TFLOPS[args.precision]
         # HBM bytes per launch of the dominant kernel: not measurable inside this process (PMC counters need
-        # their own rocprofv3 passes), so it is the committed figure of scratch/pmc_traffic.sh for that kernel
+        # their own rocprofv3 passes), so it is the committed figure of profiles/pmc_traffic.sh for that kernel
+        # (pmc_traffic.json: 256 x 256; pmc_traffic_512.json: 512 x 512)
         traffic, traffic_src = None, None
         try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+            pj = "pmc_traffic.json" if args.size == 256 else "pmc_traffic_%d.json" % args.size
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pj)) as f:
                 pt = json.load(f)
-            if pt.get("kernel") == name and args.precision == "bf16" and args.size == 256:
+            if pt.get("kernel") == name and args.precision == "bf16" and pt.get("batch", 8) == B:
                 traffic, traffic_src = pt["hbm_bytes_per_launch"], pt["source"]
         except (OSError, ValueError, KeyError):
             pass

@@ -379,10 +379,12 @@ extern "C" int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m,
                              float lr, float beta1, float beta2, float eps, int32_t step) {
     JAF_REQUIRE(p && g && m && v && n >= 1 && step >= 1);
     JAF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    // bias corrections in double, as torch.optim.Adam takes them (Python floats), rounded once; adam_tick_kernel evaluates
+    // the same two expressions on the device, so the eager and the graph-replayed step use the same numbers
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(jaf_ew_grid(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, (long)n, lr,
-                       beta1, beta2, eps, bc1, sqrtf(bc2));
+                       beta1, beta2, eps, bc1, bc2_sqrt);
     return jaf_launch_status();
 }
 
@@ -394,8 +396,8 @@ __global__ void adam_tick_kernel(float* state, float b1, float b2) {
     int* cnt = (int*)state;
     const int step = cnt[0] + 1;
     cnt[0] = step;
-    state[1] = 1.f - powf(b1, (float)step);
-    state[2] = sqrtf(1.f - powf(b2, (float)step));
+    state[1] = (float)(1.0 - pow((double)b1, (double)step));           // the expressions of jaf_adam_step, in double
+    state[2] = (float)sqrt(1.0 - pow((double)b2, (double)step));
 }
 
 __global__ void adam_dev_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,

@@ -340,6 +340,8 @@ class _BN(nn.Module):
             # The counter is bookkeeping (momentum is fixed at 0.1, nothing on the device reads it): counted on the host and added to
             # the buffer when the state is read (55 one-element launches per step otherwise).  A hipGraph capture records the
             # device-side increment instead, since the Python code does not run again on replay.
+            # Contract: the buffer is current whenever state_dict() is taken and, on the trainers, between steps
+            # (step.flush_bn_counters: one batched add per step); inside a step it lags by the calls made so far.
             if x.is_cuda and torch.cuda.is_current_stream_capturing():
                 self.num_batches_tracked += batch_parts
             else:

@@ -30,7 +30,7 @@ from . import ops
 from .crn_model import CRN_smaller
 from .networks import (Accumulate_LSTM, Accumulate_LSTM_no_loss, FaceDiscriminator, ImageDiscriminator, UNet_inpainter,
                        VGG_l1_loss)
-from .step import FlatParams, _used_flags, count_faces, face_crops
+from .step import FlatParams, _used_flags, count_faces, face_crops, flush_bn_counters
 
 CKPT_PREFIX = {"accu": "Accu", "inpaint": "inpaint", "bg": "bg", "refine": "refine", "D": "D", "face": "FD", "flow": "pro"}
 
@@ -212,6 +212,7 @@ class Stage3Trainer:
             return self._train_step(batch, used, align_corners)
         finally:
             ops.set_wgrad_stream(prev_ws)
+            flush_bn_counters(self.M)
 
     def _train_step(self, b, used, align_corners):
         M = self.M

@@ -10,9 +10,8 @@ background input (:231, passed in as data) -- on grouped device tensors.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Sequence
-
 import os
+from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -29,7 +28,10 @@ from .networks import (Accumulate_LSTM_no_loss, FaceDiscriminator, ImageDiscrimi
 LRS = {"accu": 1e-5, "inpaint": 1e-5, "refine": 1e-5, "flow": 5e-5, "D": 3e-6, "face": 1e-6}   # :169-175
 
 
-_CAPTURE = {"on": False}        # True while a train step is being captured into a hipGraph (GraphedTrainStep)
+# "on": True while a train step is being captured into a hipGraph; "settling": while GraphedTrainStep warms the host caches
+_CAPTURE = {"on": False, "settling": False}
+GRAPH_HOT = int(os.environ.get("JAF_GRAPH_HOT", "2"))          # a key is captured the GRAPH_HOT-th time it is seen in a row
+GRAPH_CACHE = int(os.environ.get("JAF_GRAPH_CACHE", "4"))      # graphs kept per trainer (each owns a private memory pool)
 
 
 class FlatParams:
@@ -309,19 +311,26 @@ class Stage4Trainer:
         backward and is picked up by that next call (`next_prosrc`: that call's propagation source)."""
         # weight-gradient kernels run on their own stream beside the data gradients (ops.set_wgrad_stream)
         prev_ws = ops.set_wgrad_stream(None if not WGRAD_STREAM else ops.aux_stream(1))
+        if not _CAPTURE["on"] and not _CAPTURE["settling"]:
+            self._last_graph = None      # an eager step in between: a graph's static hand-over slot no longer matches the sequence
         try:
             return self._train_step(batch, used, prosrc, align_corners, next_batch,
                                     prosrc if next_prosrc is None else next_prosrc)
         finally:
             ops.join_wgrad_stream()
             ops.set_wgrad_stream(prev_ws)
+            if not _CAPTURE["on"]:
+                flush_bn_counters(self.M)
 
     def train_step_graphed(self, batch, used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0, align_corners: bool = False,
                            next_batch=None, next_prosrc: Optional[int] = None):
-        """`train_step` through a captured hipGraph (GraphedTrainStep): the first call with a new key -- batch geometry,
-        `used`, `prosrc`, face boxes, with / without a next clip -- captures
-        (that call's own step runs eagerly); later calls copy the clips into the graph's static buffers and replay.  The returned tensors are the graph's own
-        output buffers: valid until the next replay."""
+        """`train_step` through a captured hipGraph (GraphedTrainStep).  A graph is specific to its key -- batch geometry, `used`,
+        `prosrc`, the face boxes (host integers that become kernel arguments of the crops), with / without a next clip.  A key
+        is captured the SECOND time it is seen in a row (`GRAPH_HOT`): data whose boxes or reference subsets change from clip
+        to clip therefore runs the eager step, exactly as `train_step`, and never pays for captures it would not replay; at
+        most `GRAPH_CACHE` graphs are kept (least recently used dropped, with their private memory pools).  The call that
+        captures runs its own step eagerly; later calls with that key copy the clips into the graph's static buffers and
+        replay.  Tensors returned by a replay are the graph's own output buffers: valid until the next replay."""
         nps = prosrc if next_prosrc is None else next_prosrc
         key = (tuple(used), prosrc, nps, bool(align_corners), next_batch is not None, ops.get_precision(),
                tuple(int(v) for v in np.asarray(batch["face_bbox"]).reshape(-1)),
@@ -329,10 +338,23 @@ class Stage4Trainer:
         graphs = self.__dict__.setdefault("_graphs", {})
         g = graphs.get(key)
         if g is None:
+            seen = self.__dict__.setdefault("_graph_seen", {})
+            n = seen.get(key, 0) + 1
+            seen.clear()                        # "in a row": another key in between starts the count again
+            seen[key] = n
+            if n < GRAPH_HOT:
+                self._last_graph = None
+                return self.train_step(batch, used, prosrc, align_corners, next_batch, nps)
+            seen.clear()
+            while len(graphs) >= max(1, GRAPH_CACHE):
+                graphs.pop(next(iter(graphs)))                      # dicts keep insertion order: the least recently used
             g = graphs[key] = GraphedTrainStep(self, batch, used, prosrc, align_corners, next_batch, nps)
+            self._last_graph = g
             return g.first
-        g.load(batch, next_batch)
-        return g.replay()
+        graphs[key] = graphs.pop(key)                               # most recently used last
+        out = g.step(batch, next_batch, in_sequence=self.__dict__.get("_last_graph") is g)
+        self._last_graph = g
+        return out
 
     @staticmethod
     def _generator_backward(total, final, fl, g_vgg):
@@ -485,6 +507,29 @@ class Stage4Trainer:
                 "final_output": final_d}
 
 
+def flush_bn_counters(module: nn.Module) -> None:
+    """Adds the host-side BatchNorm call counts (networks._BN._nbt_pending: 55 layers per stage-4 step) to the
+    `num_batches_tracked` buffers as ONE batched add, so that the buffers are current between steps for every reader
+    (state_dict() flushes by itself; `module.num_batches_tracked`, buffers(), a broadcast or a copy between modules do not)."""
+    bns = module.__dict__.get("_bn_list")
+    if bns is None:
+        bns = module.__dict__["_bn_list"] = [m for m in module.modules() if hasattr(m, "_nbt_pending")]
+    pend = [m for m in bns if m._nbt_pending]
+    if not pend:
+        return
+    torch._foreach_add_([m._buffers["num_batches_tracked"] for m in pend], [int(m._nbt_pending) for m in pend])
+    for m in pend:
+        m._nbt_pending = 0
+
+
+def _clip_token(b):
+    """Identity of a clip as the caller holds it: tensors by storage and version, host arrays by value."""
+    if b is None:
+        return None
+    return tuple((k, v.data_ptr(), v._version) if isinstance(v, torch.Tensor) else (k, np.asarray(v).tobytes())
+                 for k, v in sorted(b.items()))
+
+
 class GraphedTrainStep:
     """One full stage-4 train step captured ONCE into a hipGraph and replayed: ~1500 kernel launches on four streams become
     one graph launch, so the step no longer depends on how fast the host can enqueue (profiles/round2_host_enqueue.txt: 35-58
@@ -492,13 +537,21 @@ class GraphedTrainStep:
 
     What a captured step fixes, and how the moving parts are handled:
       * geometry and host integers -- batch shapes, the reference subset `used`, the propagation source, the face boxes
-        (kernel arguments of the crops) -- are the graph's key: `Stage4Trainer.train_step_graphed` keeps one graph per key
-        and falls back to the eager step for keys it has not captured;
-      * the batch lives in static device buffers (`load` copies a new batch in; the next clip has its own set);
+        (kernel arguments of the crops) -- are the graph's key (`Stage4Trainer.train_step_graphed`: hot keys only, LRU cap);
+      * the clips live in static device buffers.  With a next-clip slot there are THREE sets: `cur` (the clip this replay
+        trains on), `nxt` (the clip it prepares) and `stage` (where `step` puts the caller's next clip).  The graph begins
+        with cur <- nxt, nxt <- stage: call k, given (B_k, B_k+1), trains on B_k -- which call k-1 staged and prepared --
+        and prepares B_k+1;
+      * a call that does not continue the sequence (another clip than the one staged last time, or an eager step / another
+        graph in between) RESYNCS first: its clip goes into `nxt` and is prepared eagerly into the static hand-over slot;
       * Adam's bias correction needs the step count: it lives on the device (jaf_adam_step_dev), advanced inside the graph;
+        the host's counters advance by what the capture counted (one per module, three for the image discriminator);
       * the next clip's preparation (side stream 0) is produced INSIDE the graph into graph-owned tensors and copied into
         the static PreparedClip the next replay starts from -- the cross-step overlap of the eager step, kept;
-      * every side stream is joined before the capture ends (weight gradients, re-packed weight images, preparation).
+      * every side stream is joined before the capture ends (weight gradients, re-packed weight images, preparation);
+      * a capture must not find a host-side cache to fill (uploads are illegal while capturing): on a cold process the
+        step is run up to twice more to warm them, with parameters, Adam moments, step counts and BatchNorm buffers
+        restored afterwards -- the capturing call applies exactly ONE step's update, like `train_step`.
     Single-rank only: the gradient exchange of N > 1 ranks stays on the eager path."""
 
     def __init__(self, trainer: "Stage4Trainer", batch, used, prosrc, align_corners, next_batch, next_prosrc):
@@ -509,20 +562,28 @@ class GraphedTrainStep:
         clone = lambda b: {k: (v.clone() if isinstance(v, torch.Tensor) else np.array(v, copy=True)) for k, v in b.items()}
         self.cur = clone(batch)
         self.nxt = clone(next_batch) if next_batch is not None else None
-        # THIS call's step runs eagerly on the static buffers: it fills every host-side cache (plans, packed weight images,
+        self.stage = clone(next_batch) if next_batch is not None else None
+        self.staged_token = _clip_token(next_batch)
+        # THIS call's step runs eagerly on the static buffers: it fills the host-side caches (plans, packed weight images,
         # constants, LDS opt-ins) and leaves the preparation of `nxt` behind; the capture below executes nothing
-        self.settle_steps = 0
-        while True:
+        _CAPTURE["settling"] = True
+        try:
             before = ops.cache_census()
             out = tr.train_step(self.cur, self.used, prosrc, align_corners, next_batch=self.nxt, next_prosrc=next_prosrc)
-            if self.settle_steps == 0:
-                self.first = {k: v.clone() for k, v in out.items()}
-            self.settle_steps += 1
-            # a cold process builds its weight images (and the argument tables of their re-packing) over its first two
-            # steps -- the discriminator's data-gradient images only exist after the first generator backward -- and a
-            # capture must not find anything left to build (uploads are illegal while capturing)
-            if ops.cache_census() == before or self.settle_steps >= 3:
-                break
+            self.first = {k: v.clone() for k, v in out.items()}
+            self.settle_steps = 1
+            # a cold process builds its weight images (and the argument tables of their re-packing) over its first two steps
+            # -- the discriminator's data-gradient images only exist after the first generator backward.  Warm-up steps leave
+            # no trace in the training state.
+            while ops.cache_census() != before and self.settle_steps < 3:
+                snap = self._snapshot()
+                before = ops.cache_census()
+                tr._prepared = None
+                tr.train_step(self.cur, self.used, prosrc, align_corners, next_batch=self.nxt, next_prosrc=next_prosrc)
+                self._restore(snap)
+                self.settle_steps += 1
+        finally:
+            _CAPTURE["settling"] = False
         torch.cuda.synchronize()
         self.prep = tr._prepared                     # PreparedClip in ordinary memory: the graph's static hand-over slot
         if self.prep is not None:
@@ -536,10 +597,13 @@ class GraphedTrainStep:
         try:
             with torch.cuda.graph(self.graph):
                 main = torch.cuda.current_stream()
-                if self.nxt is not None:             # this replay's clip is what the previous one prepared: nxt -> cur
+                if self.nxt is not None:             # this replay's clip is what the previous one prepared: nxt -> cur, stage -> nxt
                     for k, v in self.cur.items():
                         if isinstance(v, torch.Tensor):
                             v.copy_(self.nxt[k])
+                    for k, v in self.nxt.items():
+                        if isinstance(v, torch.Tensor):
+                            v.copy_(self.stage[k])
                 if self.prep is not None:            # (after the copies: they bump the tensors' versions, which the key holds)
                     self.prep.batch, self.prep.key = self.cur, _clip_key(self.cur, prosrc)
                 tr._prepared = self.prep
@@ -557,12 +621,35 @@ class GraphedTrainStep:
                         main.wait_stream(st)
         finally:
             _CAPTURE["on"] = False
-        for n, f in tr.flat.items():                 # the capture advanced the host's counters without running anything
+        # the capture advanced the host's counters without running anything: what it counted is what one replay adds
+        self.increments = {n: f.step_count - counts[n] for n, f in tr.flat.items()}
+        for n, f in tr.flat.items():
             f.step_count = counts[n]
         tr._prepared = None
         ops.reset_pack_events()
         self.pack_entries = ops.pack_cache_entries()         # the graph writes these images: they must outlive it
         self.replays = 0
+        self.resyncs = 0
+
+    def _snapshot(self):
+        tr = self.trainer
+        return ({n: (f.flat.clone(), f.m.clone(), f.v.clone(), f.step_count) for n, f in tr.flat.items()},
+                [(bf, bf.clone()) for bf in tr.M.buffers()],
+                [(m, m._nbt_pending) for m in tr.M.modules() if hasattr(m, "_nbt_pending")])
+
+    def _restore(self, snap):
+        tr = self.trainer
+        ops.join_wgrad_stream()
+        for n, (p, m, v, c) in snap[0].items():
+            f = tr.flat[n]
+            f.flat.copy_(p); f.m.copy_(m); f.v.copy_(v)
+            f.step_count = c
+        for bf, val in snap[1]:
+            bf.copy_(val)
+        for m, c in snap[2]:
+            m._nbt_pending = c
+        for f in tr.flat.values():                   # the images follow the weights back (per module: the re-pack tables of Adam)
+            ops.refresh_packed_weights(f.params)
 
     @staticmethod
     def _prep_pairs(dst: PreparedClip, src: PreparedClip):
@@ -572,24 +659,49 @@ class GraphedTrainStep:
             pairs += list(zip(dst.vgg_target[1], src.vgg_target[1]))
         return pairs
 
-    def load(self, batch=None, next_batch=None):
-        """Copies a new clip (and the clip after it) into the static buffers.  With a next-clip slot the graph itself moves
-        `nxt` into `cur` at the start of a replay, so only `next_batch` is needed from the second call on."""
-        def put(dst, src):
-            for k, v in dst.items():
-                if isinstance(v, torch.Tensor) and src[k] is not v and src[k].data_ptr() != v.data_ptr():
+    @staticmethod
+    def _put(dst, src):
+        for k, v in dst.items():
+            if isinstance(v, torch.Tensor):
+                if src[k] is not v and src[k].data_ptr() != v.data_ptr():
                     v.copy_(src[k])
+            else:
+                dst[k] = np.array(src[k], copy=True)
+
+    def _resync(self, batch):
+        """`batch` is not the clip the previous replay staged and prepared (or something else ran in between): put it where
+        the graph expects this replay's clip (`nxt`, moved to `cur` by the graph's first nodes) and prepare it eagerly into
+        the static hand-over slot."""
+        tr = self.trainer
+        self._put(self.nxt, batch)
+        p = prepare_clip(tr.M, self.nxt, self.prosrc, with_loss_target=True)
+        main = torch.cuda.current_stream()
+        main.wait_event(p.event)
+        if p.vgg_event is not None:
+            main.wait_event(p.vgg_event)
+        with torch.no_grad():
+            for a, b in self._prep_pairs(self.prep, p):
+                a.copy_(b)
+        self.resyncs += 1
+
+    def step(self, batch, next_batch=None, in_sequence: bool = True):
+        """One replay that trains on `batch` and prepares `next_batch` (graphs captured with a next-clip slot)."""
         if self.nxt is None:
-            if batch is not None:
-                put(self.cur, batch)
-        elif next_batch is not None:
-            put(self.nxt, next_batch)
+            self._put(self.cur, batch)
+        else:
+            if next_batch is None:
+                raise ValueError("this graph was captured with a next clip: pass next_batch")
+            if not in_sequence or _clip_token(batch) != self.staged_token:
+                self._resync(batch)
+            self._put(self.stage, next_batch)
+            self.staged_token = _clip_token(next_batch)
+        return self.replay()
 
     def replay(self):
         self.graph.replay()
         self.replays += 1
         for n, f in self.trainer.flat.items():
-            f.step_count += 3 if n == "D" else 1
+            f.step_count += self.increments[n]
         return self.out
 
 

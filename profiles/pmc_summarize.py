@@ -2,7 +2,7 @@
 into the per-kernel HBM-traffic table committed as profiles/<tag>_pmc_hbm_traffic.txt and the dominant kernel's row
 profiles/pmc_traffic.json that bench.py copies into roofline.traffic.
 
-  python profiles/pmc_summarize.py <tag> [<dominant kernel name>]
+  python profiles/pmc_summarize.py <tag> [<dominant kernel name> [<json file name> [<bench arguments, for the header>]]]
 
 Units and corrections (MI355X_MICROARCH.md, HBM section): the counters are KiB as rocprofv3 reports them; on gfx950
 FETCH_SIZE tallies wide (16 B per lane) streaming reads at HALF their bytes, WRITE_SIZE is exact, so the HBM-side bytes
@@ -44,8 +44,9 @@ def main():
     rows.sort(key=lambda r: -r[5])
     out = os.path.join(ROOT, "profiles", "%s_pmc_hbm_traffic.txt" % tag)
     with open(out, "w") as fh:
+        extra = (" " + sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else ""
         fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/pmc_traffic.sh) over\n"
-                 "# `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-config2 --parity-mode-steps 0 --serial-streams`\n"
+                 "# `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-config2 --parity-mode-steps 0 --serial-streams" + extra + "`\n"
                  "# (3 train steps, bf16 packed path).  KiB as rocprofv3 reports them; gfx950: wide streaming reads are tallied at half\n"
                  "# their bytes, writes exactly (MI355X_MICROARCH.md, HBM section): est. HBM MB per launch = (2*FETCH + WRITE) KiB.\n"
                  "# Rows sorted by total estimated bytes; every kernel of the step is listed (the gather / blend kernels of the\n"
@@ -53,14 +54,15 @@ def main():
         fh.write("%-56s %8s %16s %16s %18s\n" % ("kernel", "launches", "FETCH_KiB/launch", "WRITE_KiB/launch", "est_HBM_MB/launch"))
         for k, n, f, w, mb, _ in rows:
             fh.write("%-56s %8d %16.1f %16.1f %18.2f\n" % (k[:56], n, f, w, mb))
-    dom = sys.argv[2] if len(sys.argv) > 2 else "conv_dma_kernel<4, 4, false, false, false>"
+    dom = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] else "conv_dma_kernel<4, 4, false, false, false>"
+    jname = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] else "pmc_traffic.json"
     for k, n, f, w, mb, _ in rows:
         if k == dom:
             json.dump({"kernel": dom, "launches": n, "fetch_kib_per_launch": f, "write_kib_per_launch": w,
                        "hbm_bytes_per_launch": (2 * f + w) * 1024,
                        "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                  "2*FETCH+WRITE per MI355X_MICROARCH.md)" % tag},
-                      open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+                      open(os.path.join(ROOT, "profiles", jname), "w"), indent=1)
             print("dominant", dom, "%.1f MB per launch" % ((2 * f + w) * 1024 / 1e6))
     print("wrote", out, len(rows), "kernels")
 

@@ -1,7 +1,8 @@
 """One data-parallel rank of the stage-4 trainer, started by tests/test_gpu_step_parity.py (one process per rank,
-like the driver's torch.distributed.run launch).  The ranks talk over gloo and may share one GPU -- RCCL refuses two
-ranks on one device, and the arithmetic under test (per-rank BatchNorm statistics, gradient means started from inside
-the backward pass, face-count weights) does not depend on the transport.
+like the driver's torch.distributed.run launch).  JAF_RANK_BACKEND=gloo (default): the ranks talk over gloo and share
+device 0 -- RCCL refuses two ranks on one device, and the arithmetic under test (per-rank BatchNorm statistics, gradient
+means started from inside the backward pass, face-count weights) does not depend on the transport.  JAF_RANK_BACKEND=nccl:
+RCCL, rank r on device r (test_two_rank_trainer_rccl, boxes with >= 2 GPUs).
 
   python tests/_rank_worker.py RANK WORLD PORT OUT.pt PRECISION SEED USED PROSRC [drop_face_rank]
 """
@@ -20,8 +21,13 @@ def main():
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("JAF_RANK_BACKEND", "gloo")
+    dev = rank if backend == "nccl" else 0            # RCCL: one device per rank; gloo: the ranks share device 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from jafpro_amd import ops, synth
     from jafpro_amd.dist import GradReducer, shard_batch
     from jafpro_amd.step import Stage4Trainer, _to_dev
@@ -48,7 +54,7 @@ def main():
                      "g_sum": float(g.double().sum()), "p_sum": float(p.double().sum())}
     res = {"losses": {k: float(v.reshape(-1)[0]) for k, v in out.items() if k != "final_output"},
            "final_output": out["final_output"].cpu(), "overlap_order": list(getattr(tr, "overlap_order", [])),
-           "digest": digest,
+           "digest": digest, "backend": dist.get_backend(), "device": torch.cuda.current_device(),
            "buffers": {n: {k: v.cpu() for k, v in mods[n].state_dict().items() if "running_" in k or k.endswith("num_batches_tracked")}
                        for n in ("flow", "D", "face")}}
     torch.save(res, out_path)

@@ -378,9 +378,10 @@ def test_graphed_step_matches_the_eager_step():
     next clip's preparation handed over through a static slot, every side stream joined) and replayed must train like the
     eager step, f32 arithmetic.  The GAN terms of this step are chaotic at B=1 -- two EAGER trainers started from the same
     weights differ by 5e-4 in errD after four steps and by 1.2e-2 after six (fp32 atomics reorder the weight-gradient sums,
-    Adam's first updates are sign-like; measured with scratch/graph_dbg.py: F_errG 2.8e-3 apart at the 4th step) -- so the
-    first replay is held to 6e-3 and the two after it to 3e-2; total / perceptual loss to 1e-3 throughout; a stale clip preparation, a missed update or a frozen
-    step count shows up at 1e-1 .. 1.  The first graphed call runs eagerly and captures."""
+    Adam's first updates are sign-like: F_errG 2.8e-3 apart at the 4th step) -- so the first two calls are held to 6e-3 and
+    the two after it to 3e-2; total / perceptual loss to 1e-3 throughout; a stale clip preparation, a missed update or a
+    frozen step count shows up at 1e-1 .. 1.  A key is captured the second time it is seen in a row (step.GRAPH_HOT): the
+    first graphed call IS the eager step, the second runs eagerly and captures, the third and fourth replay."""
     M1, tr1, _, batch, dbatch, _ = build(1)
     M2, tr2, _, _, _, _ = build(1)
     for tr in (tr1, tr2):                    # warm every host-side cache: the capture then needs no settling step
@@ -400,13 +401,69 @@ def test_graphed_step_matches_the_eager_step():
         # frames: two eager trainers are ~5e-3 apart by their 4th step and ~2.5e-2 by their 6th
         assert rel_l2(o["final_output"], outs[i]["final_output"]) <= (1e-2 if i <= 1 else 1e-1), i
     g = next(iter(tr2._graphs.values()))
-    assert g.settle_steps == 1 and g.replays == 3
+    assert g.settle_steps == 1 and g.replays == 2 and g.resyncs == 0
+    assert g.increments == {n: (3 if n == "D" else 1) for n in TRAINABLE}
     for n in TRAINABLE:
         assert tr1.flat[n].step_count == tr2.flat[n].step_count == (18 if n == "D" else 6)
         assert int(tr2.flat[n].dev_state.view(torch.int32)[0]) == tr2.flat[n].step_count
         assert rel_l2(tr2.flat[n].flat, tr1.flat[n].flat) <= 2e-3, n
     # a different propagation source is another graph key: captured separately (that call runs eagerly)
-    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)
+    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)          # first sighting: the eager step
+    assert len(tr2._graphs) == 1 and all(bool(torch.isfinite(o_g[k]).all()) for k in LOSSES)
+    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)          # hot: eager + capture
     assert len(tr2._graphs) == 2 and all(bool(torch.isfinite(o_g[k]).all()) for k in LOSSES)
-    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)
-    assert all(bool(torch.isfinite(o_g[k]).all()) for k in LOSSES) and tr2.flat["accu"].step_count == 8
+    o_g = tr2.train_step_graphed(dbatch, prosrc=2, next_batch=dbatch, next_prosrc=2)          # replay
+    assert all(bool(torch.isfinite(o_g[k]).all()) for k in LOSSES) and tr2.flat["accu"].step_count == 9
+
+
+def test_graphed_step_trains_on_the_clip_it_is_given():
+    """Distinct clips through the graph: call k with (B_k, B_k+1) must train on B_k with B_k's preparation and
+    prepare B_k+1.  Three different clips of one geometry (same face boxes = same graph key) in a cycle, graphed against
+    eager from the same weights: per-call losses agree (a step on the wrong clip, or one clip's textures with another's
+    background / flow / perceptual target, is off by O(1): the clips' losses differ by more than 10 %), the graph's `cur`
+    buffers hold the clip that was passed, and a call that breaks the sequence resynchronises instead of using a stale
+    hand-over slot."""
+    from jafpro_amd import synth
+    from jafpro_amd.step import _to_dev
+    M1, tr1, _, _, _, _ = build(1)
+    M2, tr2, _, _, _, _ = build(1)
+    clips = []
+    for sd in (300, 301, 302):
+        b = synth.stage4_batch(sd, 1)
+        b["face_bbox"] = synth.stage4_batch(300, 1)["face_bbox"]          # one key: the boxes are kernel arguments
+        clips.append(_to_dev(b, "cuda"))
+    seq = [0, 1, 2, 0, 1, 2, 0]
+    for tr in (tr1, tr2):
+        for _ in range(2):
+            tr.train_step(clips[0], next_batch=clips[0])
+    eager = []
+    for i in range(len(seq) - 1):
+        o = tr1.train_step(clips[seq[i]], next_batch=clips[seq[i + 1]])
+        eager.append({k: float(o[k].reshape(-1)[0]) for k in LOSSES})
+    assert abs(eager[0]["vgg_l1"] - eager[1]["vgg_l1"]) > 0.1 * abs(eager[0]["vgg_l1"]) or \
+        abs(eager[1]["vgg_l1"] - eager[2]["vgg_l1"]) > 0.1 * abs(eager[1]["vgg_l1"]), "the clips must be told apart by their loss"
+    for i in range(len(seq) - 1):
+        o = tr2.train_step_graphed(clips[seq[i]], next_batch=clips[seq[i + 1]])
+        torch.cuda.synchronize()
+        for k in ("total_loss", "vgg_l1"):
+            a, b = eager[i][k], float(o[k].reshape(-1)[0])
+            assert abs(a - b) <= (2e-3 if i < 4 else 5e-3) * max(1.0, abs(a)), (i, k, a, b)
+        if i >= 2:                                   # replays: the static buffers hold the clip that was passed / staged
+            g = next(iter(tr2._graphs.values()))
+            for k, v in g.cur.items():
+                if isinstance(v, torch.Tensor):
+                    assert torch.equal(v, clips[seq[i]][k]), (i, k)
+                    assert torch.equal(g.nxt[k], clips[seq[i + 1]][k]), (i, k)
+    g = next(iter(tr2._graphs.values()))
+    assert g.replays == len(seq) - 3 and g.resyncs == 0
+    # out of sequence: the clip passed now is not the one staged by the previous call
+    o = tr2.train_step_graphed(clips[2], next_batch=clips[1])
+    torch.cuda.synchronize()
+    assert g.resyncs == 1
+    for k, v in g.cur.items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(v, clips[2][k]), k
+    o_e = tr1.train_step(clips[2], next_batch=clips[1])
+    for k in ("total_loss", "vgg_l1"):
+        a, b = float(o_e[k].reshape(-1)[0]), float(o[k].reshape(-1)[0])
+        assert abs(a - b) <= 5e-3 * max(1.0, abs(a)), (k, a, b)

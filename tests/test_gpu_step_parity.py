@@ -115,6 +115,21 @@ def test_train_step_bf16_gradients():
     print("bf16 B=2 frame rel-L2 %.3e" % rel_l2(out["final_output"].cpu(), torch.from_numpy(gold["final_output"])))
 
 
+def test_train_step_bf16_gradients_b8():
+    """The exact benchmarked configuration (BASELINE configs[2]: B=8, bf16 matrix-core arithmetic) against the fp32 oracle's
+    B=8 fixture: frame, losses, per-module gradients, BatchNorm buffers at the bf16 bars."""
+    from jafpro_amd import ops
+    M, tr, _, batch, dbatch, mods = build(8, seed=328)
+    prev = ops.set_precision("bf16")
+    try:
+        out = tr.train_step(dbatch)
+    finally:
+        ops.set_precision(prev)
+    gold = check_step_golden("s328_b8", out, mods, frame_tol=1e-1, loss_tol=2e-2, grad_bars=BF16_GRAD_BARS, bn_tol=5e-2,
+                             tag="bf16 B=8")
+    print("bf16 B=8 frame rel-L2 %.3e" % rel_l2(out["final_output"].cpu(), torch.from_numpy(gold["final_output"])))
+
+
 def test_train_step_bf16x3_is_parity_grade():
     """The split-bf16 mode (three bf16 MFMAs per product, forward, data AND weight gradients on the matrix cores) held to
     the fp32 bars of the full step: frame <= 1e-3 L-inf, losses 2e-3, per-module gradients at the B=1 bars above."""
@@ -160,11 +175,13 @@ def test_bf16_second_step_uses_refreshed_weight_images():
     assert not torch.equal(g0["final_output"], g_fresh["final_output"])
 
 
-def _run_ranks(tmp_path, world, precision, seed, used, prosrc, drop_face_rank=-1):
+def _run_ranks(tmp_path, world, precision, seed, used, prosrc, drop_face_rank=-1, backend="gloo"):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
+    env["JAF_RANK_BACKEND"] = backend            # "nccl" (= RCCL): one device per rank; "gloo": the ranks share device 0
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs, outs = [], []
     for r in range(world):
         outp = str(tmp_path / ("rank%d.pt" % r))
@@ -196,7 +213,21 @@ def test_two_rank_trainer_vs_chunked_oracle(tmp_path, drop_face_rank):
     mean over the faces that exist."""
     used, prosrc, seed = (0, 1, 2, 3), 1, 340
     res = _run_ranks(tmp_path, 2, "f32", seed, used, prosrc, drop_face_rank)
-    gold = golden_step("ranks2_s340" + ("_drop1" if drop_face_rank >= 0 else ""))
+    _check_two_ranks(res, golden_step("ranks2_s340" + ("_drop1" if drop_face_rank >= 0 else "")), drop_face_rank)
+
+
+def test_two_rank_trainer_rccl(tmp_path):
+    """The same two-rank step over RCCL (torch.distributed backend "nccl"), one MI355X per rank: the transport the
+    multi-GPU benchmark uses (train/4...py:123-162 -> jafpro_amd/dist.py).  Needs two devices; a 1-GPU box skips it
+    (device_count() does not initialise the GPU in the test process, the ranks are child processes)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL with N > 1 ranks needs >= 2 GPUs (this box has %d)" % torch.cuda.device_count())
+    res = _run_ranks(tmp_path, 2, "f32", 340, (0, 1, 2, 3), 1, -1, backend="nccl")
+    assert all(r["backend"] == "nccl" and r["device"] == i for i, r in enumerate(res))
+    _check_two_ranks(res, golden_step("ranks2_s340"), -1)
+
+
+def _check_two_ranks(res, gold, drop_face_rank):
     ix = step_index()
     for r in range(2):
         assert res[r]["overlap_order"] == ["flow", "refine", "inpaint", "accu"]
