@@ -159,6 +159,15 @@ int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* y, int32_t 
 int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
                           int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                           void* packed, float* dz, float* dbias);
+/* Same with the image's arithmetic given: JAF_PREC_BF16 (= jaf_conv2d_pack_dz_ex) or JAF_PREC_BF16X3, the split image of
+ * the parity-grade mode -- every group of 8 channels as TWO planes, hi = bf16(dz) and right behind it lo = bf16(dz - hi)
+ * (twice the bytes; y_packed must be null) -- which jaf_conv2d_fwd_packed_io consumes when its descriptor says JAF_PREC_BF16X3
+ * (csrc/conv_dma_split.hip: three matrix-core instructions per operand pair).  jaf_conv2d_pack_input /
+ * jaf_conv2d_pack_input_resized / jaf_conv2d_packed_input_bytes take the same switch from d->precision.  No reference
+ * counterpart: the reference computes in fp32 (src/networks.py:868-878 and every other nn.Conv2d of the path).           */
+int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                            int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                            void* packed, float* dz, float* dbias, int precision);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
  * [N][G][4C/8][H*W][8], CHANNEL-MAJOR: packed channel 4*c + gate (one item = 2 hidden channels x i,f,o,g; its consumers:
  * jaf_conv2d_pack(JAF_PACK_DGRAD_LSTM) + jaf_conv2d_fwd_packed_io for d[x, h], jaf_conv2d_wgrad_packed_lstm for dW), and

@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libjafpro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["conv.hip", "conv_bf16.hip", "conv_dma.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_dma.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
+SOURCES = ["conv.hip", "conv_bf16.hip", "conv_dma.hip", "conv_dma_split.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_dma.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
            "raster.hip", "raster_bwd.hip", "raster_texture.hip", "linear.hip", "ubench.hip", "input_pipeline.hip", "metrics.hip"]
 # raster.hip must keep the reference's fp32 expression trees (no FMA contraction): see its header.
 EXTRA = {"raster.hip": ["-ffp-contract=off"], "raster_bwd.hip": ["-ffp-contract=off"], "raster_texture.hip": ["-ffp-contract=off"]}
@@ -32,7 +32,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-re
 
 def _digest(path: str, flags) -> str:
     h = hashlib.sha256()
-    for p in (path, os.path.join(CSRC, "jaf_common.h"), os.path.join(CSRC, "conv_internal.h"),
+    for p in (path, os.path.join(CSRC, "jaf_common.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(CSRC, "conv_dma_kernel.h"),
               os.path.join(HERE, "..", "include", "jafpro_hip.h")):
         with open(p, "rb") as f:
             h.update(f.read())

@@ -17,60 +17,7 @@
 #include "conv_internal.h"
 #include <stdlib.h>
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#define CD_OOB 0x40000000
-#define CD_RPW 2          // patch DMA rounds per wave (4 waves x 2 rounds x 64 lanes = 512 slots max)
-
-struct ConvDArgs {
-    const unsigned char* xp;       // packed input
-    const unsigned char* wpk;      // packed weights (jaf_conv2d_pack, bf16 image order)
-    const float* bias;
-    float* out;
-    const float* c_prev;
-    float* c_out;
-    float* h_out;
-    float* gates_out;
-    jaf_conv_desc d;
-    jaf_conv_plan p;
-    int off_w, off_tab;
-    int ntiles, ngroups8;
-    float inv_pwp, inv_pwq, inv_twin;
-    int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
-    int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
-    double* stats;     // nullable: [N][slots][2] += (sum, sum of squares) of the image's outputs (act NONE, G == 1):
-    int stat_slots;    // the statistics pass of the LayerNorm that follows, taken while the values are in registers
-    // packed-image plumbing (jaf_packed_io): the input image may have more planes per (image, group) than this layer
-    // reads, and the epilogue may write its (activated) outputs straight into the consumer's packed bf16 image
-    int in_ng8;            // planes per (image, group) of the INPUT image (>= ngroups8)
-    unsigned char* dst;    // destination packed image (nullable)
-    int dst_ng8, dst_coff, dst_img_off, dst_pad_tail;
-    int skip_f32;          // the fp32 output tensor is not written (nobody reads it)
-    int acc_out;           // out += result (jaf_packed_io.accumulate_f32)
-    float* out2;           // rows >= split of every group go here (jaf_packed_io.out2); nullptr: everything to `out`
-    int split;
-    // fused activation backward (jaf_packed_io.dz_mask): `dst` receives dz = (acc [+ *out]) * act'(x) of the PRODUCER layer
-    const unsigned char* dz_mask;
-    int dz_mask_ng8, dz_mask_coff;
-    float dz_slope;
-    float* dz_dbias;
-};
-
-// Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
-// planes: 2 bytes at ((ng*ng8 + dc/8)*HW + pix)*16 + (dc%8)*2.
-__device__ __forceinline__ unsigned char* cd_dst_ptr(unsigned char* base, long ng, int ng8, int dc, int OHW, int pix) {
-    return base + ((ng * ng8 + (dc >> 3)) * (long)OHW + pix) * 16 + (dc & 7) * 2;
-}
-
-__device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
-    f32x2 v = {a, b};
-    bf16x2 r = __builtin_convertvector(v, bf16x2);
-    return __builtin_bit_cast(unsigned int, r);
-}
+#include "conv_dma_kernel.h"
 
 // ---------------------------------------------------------------------------------------------
 // input packing: fp32 NCHW (up to three concatenated sources, grouped) -> bf16 [n][g][group8][y][x][8]
@@ -81,7 +28,29 @@ struct PackInArgs {
     unsigned char* out;
     jaf_conv_desc d;
     int ngroups8;
+    int split;             // d.precision == JAF_PREC_BF16X3: every group of 8 channels gets TWO planes, hi = bf16(v) and right behind
+                           // it lo = bf16(v - hi): [n][g][group8][hi, lo][y][x][8] (the operand images of conv_dma_split.hip)
 };
+
+// One pixel's 8 channels as a packed item; `lo`: the residual item v - bf16(v) of the split-bf16 images.
+__device__ __forceinline__ u32x4 cd_item8(float v0, float v1, float v2, float v3, float v4, float v5, float v6, float v7, bool lo) {
+    if (lo) {
+        v0 -= (float)(__bf16)v0; v1 -= (float)(__bf16)v1; v2 -= (float)(__bf16)v2; v3 -= (float)(__bf16)v3;
+        v4 -= (float)(__bf16)v4; v5 -= (float)(__bf16)v5; v6 -= (float)(__bf16)v6; v7 -= (float)(__bf16)v7;
+    }
+    u32x4 w;
+    w[0] = cd_pack2(v0, v1);
+    w[1] = cd_pack2(v2, v3);
+    w[2] = cd_pack2(v4, v5);
+    w[3] = cd_pack2(v6, v7);
+    return w;
+}
+
+// Byte offset of item (pixel `pix`) of plane `cg` of (image, group) `ng` in an image of `ng8` channel groups; split images
+// hold the hi plane of a group at 2 cg and its lo plane at 2 cg + 1.
+__device__ __forceinline__ long cd_item_off(long ng, int ng8, int cg, long HW, long pix, int split) {
+    return split ? (((ng * ng8 + cg) * 2) * HW + pix) * 16 : ((ng * ng8 + cg) * HW + pix) * 16;
+}
 
 template <int V>
 __global__ void conv_pack_input_kernel(const PackInArgs a) {
@@ -122,15 +91,11 @@ __global__ void conv_pack_input_kernel(const PackInArgs a) {
             }
         }
     }
-    unsigned char* o = a.out + ((((long)n * d.G + g) * a.ngroups8 + cg) * HW + (long)y * d.W + x) * 16;
+    unsigned char* o = a.out + cd_item_off((long)n * d.G + g, a.ngroups8, cg, HW, (long)y * d.W + x, a.split);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        u32x4 w;
-        w[0] = cd_pack2(v[0][i], v[1][i]);
-        w[1] = cd_pack2(v[2][i], v[3][i]);
-        w[2] = cd_pack2(v[4][i], v[5][i]);
-        w[3] = cd_pack2(v[6][i], v[7][i]);
-        *(u32x4*)(o + i * 16) = w;
+        *(u32x4*)(o + i * 16) = cd_item8(v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i], false);
+        if (a.split) *(u32x4*)(o + HW * 16 + i * 16) = cd_item8(v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i], true);
     }
 }
 
@@ -149,7 +114,7 @@ static bool pack_desc_ok(const jaf_conv_desc* d) {
 
 extern "C" int64_t jaf_conv2d_packed_input_bytes(const jaf_conv_desc* d) {
     if (!pack_desc_ok(d)) return -1;
-    return (int64_t)d->N * d->G * jaf_cdiv(d->Cin, 8) * d->H * d->W * 16;
+    return (int64_t)d->N * d->G * jaf_cdiv(d->Cin, 8) * d->H * d->W * 16 * (d->precision == JAF_PREC_BF16X3 ? 2 : 1);
 }
 
 extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
@@ -162,6 +127,7 @@ extern "C" int jaf_conv2d_pack_input(jaf_stream_t s, const jaf_conv_desc* d, con
     a.out = (unsigned char*)packed;
     a.d = *d;
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
+    a.split = d->precision == JAF_PREC_BF16X3 ? 1 : 0;
     const long nz = (long)d->N * d->G * a.ngroups8;
     if (nz > 65535 || d->H > 65535) return JAF_EUNSUPPORTED;
     const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
@@ -247,12 +213,9 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_kernel(const PackLaz
             }
         }
     }
-    u32x4 w;
-    w[0] = cd_pack2(v[0], v[1]);
-    w[1] = cd_pack2(v[2], v[3]);
-    w[2] = cd_pack2(v[4], v[5]);
-    w[3] = cd_pack2(v[6], v[7]);
-    *(u32x4*)(a.b.out + ((((long)n * d.G + g) * a.b.ngroups8 + cg) * HW + (long)y * d.W + x) * 16) = w;
+    unsigned char* o = a.b.out + cd_item_off((long)n * d.G + g, a.b.ngroups8, cg, HW, (long)y * d.W + x, a.b.split);
+    *(u32x4*)o = cd_item8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], false);
+    if (a.b.split) *(u32x4*)(o + HW * 16) = cd_item8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], true);
 }
 
 // The same packing with the low-resolution source tiles staged through LDS: a 64 x 16 output tile of an up-sampled source
@@ -444,15 +407,11 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const Pac
                 }
             }
         }
-        unsigned char* o = a.b.out + ((((long)n * d.G + g) * a.b.ngroups8 + cg) * HW + (long)y * d.W + x) * 16;
+        unsigned char* o = a.b.out + cd_item_off((long)n * d.G + g, a.b.ngroups8, cg, HW, (long)y * d.W + x, a.b.split);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            u32x4 w;
-            w[0] = cd_pack2(v[0][i], v[1][i]);
-            w[1] = cd_pack2(v[2][i], v[3][i]);
-            w[2] = cd_pack2(v[4][i], v[5][i]);
-            w[3] = cd_pack2(v[6][i], v[7][i]);
-            *(u32x4*)(o + i * 16) = w;
+            *(u32x4*)(o + i * 16) = cd_item8(v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i], false);
+            if (a.b.split) *(u32x4*)(o + HW * 16 + i * 16) = cd_item8(v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i], true);
         }
     }
 }
@@ -468,6 +427,7 @@ extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc
     a.b.out = (unsigned char*)packed;
     a.b.d = *d;
     a.b.ngroups8 = jaf_cdiv(d->Cin, 8);
+    a.b.split = d->precision == JAF_PREC_BF16X3 ? 1 : 0;
     for (int i = 0; i < 3; ++i) {
         a.lazy[i] = (i < d->nsrc && src_h[i] > 0) ? 1 : 0;
         a.sh[i] = a.lazy[i] ? src_h[i] : 1;
@@ -528,6 +488,7 @@ struct PackDzArgs {
     float* dbias;          // [G*C] += sum over n, pixels (nullable)
     int N, G, C, H, W, ngroups8, act;
     float slope;
+    int split;             // split-bf16 image (hi and lo planes per channel group): see PackInArgs
 };
 
 __device__ __forceinline__ float dz_of(float g, float yv, int act, float slope) {
@@ -596,15 +557,11 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
         }
     }
     if (live) {
-        unsigned char* o = a.out + ((((long)n * a.G + g) * a.ngroups8 + cg) * HW + (long)yy * a.W + x) * 16;
+        unsigned char* o = a.out + cd_item_off((long)n * a.G + g, a.ngroups8, cg, HW, (long)yy * a.W + x, a.split);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            u32x4 w;
-            w[0] = cd_pack2(v[0][i], v[1][i]);
-            w[1] = cd_pack2(v[2][i], v[3][i]);
-            w[2] = cd_pack2(v[4][i], v[5][i]);
-            w[3] = cd_pack2(v[6][i], v[7][i]);
-            *(u32x4*)(o + i * 16) = w;
+            *(u32x4*)(o + i * 16) = cd_item8(v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i], false);
+            if (a.split) *(u32x4*)(o + HW * 16 + i * 16) = cd_item8(v[0][i], v[1][i], v[2][i], v[3][i], v[4][i], v[5][i], v[6][i], v[7][i], true);
         }
     }
     if (a.dbias) {
@@ -632,7 +589,14 @@ extern "C" int jaf_conv2d_pack_dz(jaf_stream_t s, const float* dy, const float* 
 extern "C" int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
                                      int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                                      void* packed, float* dz, float* dbias) {
+    return jaf_conv2d_pack_dz_prec(s, dy, y, y_packed, y_ng8_tot, y_coff, N, G, C, H, W, act, slope, packed, dz, dbias, JAF_PREC_BF16);
+}
+
+extern "C" int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                                       int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                                       void* packed, float* dz, float* dbias, int precision) {
     JAF_REQUIRE(dy && packed && N >= 1 && G >= 1 && C >= 1 && H >= 1 && W >= 1);
+    JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
     JAF_REQUIRE(act == JAF_ACT_NONE || y || y_packed);
     // y from the packed image: only its sign is used (ReLU / LeakyReLU), which bf16 rounding keeps
     JAF_REQUIRE(!y_packed || ((act == JAF_ACT_LRELU || act == JAF_ACT_RELU) && y_coff >= 0 && (y_coff & 7) == 0 &&
@@ -640,6 +604,8 @@ extern "C" int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const floa
     PackDzArgs a;
     a.dy = dy; a.y = y; a.out = (unsigned char*)packed; a.dz = dz; a.dbias = dbias;
     a.yp = (const unsigned char*)y_packed; a.yp_ng8 = y_ng8_tot; a.yp_cg0 = y_coff / 8;
+    a.split = precision == JAF_PREC_BF16X3 ? 1 : 0;
+    JAF_REQUIRE(!(a.split && y_packed));        // (the sign image of a split-mode layer is not a plain bf16 image)
     const bool al = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
     if (al && W % 4 != 0 && ((long)H * W) % 4 == 0 && (long)H * W < (1L << 30)) { W = H * W; H = 1; }   // as in jaf_conv2d_pack_input
     a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;
@@ -793,405 +759,6 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
     else { if (v4) JAF_LGC(4, float); else if (v2) JAF_LGC(2, float); else JAF_LGC(1, float); }
 #undef JAF_LGC
     return jaf_launch_status();
-}
-
-// ---------------------------------------------------------------------------------------------
-// epilogue
-// ---------------------------------------------------------------------------------------------
-// DZ: the fused activation backward of jaf_packed_io.dz_mask.  A template parameter, not a run-time branch: with the dz
-// code in every instantiation the compiler kept its extra live ranges in ALL of them (conv_dma_kernel<4,4,false>: 160 -> 192
-// VGPRs, 3 -> 2 waves per SIMD, 9.5 -> 11.0 ms per step over its 94 launches).
-template <int MT, int NT, bool LSTM, bool DZ, bool PLAIN>
-__device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
-                                            int n, int g, int mb, int q, int OHW, unsigned char* smem,
-                                            const f32x4 (&cpre)[MT]) {
-    const jaf_conv_desc& d = a.d;
-    constexpr int MR = 16 * MT;
-    if constexpr (PLAIN) {
-        // the launch writes ONE fp32 tensor and nothing else (no packed image, statistics, accumulation or second output):
-        // its own instantiation, so that the registers of those features are not carried through the matrix-core loop
-        typedef float pvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
-        const bool pv = a.vec && (NT > 1);
-#define CD_EPILOGUE_PLAIN(ACT_)                                                                       \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-                const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
-                if (co < d.Cout) {                                                                    \
-                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
-                    float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;  \
-                    if (pv) {                                                                         \
-                        if (opix[0] >= 0) {                                                           \
-                            pvec o;                                                                   \
-                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
-                                o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
-                            *(pvec*)(op + opix[0]) = o;                                               \
-                        }                                                                             \
-                    } else {                                                                          \
-                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
-                            if (opix[nt] >= 0) op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope); \
-                    }                                                                                 \
-                }                                                                                     \
-            }                                                                                         \
-        }
-        switch (d.act) {
-            case JAF_ACT_LRELU: CD_EPILOGUE_PLAIN(JAF_ACT_LRELU) break;
-            case JAF_ACT_RELU: CD_EPILOGUE_PLAIN(JAF_ACT_RELU) break;
-            case JAF_ACT_SIGMOID: CD_EPILOGUE_PLAIN(JAF_ACT_SIGMOID) break;
-            case JAF_ACT_TANH: CD_EPILOGUE_PLAIN(JAF_ACT_TANH) break;
-            default: CD_EPILOGUE_PLAIN(JAF_ACT_NONE) break;
-        }
-#undef CD_EPILOGUE_PLAIN
-        return;
-    }
-    // ---- epilogue (D layout: column lane&15 = pixel, row (lane>>4)*4 + reg = output channel).
-    // With the pixel interleave a lane's NT tiles are NT consecutive pixels: one vector access. ----
-    typedef float fvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
-    typedef __bf16 hvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
-    const bool vec = a.vec && (NT > 1);
-    if (!LSTM) {
-        float st1 = 0.f, st2 = 0.f;     // LayerNorm statistics of this lane's outputs (ACT NONE + a.stats only)
-        if (a.dst) {
-            // The lane's 4 rows of a tile are 4 consecutive output channels = half of a 16-byte packed item
-            // (dst_coff % 4 == 0); lanes q and q^1 complete the item within the same store instruction.
-            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
-            // dz mode with a second fp32 output (the ConvLSTM's d[x_t, h_{t-1}] launch): only the rows below `split` (dx) are the
-            // producer's dz; the rows from `split` on (dh) leave through out2 as always
-            const int dC = (DZ && a.out2) ? a.split : d.Cout;
-            float wsum[MT][4];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wsum[mt][j] = 0.f;
-            const int cpad = a.dst_pad_tail ? ((a.dst_coff + dC + 7) & ~7) - a.dst_coff : dC;   // rows < cpad are written
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int co0 = mb * MR + mt * 16 + q * 4;
-                if (co0 >= cpad) continue;
-                float bv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bv[j] = (a.bias && co0 + j < d.Cout) ? a.bias[g * d.Cout + co0 + j] : 0.f;
-                float bsum[4] = {0.f, 0.f, 0.f, 0.f};     // dz mode: this lane's share of the producer's bias gradient
-                // dz mode: the sign masks of the lane's NT pixels, requested together and ahead of the first consumer's gradient
-                // (inside the pixel loop each 8-byte load sat behind the previous pixel's store: the compiler cannot move a
-                // load above a store to a pointer that may alias it)
-                unsigned int mk[NT][2];
-                if (DZ) {
-                    const long ngm = ((long)n) * d.G + g;
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        mk[nt][0] = mk[nt][1] = 0u;
-                        if (opix[nt] >= 0) {
-                            const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
-                                                                                      a.dz_mask_coff + co0, OHW, opix[nt]);
-                            mk[nt][0] = xp2[0];
-                            mk[nt][1] = xp2[1];
-                        }
-                    }
-                }
-                // dz mode, second of two consumers: the first one's gradient, 4 channels x NT pixels (one vector load per
-                // channel when the lane's pixels are consecutive)
-                float part[4][NT];
-                if (DZ && a.acc_out) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) part[j][nt] = 0.f;
-                        if (co0 + j < dC) {
-                            const float* pp = a.out2 ? a.out + (((long)n * d.G + g) * a.split + co0 + j) * OHW
-                                                     : a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co0 + j) * OHW;
-                            if (vec) {
-                                if (opix[0] >= 0) {
-                                    const fvec pv = *(const fvec*)(pp + opix[0]);
-#pragma unroll
-                                    for (int nt = 0; nt < NT; ++nt) part[j][nt] = pv[nt];
-                                }
-                            } else {
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    if (opix[nt] >= 0) part[j][nt] = pp[opix[nt]];
-                            }
-                        }
-                    }
-                }
-                // Whole 16-byte items: row groups q and q^1 hold the two halves (channels +0..3 / +4..7) of the same item for the same
-                // NT pixels.  With 4 pixels per lane they exchange halves -- v_permlane16_swap: the even group keeps pixels 0, 1, the odd
-                // one takes pixels 2, 3 -- and every lane issues two 16-byte stores instead of four 8-byte ones (the epilogue is
-                // store-issue bound; measured on the fused-dz launches: the 8-byte stores were 8-25 % of the kernel).  Needs the
-                // pair's 8 channels inside the written range and the slot on an item boundary; no lane of the pair may leave early.
-                const bool pair_ok = (NT == 4) && ((a.dst_coff & 7) == 0) && ((co0 & ~4) + 8 <= cpad);
-                unsigned int wl[NT], wh[NT];       // the lane's 8 bytes per pixel, as scalars (see the ConvLSTM transpose below)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    wl[nt] = wh[nt] = 0u;
-                    const bool pv = opix[nt] >= 0;
-                    if (!pv && !pair_ok) continue;
-                    float v[4];
-                    if (DZ) {
-                        // producer's dz: (this data gradient [+ the first consumer's]) * act'(x), x from the packed image the
-                        // consumer layer read (4 consecutive channels = 8 bytes of a 16-byte item)
-                        const unsigned int x01 = mk[nt][0], x23 = mk[nt][1];
-                        const float xs[4] = {__builtin_bit_cast(float, x01 << 16), __builtin_bit_cast(float, x01 & 0xffff0000u),
-                                             __builtin_bit_cast(float, x23 << 16), __builtin_bit_cast(float, x23 & 0xffff0000u)};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float t = 0.f;
-                            if (pv && co0 + j < dC) {
-                                t = acc[mt][nt][j];
-                                if (a.acc_out) t += part[j][nt];
-                                t *= (xs[j] > 0.f) ? 1.f : a.dz_slope;
-                            }
-                            v[j] = t;
-                            bsum[j] += t;
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (co0 + j < d.Cout) ? jaf_act(acc[mt][nt][j] + bv[j], d.act, d.slope) : 0.f;
-                    }
-                    wl[nt] = cd_pack2(v[0], v[1]);
-                    wh[nt] = cd_pack2(v[2], v[3]);
-                    if (pair_ok) continue;
-                    if (co0 + 4 <= cpad || a.dst_pad_tail) {
-                        const u32x2 w = {wl[nt], wh[nt]};
-                        *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]) = w;
-                    } else {           // a 4-group that straddles the end of this source: channel by channel
-                        unsigned short* hp = (unsigned short*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]);
-                        const unsigned int ww[2] = {wl[nt], wh[nt]};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (co0 + j < dC) hp[j] = (unsigned short)(ww[j >> 1] >> ((j & 1) * 16));
-                    }
-                }
-                if (pair_ok) {
-                    // (A, B) = (pixel 0, pixel 2) and (C, D) = (pixel 1, pixel 3): after the swaps an even group holds {own, partner's}
-                    // halves of pixels 0 and 1, an odd group {partner's, own} halves of pixels 2 and 3
-                    unsigned int a0 = wl[0], a1 = wh[0], b0 = wl[2 % NT], b1 = wh[2 % NT];
-                    unsigned int c0 = wl[1 % NT], c1 = wh[1 % NT], e0 = wl[3 % NT], e1 = wh[3 % NT];
-                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %2\n\tv_permlane16_swap_b32 %1, %3\n\t"
-                                 "v_permlane16_swap_b32 %4, %6\n\tv_permlane16_swap_b32 %5, %7\n\ts_nop 1"
-                                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(e0), "+v"(e1));
-                    const int pA = (q & 1) ? opix[2 % NT] : opix[0], pB = (q & 1) ? opix[3 % NT] : opix[1 % NT];
-                    const int cbase = a.dst_coff + (co0 & ~4);
-                    if (pA >= 0) {
-                        const u32x4 w = {a0, a1, b0, b1};
-                        *(u32x4*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, cbase, OHW, pA) = w;
-                    }
-                    if (pB >= 0) {
-                        const u32x4 w = {c0, c1, e0, e1};
-                        *(u32x4*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, cbase, OHW, pB) = w;
-                    }
-                }
-                if (DZ && a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float t = bsum[j];
-                        t += __shfl_xor(t, 1); t += __shfl_xor(t, 2); t += __shfl_xor(t, 4); t += __shfl_xor(t, 8);
-                        wsum[mt][j] = t;
-                    }
-                }
-            }
-            if (DZ && a.dz_dbias) {
-                // workgroup sum of the four waves in LDS (the patch buffer is free once every wave has left the matrix-core
-                // loop), then ONE atomic per channel and workgroup, spread over JAF_DZ_BIAS_SLOTS copies of the vector
-                // (same-address fp32 atomics serialise: one per wave and channel made these launches 3x slower)
-                __syncthreads();
-                float* red = (float*)smem;                      // [4 waves][MT * 16 rows]
-                if ((threadIdx.x & 15) == 0) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) red[(threadIdx.x >> 6) * (MT * 16) + mt * 16 + q * 4 + j] = wsum[mt][j];
-                }
-                __syncthreads();
-                if (threadIdx.x < MT * 16) {
-                    const int co = mb * MR + threadIdx.x;
-                    const float t = (red[threadIdx.x] + red[MT * 16 + threadIdx.x]) + (red[2 * MT * 16 + threadIdx.x] + red[3 * MT * 16 + threadIdx.x]);
-                    if (co < dC && t != 0.f)
-                        atomicAdd(&a.dz_dbias[(long)(blockIdx.x % JAF_DZ_BIAS_SLOTS) * (d.G * dC) + g * dC + co], t);
-                }
-            }
-        }
-        if (a.skip_f32 || (DZ && !a.out2)) return;
-#define CD_EPILOGUE(ACT_, ST_)                                                                        \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-                const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
-                if (co < d.Cout && !(DZ && co < a.split)) {      /* (dz rows went to `dst`) */  \
-                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
-                    const bool second = a.out2 && co >= a.split;                                      \
-                    float* op = second ? a.out2 + (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW \
-                                       : (a.out2 ? a.out + (((long)n * d.G + g) * a.split + co) * OHW        \
-                                                 : a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW);  \
-                    const bool accp = a.acc_out && !second;                                           \
-                    if (vec) {                                                                        \
-                        if (opix[0] >= 0) {                                                           \
-                            fvec o;                                                                   \
-                            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
-                                o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
-                            if (accp) o += *(const fvec*)(op + opix[0]);                              \
-                            *(fvec*)(op + opix[0]) = o;                                               \
-                            if (ST_) {                                                                \
-                                _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { st1 += o[nt]; st2 += o[nt] * o[nt]; } \
-                            }                                                                         \
-                        }                                                                             \
-                    } else {                                                                          \
-                        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
-                            if (opix[nt] >= 0) {                                                      \
-                                float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                 \
-                                if (accp) v += op[opix[nt]];                                          \
-                                op[opix[nt]] = v;                                                     \
-                                if (ST_) { st1 += v; st2 += v * v; }                                  \
-                            }                                                                         \
-                    }                                                                                 \
-                }                                                                                     \
-            }                                                                                         \
-        }
-        switch (d.act) {     // hoisted: one tight copy of the store loop per activation
-            case JAF_ACT_LRELU: CD_EPILOGUE(JAF_ACT_LRELU, 0) break;
-            case JAF_ACT_RELU: CD_EPILOGUE(JAF_ACT_RELU, 0) break;
-            case JAF_ACT_SIGMOID: CD_EPILOGUE(JAF_ACT_SIGMOID, 0) break;
-            case JAF_ACT_TANH: CD_EPILOGUE(JAF_ACT_TANH, 0) break;
-            default:
-                if (a.stats) { CD_EPILOGUE(JAF_ACT_NONE, 1) } else { CD_EPILOGUE(JAF_ACT_NONE, 0) }
-                break;
-        }
-#undef CD_EPILOGUE
-        if (a.stats) {      // uniform: wave sums -> LDS -> one pair of fp64 atomics per workgroup, spread over slots
-            st1 = jaf_wave_sum(st1);
-            st2 = jaf_wave_sum(st2);
-            __syncthreads();                      // every wave has left the MFMA loop: the patch buffer is free
-            float* red = (float*)smem;
-            if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = st1; red[2 * (threadIdx.x >> 6) + 1] = st2; }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double* w = a.stats + ((long)n * a.stat_slots + (blockIdx.x % a.stat_slots)) * 2;
-                atomicAdd(w, (double)((red[0] + red[2]) + (red[4] + red[6])));
-                atomicAdd(w + 1, (double)((red[1] + red[3]) + (red[5] + red[7])));
-            }
-        }
-    } else {
-        const int C = d.Cout >> 2;   // hidden channels per group (rows are gate-interleaved: 4c+gate)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int ch = ((mb * MR + mt * 16) >> 2) + q;
-            if (ch >= C) continue;
-            const float* bp = a.bias + g * d.Cout;
-            const float bi = bp[ch], bf = bp[C + ch], bo = bp[2 * C + ch], bg = bp[3 * C + ch];
-            const long hc = (((long)n * d.G + g) * C + ch) * OHW;
-            const long gc = ((long)n * d.G + g) * d.Cout * (long)OHW;
-            if (vec) {
-                // NT == 4 with a packed destination: no lane leaves before the 4 x 4 lane transpose of h below (a lane group's 4
-                // consecutive pixels are valid or invalid together; dead lanes compute on zeros and store nothing).  Hidden channels
-                // in whole groups of 4 (every real layer): the `ch >= C` exit above is then uniform over the four row groups.
-                const bool live = opix[0] >= 0;
-                const bool xpose = (NT == 4) && a.dst && (C & 3) == 0;
-                if (!live && !xpose) continue;
-                fvec cp, vi, vf, vo, vg, vc, vh;
-                float hs4[4] = {0.f, 0.f, 0.f, 0.f};     // h of the lane's pixels as scalars (see the transpose below)
-                if (a.c_prev) {
-                    if (NT == 4) {                      // fetched before the matrix-core loop (conv_dma_kernel): no exposed latency here
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) cp[nt] = cpre[mt][nt & 3];
-                    } else {
-                        cp = *(const fvec*)(a.c_prev + hc + opix[0]);
-                    }
-                }
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    vi[nt] = jaf_sigmoid(acc[mt][nt][0] + bi);
-                    vf[nt] = jaf_sigmoid(acc[mt][nt][1] + bf);
-                    vo[nt] = jaf_sigmoid(acc[mt][nt][2] + bo);
-                    vg[nt] = jaf_tanh(acc[mt][nt][3] + bg);
-                    const float c_old = a.c_prev ? cp[nt] : 0.f;
-                    vc[nt] = vf[nt] * c_old + vi[nt] * vg[nt];
-                    vh[nt] = vo[nt] * jaf_tanh(vc[nt]);
-                    hs4[nt & 3] = vh[nt];
-                }
-                if (live) {
-                    *(fvec*)(a.c_out + hc + opix[0]) = vc;
-                    if (!a.skip_f32) *(fvec*)(a.h_out + hc + opix[0]) = vh;
-                }
-                if (a.dst) {     // h_t straight into the consumer's packed image (next step's [x, h] / the decoder's skip)
-                    const long ngd = ((long)(n + a.dst_img_off)) * d.G + g;
-                    if (xpose) {
-                        // the 4 row groups (q) of a lane column hold channels cb .. cb+3 of the same 4 pixels: a 4 x 4 transpose over
-                        // (q, pixel) -- two v_permlane32_swap + two v_permlane16_swap -- gives every lane 4 consecutive channels of
-                        // ONE pixel = 8 contiguous bytes of its packed item: 1 store instead of 4 two-byte ones (12 -> 3 per lane).
-                        // From assembly and from scalar copies of h: fed with elements of the float4 `vh`, this compiler passed ONE
-                        // register as all four operands (builtins and assembly alike; the sequence itself is verified in
-                        // profiles/experiments/swap_test*.hip).
-                        unsigned t0 = __builtin_bit_cast(unsigned, hs4[0]), t1 = __builtin_bit_cast(unsigned, hs4[1]);
-                        unsigned t2 = __builtin_bit_cast(unsigned, hs4[2]), t3 = __builtin_bit_cast(unsigned, hs4[3]);
-                        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %1, %3\n\ts_nop 1\n\t"
-                                     "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
-                                     : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-                        if (live) {
-                            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                            const u32x2 w = {cd_pack2(__builtin_bit_cast(float, t0), __builtin_bit_cast(float, t1)),
-                                             cd_pack2(__builtin_bit_cast(float, t2), __builtin_bit_cast(float, t3))};
-                            *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + (ch - q), OHW, opix[0] + q) = w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            *(__bf16*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt) = (__bf16)vh[nt];
-                    }
-                }
-                if (a.gates_out && live) {
-                    if (a.gates_bf16) {
-                        // bf16 gates are kept gate-innermost, [n][g][c][pixel][i, f, o, g]: the lane's NT pixels x 4 gates are
-                        // 8 NT contiguous bytes (two 16-byte stores at NT = 4 instead of four 8-byte ones; the epilogue is
-                        // store-issue bound) and the gate backward fetches a pixel pair's four gates with one 16-byte load
-                        typedef __bf16 g4vec __attribute__((ext_vector_type(NT == 1 ? 8 : 4 * NT)));
-                        typedef float f4vec __attribute__((ext_vector_type(NT == 1 ? 8 : 4 * NT)));
-                        f4vec gv;
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            gv[4 * nt] = vi[nt]; gv[4 * nt + 1] = vf[nt]; gv[4 * nt + 2] = vo[nt]; gv[4 * nt + 3] = vg[nt];
-                        }
-                        *(g4vec*)((__bf16*)a.gates_out + gc + ((long)ch * OHW + opix[0]) * 4) = __builtin_convertvector(gv, g4vec);
-                    } else {
-                        float* gp = a.gates_out + gc + opix[0];
-                        *(fvec*)(gp + (long)(ch)*OHW) = vi;
-                        *(fvec*)(gp + (long)(C + ch) * OHW) = vf;
-                        *(fvec*)(gp + (long)(2 * C + ch) * OHW) = vo;
-                        *(fvec*)(gp + (long)(3 * C + ch) * OHW) = vg;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    if (opix[nt] < 0) continue;
-                    const float gi = jaf_sigmoid(acc[mt][nt][0] + bi);
-                    const float gf = jaf_sigmoid(acc[mt][nt][1] + bf);
-                    const float go = jaf_sigmoid(acc[mt][nt][2] + bo);
-                    const float gg = jaf_tanh(acc[mt][nt][3] + bg);
-                    const float cp = a.c_prev ? a.c_prev[hc + opix[nt]] : 0.f;
-                    const float cc = gf * cp + gi * gg;
-                    a.c_out[hc + opix[nt]] = cc;
-                    const float hv = go * jaf_tanh(cc);
-                    if (!a.skip_f32) a.h_out[hc + opix[nt]] = hv;
-                    if (a.dst)
-                        *(__bf16*)cd_dst_ptr(a.dst, ((long)(n + a.dst_img_off)) * d.G + g, a.dst_ng8, a.dst_coff + ch, OHW, opix[nt]) = (__bf16)hv;
-                    if (a.gates_out) {
-                        if (a.gates_bf16) {
-                            __bf16* gp = (__bf16*)a.gates_out + gc + ((long)ch * OHW + opix[nt]) * 4;
-                            gp[0] = (__bf16)gi;
-                            gp[1] = (__bf16)gf;
-                            gp[2] = (__bf16)go;
-                            gp[3] = (__bf16)gg;
-                        } else {
-                            float* gp = a.gates_out + gc + opix[nt];
-                            gp[(long)(ch)*OHW] = gi;
-                            gp[(long)(C + ch) * OHW] = gf;
-                            gp[(long)(2 * C + ch) * OHW] = go;
-                            gp[(long)(3 * C + ch) * OHW] = gg;
-                        }
-                    }
-                }
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1409,7 +976,8 @@ static bool cd_desc_ok(const jaf_conv_desc* d) {
     if (d->w_cin_off < 0 || d->w_cin_tot < 1) return false;
     if (d->out_coff < 0 || d->out_coff + d->G * d->Cout > d->out_ctot) return false;
     if (d->pad_t < 0 || d->pad_l < 0) return false;
-    if (d->precision != JAF_PREC_BF16) return false;
+    // JAF_PREC_BF16X3: the same kernels' split-bf16 form (conv_dma_split.hip) over hi / lo operand images
+    if (d->precision != JAF_PREC_BF16 && d->precision != JAF_PREC_BF16X3) return false;
     return true;
 }
 
@@ -1430,6 +998,10 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     }
     const int groups = jaf_cdiv(d->Cin, 8);
     const long OHW = (long)d->OH * d->OW;
+    // split-bf16 (conv_dma_split.hip): hi and lo planes of the patch and of the weight image in LDS (twice the bytes), three
+    // matrix-core instructions per operand pair, two LDS reads per operand
+    const bool split = d->precision == JAF_PREC_BF16X3;
+    const int sb = split ? 2 : 1;
 
     double bestCost = 1e300;
     int bTW = 0, bNT = 0, bNG = 0, bMT = 0;
@@ -1471,13 +1043,13 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 const int ng_last = groups - (nchunks - 1) * NG;
                 const int nsteps = jaf_cdiv(taps * NG, 4);
                 const int nsteps_last = jaf_cdiv(taps * ng_last, 4);
-                const long lds = (long)NG * plane + (long)nsteps * MT * 1024 + 2L * 16 * nsteps * 4 + 64;
+                const long lds = (long)sb * NG * plane + (long)sb * nsteps * MT * 1024 + 2L * 16 * nsteps * 4 + 64;
                 if (lds > 150 * 1024) continue;
                 const double total_steps = (double)(nchunks - 1) * nsteps + nsteps_last;
-                const double mfma = (double)MT * NT * 16.0;
-                const double ldsrd = 4.0 * (MT + NT) * 4.0;
+                const double mfma = (double)MT * NT * 16.0 * (split ? 3.0 : 1.0);
+                const double ldsrd = 4.0 * (MT + NT) * 4.0 * sb;
                 const double t_step = (mfma > ldsrd ? mfma : ldsrd) + 40.0;
-                const double stage = 600.0 + ((double)npos * NG * 16.0 + (double)nsteps * MT * 1024.0) / 48.0;
+                const double stage = 600.0 + sb * ((double)npos * NG * 16.0 + (double)nsteps * MT * 1024.0) / 48.0;
                 const int blocks_cu = (int)(160 * 1024 / lds);
                 const int bl = blocks_cu > 6 ? 6 : blocks_cu;
                 // two resident workgroups do not overlap each other's phases (DMA, matrix cores and epilogue of
@@ -1517,7 +1089,7 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
         plan->tiles_x = 1;
         plan->tiles_p = jaf_cdiv(OHW, Pn);
     }
-    plan->precision = JAF_PREC_BF16;
+    plan->precision = d->precision;
     plan->MT = MT;
     plan->NT = bNT;
     plan->NG = bNG;
@@ -1537,13 +1109,15 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     plan->nsteps = jaf_cdiv(taps * bNG, 4);
     plan->nsteps_last = jaf_cdiv(taps * plan->ng_last, 4);
     plan->mblocks = jaf_cdiv(M, 16 * MT);
-    plan->lds_bytes = (int)((long)bNG * plan->plane + (long)plan->nsteps * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
-    plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * plan->nsteps * MT * 1024) / 4;
+    plan->lds_bytes = (int)((long)sb * bNG * plan->plane + (long)sb * plan->nsteps * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
+    // (split: the hi image and the residual image of every chunk, [chunk][image][k-step]: the layout jaf_conv2d_pack makes)
+    plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * sb * plan->nsteps * MT * 1024) / 4;
     return JAF_OK;
 }
 
 static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
-    if (!p || p->precision != JAF_PREC_BF16) return false;
+    if (!p || p->precision != d->precision) return false;
+    const int sb = d->precision == JAF_PREC_BF16X3 ? 2 : 1;
     if (p->MT < 1 || p->MT > 4) return false;
     if (p->NT != 1 && p->NT != 2 && p->NT != 4) return false;
     if (p->NG < 1 || p->NG > 4) return false;
@@ -1570,7 +1144,7 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     }
     if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
     if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
-    if (p->lds_bytes < p->NG * p->plane + p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
+    if (p->lds_bytes < sb * p->NG * p->plane + sb * p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
     if (p->lds_bytes > 160 * 1024) return false;
     if ((long)d->H * d->W * 16 >= CD_OOB) return false;
     return true;
@@ -1640,8 +1214,9 @@ static int cd_launch_mt(const ConvDArgs& a, hipStream_t s) {
 static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* plan) {
     a.d = *d;
     a.p = *plan;
-    a.off_w = plan->NG * plan->plane;
-    a.off_tab = a.off_w + plan->nsteps * plan->MT * 1024;
+    const int sb = d->precision == JAF_PREC_BF16X3 ? 2 : 1;        // split: [hi planes][lo planes][hi weights][lo weights][table]
+    a.off_w = sb * plan->NG * plan->plane;
+    a.off_tab = a.off_w + sb * plan->nsteps * plan->MT * 1024;
     a.ntiles = plan->tiles_x * plan->tiles_p;
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     a.inv_pwp = 1.0f / (float)plan->PWp;
@@ -1730,6 +1305,11 @@ extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, 
     a.out = out;
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
+    if (d->precision == JAF_PREC_BF16X3) {
+        // split-bf16: same epilogue, but no packed destination / sign image (those are plain bf16 images)
+        JAF_REQUIRE(!a.dst && !a.dz_mask);
+        return cd_split_launch(a, (hipStream_t)s, false);
+    }
     return cd_launch_mt<false>(a, (hipStream_t)s);
 }
 
@@ -1746,6 +1326,7 @@ extern "C" int jaf_conv2d_fwd_packed_stats(jaf_stream_t s, const jaf_conv_desc* 
     a.out = out;
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
+    if (d->precision == JAF_PREC_BF16X3) return cd_split_launch(a, (hipStream_t)s, false);
     return cd_launch_mt<false>(a, (hipStream_t)s);
 }
 
@@ -1782,5 +1363,9 @@ extern "C" int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_de
     a.h_out = h_out;
     a.gates_out = (float*)gates_out;
     a.gates_bf16 = gates_bf16 ? 1 : 0;
+    if (d->precision == JAF_PREC_BF16X3) {
+        JAF_REQUIRE(!a.dst);
+        return cd_split_launch(a, (hipStream_t)s, true);
+    }
     return cd_launch_mt<true>(a, (hipStream_t)s);
 }

@@ -257,12 +257,29 @@ def _fill_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
     return d
 
 
+# JAF_PREC_BF16X3 on the packed / DMA-staged kernels too (csrc/conv_dma_split.hip: hi + lo operand images, three matrix-core
+# instructions per product); JAF_NO_SPLIT_PACKED=1 keeps the fp32-input split kernels of conv_bf16.hip for A/B measurements
+_SPLIT_PACKED = os.environ.get("JAF_NO_SPLIT_PACKED") is None
+
+
+def _packed_prec(prec) -> bool:
+    return _USE_PACKED and (prec == PREC_BF16 or (prec == PREC_BF16X3 and _SPLIT_PACKED))
+
+
 def _packed_path_now() -> bool:
-    return _USE_PACKED and _PRECISION == PREC_BF16
+    return _packed_prec(_PRECISION)
 
 
 def _packed_path(d: ConvDesc) -> bool:
-    return _USE_PACKED and d.precision == PREC_BF16
+    return _packed_prec(d.precision)
+
+
+def _conv_kernel_name(pl, lstm: bool, dz: bool = False, plain: bool = False) -> str:
+    """The packed-path instantiation as rocprofv3 names it."""
+    if pl.precision == PREC_BF16X3:
+        return "conv_dma_split_kernel<%d, %d, %s>" % (pl.MT, pl.NT, "true" if lstm else "false")
+    return "conv_dma_kernel<%d, %d, %s, %s, %s>" % (pl.MT, pl.NT, "true" if lstm else "false", "true" if dz else "false",
+                                                   "true" if plain else "false")
 
 
 def _plan(key, d: ConvDesc, lstm: int, flags: int = 0) -> ConvPlan:
@@ -699,9 +716,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             # named as rocprofv3 names the instantiation jaf_conv2d_fwd_packed_io picks: <MT, NT, LSTM, DZ, PLAIN>
             plain = (dz_fuse is None and dst is None and sums is None and not accumulate and out2 is None and not skip_f32
                      and not _NO_PLAIN_CONV)
-            _PROF.end("conv_dma_kernel<%d, %d, false, %s, %s>" % (pl.MT, pl.NT, "true" if dz_fuse is not None else "false",
-                                                                  "true" if plain else "false"),
-                      2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
+            _PROF.end(_conv_kernel_name(pl, False, dz_fuse is not None, plain), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
     if accumulate or out2 is not None:
         raise RuntimeError("conv: accumulate / out2 are features of the packed bf16 path")
@@ -878,7 +893,8 @@ class _ConvFn(Function):
             xp is not None and use_img and m.dst is not None and m.dst.coff % 8 == 0 and m.act in (ACT_LRELU, ACT_RELU)
             and _Y_SIGN_FROM_IMAGE) or (y.stride(0) == 0 and y.numel() > 1) else None
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
-        ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
+        # (split-bf16: the weight gradient stays on the fp32-input split kernel, which reads the fp32 sources)
+        ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m) and _PRECISION == PREC_BF16) else None
         ctx.xp_ng8 = m.prepacked.ng8 if (use_img and m.prepacked is not None) else 0
         ctx.meta = m
         ctx.mode = (_PRECISION, _USE_PACKED)
@@ -926,9 +942,9 @@ class _ConvFn(Function):
             ctx.fused = None
             dz = None
             db_done = True
-        elif _USE_PACKED and _PRECISION == PREC_BF16:
+        elif _packed_path_now():
             # one pass: activation backward + bias gradient + packed bf16 dz (+ fp32 dz only if the
-            # weight gradient of this layer still runs on the fp32-input kernel)
+            # weight gradient of this layer still runs on the fp32-input kernel); split-bf16: hi and lo planes
             need_f32 = ctx.needs_input_grad[0] and ctx.xp is None
             dz = torch.empty_like(dy) if need_f32 else None
             dbt = None
@@ -939,7 +955,7 @@ class _ConvFn(Function):
                     dbt = db = torch.zeros(m.G * m.Cout, device=dy.device, dtype=torch.float32)
                 db_done = True
             ng8 = (m.Cout + 7) // 8
-            dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16, device=dy.device, dtype=torch.uint8)
+            dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16 * (2 if _PRECISION == PREC_BF16X3 else 1), device=dy.device, dtype=torch.uint8)
             yimg = getattr(ctx, "y_img", None)
             with _hbm("conv_pack_dz_kernel", dy.numel() * (4.0 + ((2.0 if yimg else 4.0) if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
                 per = dzp.numel() // m.N
@@ -952,9 +968,9 @@ class _ConvFn(Function):
                                                       _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
                                                       _p(dbt)), "jaf_conv2d_pack_dz_ex")
                         continue
-                    check(L.jaf_conv2d_pack_dz(_s(), _p(dy[n0:n1]), _p(y[n0:n1]) if m.act != ACT_NONE else None, n1 - n0, m.G, m.Cout,
-                                               m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
-                                               _p(dz[n0:n1]) if dz is not None else None, _p(dbt)), "jaf_conv2d_pack_dz")
+                    check(L.jaf_conv2d_pack_dz_prec(_s(), _p(dy[n0:n1]), _p(y[n0:n1]) if m.act != ACT_NONE else None, None, 0, 0,
+                                                    n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
+                                                    _p(dz[n0:n1]) if dz is not None else None, _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_prec")
         elif m.act != ACT_NONE:
             dz = torch.empty_like(dy)
             check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
@@ -1186,7 +1202,7 @@ class _ConvLSTMFn(Function):
                     xp = pack_input([x[t]] if first else [x[t], hprev], d)
                     if final_dst is not None and t + 1 == T and packed_active():
                         io = _io_struct(None, final_dst)
-                if keep:
+                if keep and d.precision == PREC_BF16:        # (the packed weight gradient reads them; split-bf16: fp32-input kernel)
                     xps.append(xp)
                 check(L.jaf_convlstm_cell_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
                                                         None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
@@ -1194,7 +1210,7 @@ class _ConvLSTMFn(Function):
                                                         ctypes.byref(io) if io is not None else None),
                       "jaf_convlstm_cell_fwd_packed_io")
                 if ev is not None:
-                    _PROF.end("conv_dma_kernel<%d, %d, true, false, false>" % (pl.MT, pl.NT), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                    _PROF.end(_conv_kernel_name(pl, True), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
                                           None if first else _p(hprev), _p(wpk), _p(bias),
@@ -1311,7 +1327,7 @@ class _ConvLSTMFn(Function):
                                                None if first else _p(cprev), _p(cs[t]), _p(dc_prev)),
                       "jaf_convlstm_gates_bwd")
                 ev = _PROF.begin() if _PROF is not None else None
-                if ctx.xps is not None and _packed_path(d):
+                if ctx.xps is not None and _packed_path(d) and d.precision == PREC_BF16:
                     gd = _make_desc(N, G, 4 * C, 1, H, W, H, W, 1, 1, 1, 0, 0, 1, gspec, 1, 0, G, 0, ACT_NONE, 0.0)
                     gtp = pack_input([gt], gd)
                     check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),

@@ -420,7 +420,7 @@ def test_graphed_step_trains_on_the_clip_it_is_given():
     """Distinct clips through the graph: call k with (B_k, B_k+1) must train on B_k with B_k's preparation and
     prepare B_k+1.  Three different clips of one geometry (same face boxes = same graph key) in a cycle, graphed against
     eager from the same weights: per-call losses agree (a step on the wrong clip, or one clip's textures with another's
-    background / flow / perceptual target, is off by O(1): the clips' losses differ by more than 10 %), the graph's `cur`
+    background / flow / perceptual target, is off by several times the bar: the clips' losses are 1.4-2.3 % apart), the graph's `cur`
     buffers hold the clip that was passed, and a call that breaks the sequence resynchronises instead of using a stale
     hand-over slot."""
     from jafpro_amd import synth
@@ -440,8 +440,9 @@ def test_graphed_step_trains_on_the_clip_it_is_given():
     for i in range(len(seq) - 1):
         o = tr1.train_step(clips[seq[i]], next_batch=clips[seq[i + 1]])
         eager.append({k: float(o[k].reshape(-1)[0]) for k in LOSSES})
-    assert abs(eager[0]["vgg_l1"] - eager[1]["vgg_l1"]) > 0.1 * abs(eager[0]["vgg_l1"]) or \
-        abs(eager[1]["vgg_l1"] - eager[2]["vgg_l1"]) > 0.1 * abs(eager[1]["vgg_l1"]), "the clips must be told apart by their loss"
+    # the synthetic clips' perceptual losses are 1.4-2.3 % apart (157.0 / 159.2 / 162.8): several times the bars below
+    for i in range(3):
+        assert abs(eager[i]["vgg_l1"] - eager[(i + 1) % 3]["vgg_l1"]) > 1e-2 * abs(eager[i]["vgg_l1"]), "the clips must be told apart by their loss"
     for i in range(len(seq) - 1):
         o = tr2.train_step_graphed(clips[seq[i]], next_batch=clips[seq[i + 1]])
         torch.cuda.synchronize()
