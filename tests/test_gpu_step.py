@@ -136,27 +136,33 @@ def test_train_step_with_gradient_overlap_on_one_rank_group():
         dist.destroy_process_group()
 
 
-def test_forward_clip_parity():
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_forward_clip_parity(mode):
     """BASELINE config 2 (test/conv_pro_test.py -n 4, forward only, fp32): B=2 clips, 3 target frames each,
     every frame propagated from the reference nearest in time: pred_target <= 1e-3 L-inf vs the CPU oracle's
-    forward_clip (fixture clip_s400)."""
+    forward_clip (fixture clip_s400) -- in the exact-fp32 arithmetic and in the split-bf16 one (three bf16 matrix-core
+    instructions per product on the packed / DMA-staged kernels), the faster arithmetic that holds the same bar."""
     import time
-    from jafpro_amd import synth
+    from jafpro_amd import ops, synth
     from jafpro_amd.step import forward_clip, _to_dev
     M, tr, orc, _, _, _ = build(1)
     clip = synth.stage4_clip(400, 2, 3)
     assert list(clip["chosen_frame"]) == [0, 0, 1, 2]
     dclip = _to_dev(clip, "cuda")
-    out = forward_clip(M, dclip)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = forward_clip(M, dclip)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    prev = ops.set_precision(mode)
+    try:
+        out = forward_clip(M, dclip)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = forward_clip(M, dclip)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        ops.set_precision(prev)
     ref = torch.from_numpy(golden_step("clip_s400")["pred_target"])
     assert out.shape == (2, 3, 3, 256, 256)
     err = (out.cpu() - ref).abs().max().item()
-    print("forward_clip B=2 F=3: max|diff| = %.3e, %.1f ms (fp32, %.1f frames/s)" % (err, dt * 1e3, 6 / dt))
+    print("forward_clip B=2 F=3: max|diff| = %.3e, %.1f ms (%s, %.1f frames/s)" % (err, dt * 1e3, mode, 6 / dt))
     assert err <= 1e-3
 
 
