@@ -36,6 +36,11 @@ layers = {
  "unet16":  (8, 1, [128], 128, 16, 3, 1),
  "lstm25":  (32, 24, [24], 24, 25, 3, 1),
  "lstm50":  (32, 24, [24], 24, 50, 3, 1),
+ "dg48":    (8, 24, [48], 24, 200, 3, 1),
+ "dg96":    (8, 24, [96], 48, 100, 3, 1),
+ "enc1":    (32, 24, [3], 12, 200, 5, 1),
+ "dec12":   (8, 24, [12], 12, 200, 3, 1),
+ "dec72":   (8, 24, [72], 24, 100, 3, 1),
 }
 for name, (N, G, cins, Cout, S, k, st) in layers.items():
     if which != "all" and which != name: continue
