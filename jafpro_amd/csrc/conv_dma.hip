@@ -1253,19 +1253,8 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.off_tab = a.off_w + sb * plan->nsteps * plan->MT * 1024;
     a.off_red = 0;          // the epilogue's reduction scratch: the (idle) patch buffer unless cd_launch_one moves it
     a.ntiles = plan->tiles_x * plan->tiles_p;
-    {
-        // pixel tiles per workgroup (conv_dma_kernel's walk): only where the launch keeps the chip busy for many rounds anyway
-        // (>= 8 rounds of 1024 resident workgroups after the division); JAF_CONV_TPW forces a value (A/B)
-        static const int tpw_env = getenv("JAF_CONV_TPW") ? atoi(getenv("JAF_CONV_TPW")) : 0;
-        const long nblk1 = (long)a.ntiles * plan->mblocks * d->N * d->G;
-        int tpw = tpw_env > 0 ? tpw_env : (int)(nblk1 / (1024L * 8));
-        if (tpw > 4) tpw = 4;
-        if (tpw < 1) tpw = 1;
-        if (tpw > a.ntiles) tpw = a.ntiles;
-        if (sb == 2) tpw = 1;                                      // (conv_dma_split_kernel walks one tile)
-        a.tpw = tpw;
-        a.ntgroups = jaf_cdiv(a.ntiles, tpw);
-    }
+    a.tpw = 1;
+    a.ntgroups = a.ntiles;
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     a.inv_pwp = 1.0f / (float)plan->PWp;
     a.inv_pwq = 1.0f / (float)(plan->ilv ? plan->PWp / plan->NT : plan->PWp);
@@ -1290,6 +1279,30 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.dz_mask_ng8 = a.dz_mask_coff = 0;
     a.dz_slope = 0.f;
     a.dz_dbias = nullptr;
+}
+
+// Pixel tiles per workgroup (conv_dma_kernel's walk).  Measured (profiles/experiments/mb_conv.py, JAF_CONV_TPW = 1 / 2 / 4): the
+// ConvLSTM cell, whose epilogue is long (five transcendentals and six stores per hidden pixel), gains 22 % at the 200 x 200 level
+// (1.196 -> 0.935 ms per step incl. packing) from having the next tile's DMA in flight under it; plain convolutions LOSE 5-30 %
+// (their epilogue is a few stores, and `s_waitcnt vmcnt(0)` in front of the next tile's matrix-core loop also waits for those
+// stores to complete, which a one-tile workgroup never does).  So: the cell kernel only, and only where the launch keeps the
+// chip busy for many rounds anyway (>= 8 rounds of 1024 resident workgroups after the division).  JAF_CONV_TPW forces a value.
+static void cd_set_tpw(ConvDArgs& a, bool lstm) {
+    static const int tpw_env = getenv("JAF_CONV_TPW") ? atoi(getenv("JAF_CONV_TPW")) : 0;
+    const long nblk1 = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
+    // fused-dz data gradients (sign-mask and partner-gradient loads, packed stores, a workgroup reduction in the epilogue): step
+    // 65.2 -> 64.9 ms on top of the cell kernel's 66.0 -> 65.2 (same box, two alternating pairs); JAF_CONV_TPW_DZ=0 switches it off
+    static const int dz_env = getenv("JAF_CONV_TPW_DZ") ? atoi(getenv("JAF_CONV_TPW_DZ")) : 1;
+    // every launch with a packed destination or LayerNorm statistics (the CRN forward layers): step 64.6 -> 63.9 ms (two pairs)
+    static const int dst_env = getenv("JAF_CONV_TPW_DST") ? atoi(getenv("JAF_CONV_TPW_DST")) : 1;
+    const bool walk = lstm || (dz_env && a.dz_mask) || (dst_env && (a.dst || a.stats));
+    int tpw = tpw_env > 0 ? tpw_env : (walk ? (int)(nblk1 / (1024L * 8)) : 1);
+    if (tpw > 4) tpw = 4;
+    if (tpw < 1) tpw = 1;
+    if (tpw > a.ntiles) tpw = a.ntiles;
+    if (a.d.precision == JAF_PREC_BF16X3) tpw = 1;                 // (conv_dma_split_kernel walks one tile)
+    a.tpw = tpw;
+    a.ntgroups = jaf_cdiv(a.ntiles, tpw);
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1353,6 +1366,7 @@ extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, 
     a.out = out;
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
+    cd_set_tpw(a, false);
     if (d->precision == JAF_PREC_BF16X3) {
         // split-bf16: same epilogue, but no packed destination / sign image (those are plain bf16 images)
         JAF_REQUIRE(!a.dst && !a.dz_mask);
@@ -1374,6 +1388,7 @@ extern "C" int jaf_conv2d_fwd_packed_stats(jaf_stream_t s, const jaf_conv_desc* 
     a.out = out;
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
+    cd_set_tpw(a, false);
     if (d->precision == JAF_PREC_BF16X3) return cd_split_launch(a, (hipStream_t)s, false);
     return cd_launch_mt<false>(a, (hipStream_t)s);
 }
@@ -1411,6 +1426,7 @@ extern "C" int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_de
     a.h_out = h_out;
     a.gates_out = (float*)gates_out;
     a.gates_bf16 = gates_bf16 ? 1 : 0;
+    cd_set_tpw(a, true);
     if (d->precision == JAF_PREC_BF16X3) {
         JAF_REQUIRE(!a.dst);
         return cd_split_launch(a, (hipStream_t)s, true);
