@@ -592,6 +592,14 @@ int jaf_ubench_copy(jaf_stream_t s, const void* src, void* dst, int64_t n16);
  * (bench.py reports the best as this box's HBM ceiling): 0: 4 in flight, 1: 4 nt, 2: 8 nt, 3: 2 nt, 4: 1 nt, 5: 1. */
 int jaf_ubench_copy_variant(jaf_stream_t s, const void* src, void* dst, int64_t n16, int32_t variant, int32_t blocks);
 
+/* Profiling aid: while jaf_kernel_names(1) is on, every convolution-family launch (forward / data gradient, ConvLSTM cell,
+ * weight gradients, the resizing pack) leaves the name of the kernel instantiation it picked -- as rocprofv3 prints it,
+ * e.g. "conv_dma_kernel<4, 4, false, false, false>" -- in a thread-local buffer that jaf_last_kernel_name copies out (NUL-terminated, truncated to buflen).  The launch
+ * code is the only place that knows which instantiation runs; bench.py's roofline rows and profiles/ take their names from
+ * here.  jaf_kernel_names returns the previous setting.  No reference counterpart (the reference has no profiler hooks).     */
+int jaf_kernel_names(int on);
+int jaf_last_kernel_name(char* buf, int32_t buflen);
+
 #ifdef __cplusplus
 }
 #endif

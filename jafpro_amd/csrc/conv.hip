@@ -420,6 +420,7 @@ static int launch_nt(const ConvArgs& a, hipStream_t s) {
     do {                                                                                             \
         auto k = conv_mfma_kernel<KS, MT, NT_, LSTM>;                                                \
         if (lds > 48 * 1024) hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        JAF_NOTE_KERNEL("conv_mfma_kernel<%d, %d, %d, %s>", KS, MT, NT_, LSTM ? "true" : "false");      \
         hipLaunchKernelGGL(k, grid, block, lds, s, a);                                               \
     } while (0)
     switch (a.p.NT) {

@@ -641,6 +641,7 @@ static int launch_one(const ConvBArgs& a, hipStream_t s) {
     }
     const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
     if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
+    JAF_NOTE_KERNEL("conv_bf16_kernel<%d, %d, %d, %s>", MT, NT, NS, LSTM ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }

@@ -458,6 +458,7 @@ extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc
         const size_t lds = (size_t)8 * a.cap * sizeof(float);       // <= 40 KB
         const dim3 grid(jaf_cdiv(d->W, PL_TW), jaf_cdiv(d->H, PL_TH), (unsigned)nz);
         const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
+        JAF_NOTE_KERNEL("conv_pack_input_lazy_lds_kernel<%d>", (al && d->W % 4 == 0) ? 4 : 1);
         if (al && d->W % 4 == 0) hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<4>, grid, dim3(256), lds, (hipStream_t)s, a);
         else hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, a);
         return jaf_launch_status();
@@ -466,6 +467,7 @@ extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc
     int tx = 64;
     while (tx > 8 && (tx >> 1) >= d->W) tx >>= 1;
     const int ty = 256 / tx;
+    JAF_NOTE_KERNEL("conv_pack_input_lazy_kernel");
     hipLaunchKernelGGL(conv_pack_input_lazy_kernel, dim3(jaf_cdiv(d->W, tx), jaf_cdiv(d->H, ty), (unsigned)nz), dim3(tx, ty), 0,
                        (hipStream_t)s, a);
     return jaf_launch_status();
@@ -1197,6 +1199,7 @@ static int cd_launch_one(const ConvDArgs& a_in, hipStream_t s) {
                 const int e = jaf_lds_optin((const void*)kz, optin_z);
                 if (e) return e;
             }
+            JAF_NOTE_KERNEL("conv_dma_kernel<%d, %d, false, true, false>", MT, NT);
             hipLaunchKernelGGL(kz, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
             return jaf_launch_status();
         }
@@ -1210,6 +1213,7 @@ static int cd_launch_one(const ConvDArgs& a_in, hipStream_t s) {
                 const int e = jaf_lds_optin((const void*)kp, optin_p);
                 if (e) return e;
             }
+            JAF_NOTE_KERNEL("conv_dma_kernel<%d, %d, false, false, true>", MT, NT);
             hipLaunchKernelGGL(kp, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
             return jaf_launch_status();
         }
@@ -1220,6 +1224,7 @@ static int cd_launch_one(const ConvDArgs& a_in, hipStream_t s) {
         const int e = jaf_lds_optin((const void*)k, optin);
         if (e) return e;
     }
+    JAF_NOTE_KERNEL("conv_dma_kernel<%d, %d, %s, false, false>", MT, NT, LSTM ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }

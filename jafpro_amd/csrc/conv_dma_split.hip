@@ -218,6 +218,7 @@ static int cds_launch_one(const ConvDArgs& a, hipStream_t s) {
         const int e = jaf_lds_optin((const void*)k, optin);
         if (e) return e;
     }
+    JAF_NOTE_KERNEL("conv_dma_split_kernel<%d, %d, %s>", MT, NT, LSTM ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }

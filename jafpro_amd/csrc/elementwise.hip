@@ -464,3 +464,19 @@ extern "C" int jaf_axpby(jaf_stream_t s, float a, const float* x, float b, float
     hipLaunchKernelGGL(axpby_kernel, dim3(jaf_ew_grid(n)), dim3(256), 0, (hipStream_t)s, a, x, b, y, (long)n);
     return jaf_launch_status();
 }
+
+// ------------------------------------------------------------------ kernel names for the profiler rows
+thread_local char jaf_kname_buf[160] = "";
+int jaf_kname_on = 0;
+
+extern "C" int jaf_kernel_names(int on) {
+    const int prev = jaf_kname_on;
+    jaf_kname_on = on ? 1 : 0;
+    return prev;
+}
+
+extern "C" int jaf_last_kernel_name(char* buf, int32_t buflen) {
+    JAF_REQUIRE(buf && buflen >= 1);
+    snprintf(buf, (size_t)buflen, "%s", jaf_kname_buf);
+    return JAF_OK;
+}

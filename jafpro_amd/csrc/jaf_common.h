@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include "../../include/jafpro_hip.h"
 
 #define JAF_WAVE 64
@@ -16,6 +17,12 @@ static inline int jaf_launch_status() {
 }
 
 #define JAF_REQUIRE(cond) do { if (!(cond)) return JAF_EINVAL; } while (0)
+
+// Name of the kernel instantiation a launch path picked, as rocprofv3 prints it (jaf_last_kernel_name): written by the launch
+// code itself -- the one place that knows -- while jaf_kernel_names(1) is on (bench.py's roofline step, profiling scripts).
+extern thread_local char jaf_kname_buf[160];
+extern int jaf_kname_on;
+#define JAF_NOTE_KERNEL(...) do { if (jaf_kname_on) snprintf(jaf_kname_buf, sizeof(jaf_kname_buf), __VA_ARGS__); } while (0)
 
 // Opt a kernel into > 48 KB of dynamic LDS.  The attribute belongs to the (kernel, DEVICE) pair, so the
 // "already done" flag is kept per device of the calling thread (`cache`: one zero-initialised int[JAF_MAX_DEVICES]

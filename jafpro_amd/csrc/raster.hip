@@ -15,7 +15,7 @@
 #define LCAP 768     // LDS face list capacity
 
 struct FaceRec {     // 13 x 4 bytes per face in the workspace
-    float inv[9];
+    float adj[9];
     int bb[4];       // xmin, xmax, ymin, ymax (pixel units, kernel orientation); xmin>xmax = culled
 };
 
@@ -50,23 +50,23 @@ extern "C" int jaf_project_faces(jaf_stream_t s, const float* verts, const float
 __global__ void raster_setup_kernel(const float* faces, FaceRec* rec, int total, int is) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const float* face = faces + (long)i * 9;
+    const float* tri = faces + (long)i * 9;
     FaceRec r;
-    for (int k = 0; k < 9; ++k) r.inv[k] = 0.f;
+    for (int k = 0; k < 9; ++k) r.adj[k] = 0.f;
     r.bb[0] = 1; r.bb[1] = 0; r.bb[2] = 1; r.bb[3] = 0;
-    const bool back = (face[7] - face[1]) * (face[3] - face[0]) < (face[4] - face[1]) * (face[6] - face[0]);
+    const bool back = (tri[7] - tri[1]) * (tri[3] - tri[0]) < (tri[4] - tri[1]) * (tri[6] - tri[0]);
     if (!back) {
-        float p[3][2];
-        for (int num = 0; num < 3; num++)
-            for (int dim = 0; dim < 2; dim++) p[num][dim] = (float)(0.5 * (double)(face[3 * num + dim] * is + is - 1));
-        float inv[9] = {
-            p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-            p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-            p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
-        const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]));
-        for (int k = 0; k < 9; ++k) r.inv[k] = inv[k] / den;
-        const float xmn = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmx = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
-        const float ymn = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymx = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
+        float pt[3][2];
+        for (int v = 0; v < 3; v++)
+            for (int ax = 0; ax < 2; ax++) pt[v][ax] = (float)(0.5 * (double)(tri[3 * v + ax] * is + is - 1));
+        float adj[9] = {
+            pt[1][1] - pt[2][1], pt[2][0] - pt[1][0], pt[1][0] * pt[2][1] - pt[2][0] * pt[1][1],
+            pt[2][1] - pt[0][1], pt[0][0] - pt[2][0], pt[2][0] * pt[0][1] - pt[0][0] * pt[2][1],
+            pt[0][1] - pt[1][1], pt[1][0] - pt[0][0], pt[0][0] * pt[1][1] - pt[1][0] * pt[0][1]};
+        const float area2 = (pt[2][0] * (pt[0][1] - pt[1][1]) + pt[0][0] * (pt[1][1] - pt[2][1]) + pt[1][0] * (pt[2][1] - pt[0][1]));
+        for (int k = 0; k < 9; ++k) r.adj[k] = adj[k] / area2;
+        const float xmn = fminf(pt[0][0], fminf(pt[1][0], pt[2][0])), xmx = fmaxf(pt[0][0], fmaxf(pt[1][0], pt[2][0]));
+        const float ymn = fminf(pt[0][1], fminf(pt[1][1], pt[2][1])), ymx = fmaxf(pt[0][1], fmaxf(pt[1][1], pt[2][1]));
         // clamp before the int conversion; one pixel of slack on every side
         r.bb[0] = (int)floorf(fmaxf(xmn, -4.f)) - 1;
         r.bb[1] = (int)ceilf(fminf(xmx, (float)is + 4.f)) + 1;
@@ -103,11 +103,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float* faces, co
     const float* fbase = faces + (long)bn * NF * 9;
     const FaceRec* rbase = rec + (long)bn * NF;
 
-    float depth_min = far_;
-    int face_index_min = -1;
-    int slot_min = -1;          // LDS slot of the winning face in the batch it came from (return_depth only)
-    float weight_min[3] = {0.f, 0.f, 0.f};
-    float face_inv_min[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float z_best = far_;
+    int f_best = -1;
+    int slot_best = -1;          // LDS slot of the winning tri in the batch it came from (return_depth only)
+    float bc_best[3] = {0.f, 0.f, 0.f};
+    float bary_best[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     if (tid == 0) s_count = 0;
     __syncthreads();
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float* faces, co
         if (lane == 0) s_wcount[wave] = __popcll(m);
         __syncthreads();
         int off = s_count;
-        for (int w = 0; w < wave; ++w) off += s_wcount[w];
+        for (int bc = 0; bc < wave; ++bc) off += s_wcount[bc];
         if (ov) s_list[off + wprefix] = f;
         __syncthreads();
         if (tid == 0) s_count += s_wcount[0] + s_wcount[1] + s_wcount[2] + s_wcount[3];
@@ -136,39 +136,39 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float* faces, co
                 const int i = e / 9, k = e - i * 9;
                 const int ff = s_list[i];
                 s_face[e] = fbase[(long)ff * 9 + k];
-                s_inv[e] = rbase[ff].inv[k];
+                s_inv[e] = rbase[ff].adj[k];
             }
             __syncthreads();
             if (inside_img) {
                 for (int i = 0; i < cnt; ++i) {
-                    const float* face = s_face + i * 9;
-                    const float* face_inv = s_inv + i * 9;
-                    if (((yp - face[1]) * (face[3] - face[0]) < (xp - face[0]) * (face[4] - face[1])) ||
-                        ((yp - face[4]) * (face[6] - face[3]) < (xp - face[3]) * (face[7] - face[4])) ||
-                        ((yp - face[7]) * (face[0] - face[6]) < (xp - face[6]) * (face[1] - face[7])))
+                    const float* tri = s_face + i * 9;
+                    const float* bary = s_inv + i * 9;
+                    if (((yp - tri[1]) * (tri[3] - tri[0]) < (xp - tri[0]) * (tri[4] - tri[1])) ||
+                        ((yp - tri[4]) * (tri[6] - tri[3]) < (xp - tri[3]) * (tri[7] - tri[4])) ||
+                        ((yp - tri[7]) * (tri[0] - tri[6]) < (xp - tri[6]) * (tri[1] - tri[7])))
                         continue;
-                    float w[3];
-                    w[0] = face_inv[0] * xi + face_inv[1] * yi + face_inv[2];
-                    w[1] = face_inv[3] * xi + face_inv[4] * yi + face_inv[5];
-                    w[2] = face_inv[6] * xi + face_inv[7] * yi + face_inv[8];
-                    float w_sum = 0;
+                    float bc[3];
+                    bc[0] = bary[0] * xi + bary[1] * yi + bary[2];
+                    bc[1] = bary[3] * xi + bary[4] * yi + bary[5];
+                    bc[2] = bary[6] * xi + bary[7] * yi + bary[8];
+                    float bc_sum = 0;
                     for (int k = 0; k < 3; k++) {
-                        w[k] = fminf(fmaxf(w[k], 0.f), 1.f);
-                        w_sum += w[k];
+                        bc[k] = fminf(fmaxf(bc[k], 0.f), 1.f);
+                        bc_sum += bc[k];
                     }
-                    for (int k = 0; k < 3; k++) w[k] /= w_sum;
-                    const float zp = (float)(1. / (double)(w[0] / face[2] + w[1] / face[5] + w[2] / face[8]));
-                    if (zp <= near_ || far_ <= zp) continue;
-                    if (zp < depth_min) {
-                        depth_min = zp;
-                        face_index_min = s_list[i];
-                        slot_min = i;
-                        weight_min[0] = w[0]; weight_min[1] = w[1]; weight_min[2] = w[2];
+                    for (int k = 0; k < 3; k++) bc[k] /= bc_sum;
+                    const float z_here = (float)(1. / (double)(bc[0] / tri[2] + bc[1] / tri[5] + bc[2] / tri[8]));
+                    if (z_here <= near_ || far_ <= z_here) continue;
+                    if (z_here < z_best) {
+                        z_best = z_here;
+                        f_best = s_list[i];
+                        slot_best = i;
+                        bc_best[0] = bc[0]; bc_best[1] = bc[1]; bc_best[2] = bc[2];
                     }
                 }
-                if (finv_map && slot_min >= 0) {          // the winner of this batch: keep its inverse before the LDS is reused
-                    for (int k = 0; k < 9; ++k) face_inv_min[k] = s_inv[slot_min * 9 + k];
-                    slot_min = -1;
+                if (finv_map && slot_best >= 0) {          // the winner of this batch: keep its inverse before the LDS is reused
+                    for (int k = 0; k < 9; ++k) bary_best[k] = s_inv[slot_best * 9 + k];
+                    slot_best = -1;
                 }
             }
             __syncthreads();
@@ -180,14 +180,14 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const float* faces, co
     if (inside_img) {
         // vertical flip of rasterize.py:334-338 folded into the store (flip == 0: the maps RasterizeFunction saves)
         const long o = ((long)bn * is + (flip ? (is - 1 - yi) : yi)) * is + xi;
-        fim[o] = face_index_min;
-        wim[o * 3 + 0] = weight_min[0];
-        wim[o * 3 + 1] = weight_min[1];
-        wim[o * 3 + 2] = weight_min[2];
-        if (depth) depth[o] = depth_min;                                   // far where nothing was hit (rasterize.py:52)
-        if (alpha) alpha[o] = face_index_min >= 0 ? 1.f : 0.f;             // forward_alpha_map (rasterize.py:188-192)
+        fim[o] = f_best;
+        wim[o * 3 + 0] = bc_best[0];
+        wim[o * 3 + 1] = bc_best[1];
+        wim[o * 3 + 2] = bc_best[2];
+        if (depth) depth[o] = z_best;                                   // far where nothing was hit (rasterize.py:52)
+        if (alpha) alpha[o] = f_best >= 0 ? 1.f : 0.f;             // forward_alpha_map (rasterize.py:188-192)
         if (finv_map)
-            for (int k = 0; k < 9; ++k) finv_map[o * 9 + k] = face_inv_min[k];
+            for (int k = 0; k < 9; ++k) finv_map[o * 9 + k] = bary_best[k];
     }
 }
 

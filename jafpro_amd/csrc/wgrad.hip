@@ -263,6 +263,7 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
     do {                                                                                            \
         auto k = conv_wgrad_kernel<MT_, NP_>;                                                       \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        JAF_NOTE_KERNEL("conv_wgrad_kernel<%d, %d>", MT_, NP_);                                     \
         hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                          \
     } while (0)
 #define JAF_WG_NP(MT_)                          \

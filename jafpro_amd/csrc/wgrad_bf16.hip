@@ -412,6 +412,7 @@ int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const f
                                                 (double)jaf_kernel_slots((const void*)k, lds, occ), 5e-6); \
         const long nblk = outblocks * a.nsplit;                                                        \
         if (nblk > 0x7fffffffL) return JAF_EINVAL;                                                     \
+        JAF_NOTE_KERNEL("conv_wgrad_bf16_kernel<%d, %s>", MT_, (SP_) ? "true" : "false");               \
         hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);                     \
     } while (0)
     if (split) switch (MTW) {

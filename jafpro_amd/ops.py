@@ -120,52 +120,14 @@ class _arith:
         return False
 
 
-_WGRAD_NO_DB = os.environ.get("JAF_WGRAD_NO_DB") is not None
+_NAME_BUF = ctypes.create_string_buffer(160)
 
 
-def _wgrad_dma_name(Cout: int, KS: int, Cin: int = 16, G: int = 1, N: int = 1, OH: int = 1 << 20, OW: int = 1 << 20, stride: int = 1) -> str:
-    """Template instantiation jaf_conv2d_wgrad_packed launches (same rule as csrc/wgrad_dma.hip), so that the
-    bench's per-kernel rows carry the names rocprofv3 reports."""
-    mt_best, pad_best = 1, None
-    for mt in ((1,) if KS == 5 else (4, 3, 2, 1)):
-        pad = -(-Cout // (16 * mt)) * 16 * mt
-        if pad_best is None or pad < pad_best:
-            mt_best, pad_best = mt, pad
-    ph, pw = 7 * stride + KS, 15 * stride + KS
-    xplane = -(-(ph * (-(-pw // 8) * 8) * 32) // 1024) * 1024
-    nx = xplane // 1024
-    if KS != 5:        # launches that cannot fill the chip use smaller output blocks
-        wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
-        while wc > 1 and -(-(wc * nx) // 4) > 11:
-            wc >>= 1
-        sp = min(N * -(-OW // 16) * -(-OH // 8), 96)
-        while G * -(-Cout // (16 * mt_best)) * -(-Cin // (16 * wc)) * sp < 512:
-            if mt_best > 1:
-                mt_best = 2 if mt_best == 4 else 1
-            elif wc > 1:
-                wc >>= 1
-            else:
-                break
-    else:
-        wc = 1 if Cin <= 16 else (2 if Cin <= 32 else 4)
-    # two tile buffers when a (patch, dz) tile is at most 40 KB
-    db = (wc * xplane + mt_best * 4096 <= 40 * 1024) and not _WGRAD_NO_DB
-    need = -(-(wc * nx) // 4)                # patch DMA pieces per wave: the XI template argument
-    xi = 4 if need <= 4 else (8 if need <= 8 else 11)
-    return "conv_wgrad_dma_kernel<%d, %d, %s, %s, %d>" % (mt_best, KS, "true" if (KS == 5 and Cin <= 8) else "false",
-                                                          "true" if db else "false", xi)
-
-
-def _wgrad_name(KH, KW) -> str:
-    return "conv_wgrad_bf16_kernel" if (_PRECISION in (PREC_BF16, PREC_BF16X3) and KH == 3 and KW == 3) else "conv_wgrad_kernel"
-
-
-def _kname(lstm: bool, KH, KW, pl) -> str:
-    if pl.precision == PREC_F32:
-        return "conv_mfma_kernel<%d, %d, %d, %s>" % (3 if (KH == 3 and KW == 3) else 0, pl.MT, pl.NT,
-                                                      "true" if lstm else "false")
-    return "conv_bf16_kernel<%d, %d, %d, %s>" % (pl.MT, pl.NT, 3 if pl.precision == PREC_BF16X3 else 1,
-                                                  "true" if lstm else "false")
+def _launched() -> str:
+    """Name of the kernel instantiation the last convolution-family launch of this thread picked, as rocprofv3 prints it
+    (jaf_last_kernel_name: written by the launch code itself while a profiler is set, see set_profiler)."""
+    check(lib().jaf_last_kernel_name(_NAME_BUF, len(_NAME_BUF)), "jaf_last_kernel_name")
+    return _NAME_BUF.value.decode()
 
 
 class KernelProfiler:
@@ -202,6 +164,7 @@ class KernelProfiler:
 def set_profiler(p):
     global _PROF
     _PROF = p
+    lib().jaf_kernel_names(1 if p is not None else 0)
 
 
 class _hbm:
@@ -216,7 +179,7 @@ class _hbm:
 
     def __exit__(self, *exc):
         if self.ev is not None and exc[0] is None:
-            _PROF.end(self.name, 0.0, self.ev, self.nbytes)
+            _PROF.end(self.name if self.name is not None else _launched(), 0.0, self.ev, self.nbytes)
         return False
 
 
@@ -274,14 +237,6 @@ def _packed_path(d: ConvDesc) -> bool:
     return _packed_prec(d.precision)
 
 
-def _conv_kernel_name(pl, lstm: bool, dz: bool = False, plain: bool = False) -> str:
-    """The packed-path instantiation as rocprofv3 names it."""
-    if pl.precision == PREC_BF16X3:
-        return "conv_dma_split_kernel<%d, %d, %s>" % (pl.MT, pl.NT, "true" if lstm else "false")
-    return "conv_dma_kernel<%d, %d, %s, %s, %s>" % (pl.MT, pl.NT, "true" if lstm else "false", "true" if dz else "false",
-                                                   "true" if plain else "false")
-
-
 def _plan(key, d: ConvDesc, lstm: int, flags: int = 0) -> ConvPlan:
     packed = _packed_path(d)
     k = (key, lstm, d.precision, packed, flags if packed else 0)
@@ -294,19 +249,6 @@ def _plan(key, d: ConvDesc, lstm: int, flags: int = 0) -> ConvPlan:
             check(lib().jaf_conv2d_plan(ctypes.byref(d), lstm, ctypes.byref(pl)), "jaf_conv2d_plan")
         _PLAN_CACHE[k] = pl
     return pl
-
-
-def _lazy_pack_name(H: int, W: int, lazies) -> str:
-    """Kernel jaf_conv2d_pack_input_resized launches (same rule as csrc/conv_dma.hip), for the bench's per-kernel rows."""
-    staged = W >= 48
-    for sh, sw, al in lazies:
-        sy = ((sh - 1) / (H - 1) if H > 1 else 0.0) if al else sh / H
-        sx = ((sw - 1) / (W - 1) if W > 1 else 0.0) if al else sw / W
-        if (math.ceil(sy * 16) + 3) * (math.ceil(sx * 64) + 3) > 1280:
-            staged = False
-    if not staged:
-        return "conv_pack_input_lazy_kernel"
-    return "conv_pack_input_lazy_lds_kernel<%d>" % (4 if W % 4 == 0 else 1)
 
 
 def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc, lazy=None) -> torch.Tensor:
@@ -331,8 +273,7 @@ def pack_input(srcs: Sequence[torch.Tensor], d: ConvDesc, lazy=None) -> torch.Te
             else:
                 real.append(l[0])
                 sh[i], sw[i], al[i] = int(l[0].shape[2]), int(l[0].shape[3]), 1 if l[1] else 0
-        name = _lazy_pack_name(d.H, d.W, [(sh[i], sw[i], al[i]) for i, l in enumerate(lazy) if l is not None]) if _PROF is not None else ""
-        with _hbm(name, sum(4.0 * r.numel() for r in real) + nbytes):
+        with _hbm(None, sum(4.0 * r.numel() for r in real) + nbytes):      # (None: the kernel the launch picks, see _launched)
             per = nbytes // d.N
             for n0, n1 in chunks:
                 dc = type(d).from_buffer_copy(d)
@@ -713,10 +654,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if sums is not None:
             ln_stats.filled = True
         if ev is not None:
-            # named as rocprofv3 names the instantiation jaf_conv2d_fwd_packed_io picks: <MT, NT, LSTM, DZ, PLAIN>
-            plain = (dz_fuse is None and dst is None and sums is None and not accumulate and out2 is None and not skip_f32
-                     and not _NO_PLAIN_CONV)
-            _PROF.end(_conv_kernel_name(pl, False, dz_fuse is not None, plain), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
+            _PROF.end(_launched(), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
         return (out, xp) if want_xp else out
     if accumulate or out2 is not None:
         raise RuntimeError("conv: accumulate / out2 are features of the packed bf16 path")
@@ -725,7 +663,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
     check(lib().jaf_conv2d_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), ps[0], ps[1], ps[2], _p(wpk), _p(bias),
                                _p(out)), "jaf_conv2d_fwd")
     if ev is not None:
-        _PROF.end(_kname(False, KH, KW, pl), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
+        _PROF.end(_launched(), 2.0 * N * G * Cout * Cin * KH * KW * OH * OW / (dil * dil), ev)
     return (out, None) if want_xp else out
 
 
@@ -783,7 +721,6 @@ def _slot_of(t) -> Optional["GradSlot"]:
     return getattr(t, "_jaf_gradslot", None)
 
 
-_NO_PLAIN_CONV = os.environ.get("JAF_NO_PLAIN_CONV") is not None
 _FUSED_DZ = os.environ.get("JAF_NO_FUSED_DZ") is None
 _FUSED_DZ_MIN_G = int(os.environ.get("JAF_FUSED_DZ_MIN_G", "1"))      # experiment hook: hand dz over only in layers with >= this many groups
 
@@ -864,11 +801,11 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool, stream=None):
             dzp = pack_input([dz], dzd)
         check(L.jaf_conv2d_wgrad_packed_ex(sh, ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
                                            1 if inplace else 0), "jaf_conv2d_wgrad_packed_ex")
-        wname = _wgrad_dma_name(m.Cout, m.KH, m.Cin, m.G, m.N, m.OH, m.OW, m.stride)
+        wname = _launched() if ev is not None else ""
     else:
         check(L.jaf_conv2d_wgrad(sh, ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
               "jaf_conv2d_wgrad")
-        wname = _wgrad_name(m.KH, m.KW)
+        wname = _launched() if ev is not None else ""
     if ev is not None:
         _PROF.end(wname, 2.0 * m.N * m.G * m.Cout * m.Cin * m.KH * m.KW * m.OH * m.OW, ev)
     return None if inplace else dw
@@ -1210,14 +1147,14 @@ class _ConvLSTMFn(Function):
                                                         ctypes.byref(io) if io is not None else None),
                       "jaf_convlstm_cell_fwd_packed_io")
                 if ev is not None:
-                    _PROF.end(_conv_kernel_name(pl, True), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                    _PROF.end(_launched(), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 continue
             check(L.jaf_convlstm_cell_fwd(_s(), ctypes.byref(d), ctypes.byref(pl), _p(x[t]),
                                           None if first else _p(hprev), _p(wpk), _p(bias),
                                           None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
                                           _p(gates[t]) if keep else None), "jaf_convlstm_cell_fwd")
             if ev is not None:
-                _PROF.end(_kname(True, 3, 3, pl), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                _PROF.end(_launched(), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
         ctx.G = G
         ctx.need_all = need_all
         ctx.bias_ref = bias
@@ -1317,7 +1254,7 @@ class _ConvLSTMFn(Function):
                     check(L.jaf_conv2d_wgrad_packed_lstm(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
                                                          1 if w_inplace else acc, C), "jaf_conv2d_wgrad_packed_lstm")
                     if ev is not None:
-                        _PROF.end(_wgrad_dma_name(4 * C, 3, Cin, G, N, H, W), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
+                        _PROF.end(_launched(), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:
                     gtp.record_stream(wst)
                     ctx.xps[t].record_stream(wst)
@@ -1332,11 +1269,11 @@ class _ConvLSTMFn(Function):
                     gtp = pack_input([gt], gd)
                     check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
                                                        1 if w_inplace else acc), "jaf_conv2d_wgrad_packed_ex")
-                    wname = _wgrad_dma_name(4 * C, 3, Cin, G, N, H, W)
+                    wname = _launched() if ev is not None else ""
                 else:
                     check(L.jaf_conv2d_wgrad(_s(), ctypes.byref(d), _p(x[t]), None if first else _p(hprev), None,
                                              _p(gt), _p(dw), 1 if w_inplace else acc), "jaf_conv2d_wgrad")
-                    wname = _wgrad_name(3, 3)
+                    wname = _launched() if ev is not None else ""
                 if ev is not None:
                     _PROF.end(wname, 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 check(L.jaf_channel_sum(_s(), _p(gt), N, 4 * GC, 0, 4 * GC, H * W, _p(db), 1 if b_inplace else acc),
