@@ -798,7 +798,7 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
     unsigned char* s_w = smem + a.off_w;
     int* s_tab = (int*)(smem + a.off_tab);
 
-    // ---- block -> (row block, group of `tpw` consecutive pixel tiles, image, group), XCD-contiguous ----
+    // ---- block -> (row block, pixel tile, image, group), XCD-contiguous ----
     int L;
     {
         const int nblk = gridDim.x, bid = blockIdx.x;
@@ -807,12 +807,17 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
     }
     const int mb = L % P.mblocks;
     L /= P.mblocks;
-    const int tg = L % a.ntgroups;
-    const int ngi = L / a.ntgroups;
+    const int tile = L % a.ntiles;
+    const int ngi = L / a.ntiles;
     const int n = ngi / d.G;
     const int g = ngi - n * d.G;
-    const int tile0 = tg * a.tpw;
-    const int ntl = min(a.tpw, a.ntiles - tile0);        // pixel tiles this workgroup walks (>= 1)
+    const int tx = tile % P.tiles_x;
+    const int tb = tile / P.tiles_x;
+    const int x0 = tx * P.TWIN;
+    const int pbase = tb * (64 * NT);
+    const int oy0 = pbase / P.TWIN;
+    const int iy0 = oy0 * d.stride - d.pad_t;
+    const int ix0 = x0 * d.stride - d.pad_l;
     const int OHW = d.OH * d.OW;
     const int HW = d.H * d.W;
 
@@ -837,15 +842,24 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
         }
     }
 
-    // ---- DMA source offsets of a pixel tile: wave w fills rounds w and w+4 (64 slots each) of every group plane ----
+    // ---- per-lane output pixels ----
+    int boff[NT];
+    int opix[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int p = a.ilv ? (pbase + wave * 16 * NT + li * NT + nt) : (pbase + (wave * NT + nt) * 16 + li);
+        const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
+        const int oxr = p - oy * P.TWIN;
+        const int ox = x0 + oxr;
+        const bool valid = (oy < d.OH) && (ox < d.OW);
+        boff[nt] = valid ? (((oy - oy0) * d.stride * PWp + (oxr >> lg) * d.stride) * 16) : 0;
+        opix[nt] = valid ? (oy * d.OW + ox) : -1;
+    }
+
+    // ---- DMA source offsets: wave w fills rounds w and w+4 (64 slots each) of every group plane ----
     const int nrounds = (npos + 63) >> 6;
     int dvoff[CD_RPW];
-    auto dma_offsets = [&](int tile) {
-        const int tx = tile % P.tiles_x;
-        const int tb = tile / P.tiles_x;
-        const int oy0 = (tb * (64 * NT)) / P.TWIN;
-        const int iy0 = oy0 * d.stride - d.pad_t;
-        const int ix0 = tx * P.TWIN * d.stride - d.pad_l;
+    {
         const int dil = d.dil_in;
         const int Hd = (d.H - 1) * dil + 1;
         const int Wd = (d.W - 1) * dil + 1;
@@ -866,127 +880,87 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
             }
             dvoff[j] = ok ? ((iy * d.W + ix) * 16) : CD_OOB;
         }
-    };
+    }
     // plane (group8 = 0) of this (image, group); consecutive group8 planes are HW*16 bytes apart
     const unsigned char* xbase = a.xp + (((long)n * d.G + g) * a.in_ng8) * (long)HW * 16;
     const int plane_bytes = HW * 16;
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ConvLSTM: the previous cell state of this lane's 4 consecutive pixels (vector epilogue, NT == 4) is requested NOW, so
+    // that its HBM latency runs under the patch DMA and the matrix-core loop instead of inside the epilogue (with 3
+    // workgroups per CU nothing else hides it: the 200 x 200 level sat at 3.1 TB/s)
+    f32x4 cpre[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) cpre[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (LSTM && NT == 4 && a.c_prev && a.vec && opix[0] >= 0) {
+        const int C = d.Cout >> 2;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int ch = ((mb * MR + mt * 16) >> 2) + q;
+            if (ch < C) cpre[mt] = *(const f32x4*)(a.c_prev + (((long)n * d.G + g) * C + ch) * OHW + opix[0]);
+        }
+    }
+
     const long wchunk_bytes = (long)P.nsteps * MT * 1024;
     const unsigned char* wbase = a.wpk + ((long)(g * P.mblocks + mb) * P.nchunks) * wchunk_bytes;
 
-    // ---- weights and patch of one chunk: DMA straight into LDS (source offsets of the tile in dvoff) ----
-    auto issue = [&](int chunk, bool weights) {
+    for (int chunk = 0; chunk < P.nchunks; ++chunk) {
         const bool last = (chunk == P.nchunks - 1);
         const int ngc = last ? P.ng_last : NG;
         const int nst = last ? P.nsteps_last : P.nsteps;
-        if (weights) {
+        __syncthreads();   // previous chunk consumed (first pass: slot table visible)
+
+        // ---- weights and patch: DMA straight into LDS.  Overlap with the matrix cores comes from the
+        // 2-6 workgroups resident per CU (LDS/VGPR footprint is small); an intra-workgroup second
+        // buffer measured slower than the extra resident workgroup it costs. ----
+        {
             const unsigned char* wsrc = wbase + (long)chunk * wchunk_bytes;
             for (int e = wave; e < nst * MT; e += 4)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + e * 1024 + lane * 16),
                                                  (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
-        }
-        const unsigned char* cbase = xbase + (long)(chunk * NG) * plane_bytes;
-        for (int grp = 0; grp < ngc; ++grp) {
-            const __amdgpu_buffer_rsrc_t rs =
-                __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)grp * plane_bytes), 0, plane_bytes, 0x00020000);
+            const unsigned char* cbase = xbase + (long)(chunk * NG) * plane_bytes;
+            for (int grp = 0; grp < ngc; ++grp) {
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)grp * plane_bytes), 0, plane_bytes, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < CD_RPW; ++j) {
-                const int round = wave + 4 * j;
-                if (round < nrounds)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(s_patch + grp * plane + round * 1024),
-                                                             16, dvoff[j], 0, 0, 0);
-            }
-        }
-    };
-
-    // Overlap of one workgroup's own phases: a workgroup walks `tpw` consecutive pixel tiles of its (row block, image, group);
-    // the DMA of tile i + 1's first chunk is issued right after tile i's last matrix-core step -- the patch buffer is free then --
-    // and lands under tile i's epilogue (which only stores registers).  Single-chunk layers keep their weight image in LDS for
-    // the whole walk.  (Other resident workgroups used to be the only overlap: DESIGN.md, "the phases add".)
-    dma_offsets(tile0);
-    issue(0, true);
-
-    for (int ti = 0; ti < ntl; ++ti) {
-        const int tile = tile0 + ti;
-        const int tx = tile % P.tiles_x;
-        const int tb = tile / P.tiles_x;
-        const int x0 = tx * P.TWIN;
-        const int pbase = tb * (64 * NT);
-        const int oy0 = pbase / P.TWIN;
-
-        // ---- per-lane output pixels ----
-        int boff[NT];
-        int opix[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int p = a.ilv ? (pbase + wave * 16 * NT + li * NT + nt) : (pbase + (wave * NT + nt) * 16 + li);
-            const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
-            const int oxr = p - oy * P.TWIN;
-            const int ox = x0 + oxr;
-            const bool valid = (oy < d.OH) && (ox < d.OW);
-            boff[nt] = valid ? (((oy - oy0) * d.stride * PWp + (oxr >> lg) * d.stride) * 16) : 0;
-            opix[nt] = valid ? (oy * d.OW + ox) : -1;
-        }
-
-        f32x4 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        // ConvLSTM: the previous cell state of this lane's 4 consecutive pixels (vector epilogue, NT == 4) is requested NOW, so
-        // that its HBM latency runs under the patch DMA and the matrix-core loop instead of inside the epilogue (with 3
-        // workgroups per CU nothing else hides it: the 200 x 200 level sat at 3.1 TB/s)
-        f32x4 cpre[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) cpre[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (LSTM && NT == 4 && a.c_prev && a.vec && opix[0] >= 0) {
-            const int C = d.Cout >> 2;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int ch = ((mb * MR + mt * 16) >> 2) + q;
-                if (ch < C) cpre[mt] = *(const f32x4*)(a.c_prev + (((long)n * d.G + g) * C + ch) * OHW + opix[0]);
-            }
-        }
-
-        for (int chunk = 0; chunk < P.nchunks; ++chunk) {
-            const bool last = (chunk == P.nchunks - 1);
-            const int nst = last ? P.nsteps_last : P.nsteps;
-            if (chunk > 0) {
-                __syncthreads();   // previous chunk consumed
-                issue(chunk, true);
-            }
-            __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
-            __syncthreads();                    // (first pass: slot table visible)
-
-            // ---- MFMA over the chunk's steps ----
-            const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
-            u32x4 tnext = *(const u32x4*)tab;                 // slot-table entry fetched one step ahead
-            for (int st = 0; st < nst; ++st) {
-                const u32x4 t4 = tnext;
-                tnext = *(const u32x4*)(tab + 16 * (st + 1 < nst ? st + 1 : st));
-                const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
-                bf16x8 bh[NT];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const bf16x8 ah = *(const bf16x8*)(s_w + (st * MT + mt) * 1024 + lane * 16);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                for (int j = 0; j < CD_RPW; ++j) {
+                    const int round = wave + 4 * j;
+                    if (round < nrounds)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(s_patch + grp * plane + round * 1024),
+                                                                 16, dvoff[j], 0, 0, 0);
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
+        __syncthreads();
 
-        if (ti + 1 < ntl) {
-            __syncthreads();       // every wave has left the matrix-core loop: patch (and, multi-chunk, weight) buffers are free
-            dma_offsets(tile + 1);
-            issue(0, P.nchunks > 1);
+        // ---- MFMA over the chunk's steps ----
+        const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
+        u32x4 tnext = *(const u32x4*)tab;                 // slot-table entry fetched one step ahead
+        for (int st = 0; st < nst; ++st) {
+            const u32x4 t4 = tnext;
+            tnext = *(const u32x4*)(tab + 16 * (st + 1 < nst ? st + 1 : st));
+            const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+            bf16x8 bh[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const bf16x8 ah = *(const bf16x8*)(s_w + (st * MT + mt) * 1024 + lane * 16);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+            }
         }
-
-        // ---- epilogue (its workgroup reductions use their own LDS scratch behind the slot table) ----
-        cd_epilogue<MT, NT, LSTM, DZ, PLAIN>(a, acc, opix, n, g, mb, q, OHW, smem + a.off_red, cpre);
     }
+
+    // ---- epilogue ----
+    cd_epilogue<MT, NT, LSTM, DZ, PLAIN>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1180,16 +1154,9 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
 
 template <int MT, int NT, bool LSTM>
 static int cd_launch_one(const ConvDArgs& a_in, hipStream_t s) {
-    ConvDArgs a = a_in;
-    int lds = a.p.lds_bytes;
-    if (a.tpw > 1 && (a.stats || a.dz_dbias)) {
-        // a walking workgroup has the next tile's DMA in flight while its epilogue reduces over the workgroup: those launches
-        // get CD_RED_BYTES of scratch behind everything else (one tile per workgroup: the idle patch buffer, as before)
-        a.off_red = (lds + 15) & ~15;
-        lds = a.off_red + CD_RED_BYTES;
-        if (lds > 160 * 1024) { a.tpw = 1; a.ntgroups = a.ntiles; a.off_red = 0; lds = a.p.lds_bytes; }
-    }
-    const long nblk = (long)a.ntgroups * a.p.mblocks * a.d.N * a.d.G;
+    const ConvDArgs& a = a_in;
+    const int lds = a.p.lds_bytes;
+    const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
     if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
     if constexpr (!LSTM) {
         if (a.dz_mask) {          // the fused activation backward has its own instantiation (see cd_epilogue)
@@ -1256,10 +1223,7 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     const int sb = d->precision == JAF_PREC_BF16X3 ? 2 : 1;        // split: [hi planes][lo planes][hi weights][lo weights][table]
     a.off_w = sb * plan->NG * plan->plane;
     a.off_tab = a.off_w + sb * plan->nsteps * plan->MT * 1024;
-    a.off_red = 0;          // the epilogue's reduction scratch: the (idle) patch buffer unless cd_launch_one moves it
     a.ntiles = plan->tiles_x * plan->tiles_p;
-    a.tpw = 1;
-    a.ntgroups = a.ntiles;
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     a.inv_pwp = 1.0f / (float)plan->PWp;
     a.inv_pwq = 1.0f / (float)(plan->ilv ? plan->PWp / plan->NT : plan->PWp);
@@ -1284,30 +1248,6 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.dz_mask_ng8 = a.dz_mask_coff = 0;
     a.dz_slope = 0.f;
     a.dz_dbias = nullptr;
-}
-
-// Pixel tiles per workgroup (conv_dma_kernel's walk).  Measured (profiles/experiments/mb_conv.py, JAF_CONV_TPW = 1 / 2 / 4): the
-// ConvLSTM cell, whose epilogue is long (five transcendentals and six stores per hidden pixel), gains 22 % at the 200 x 200 level
-// (1.196 -> 0.935 ms per step incl. packing) from having the next tile's DMA in flight under it; plain convolutions LOSE 5-30 %
-// (their epilogue is a few stores, and `s_waitcnt vmcnt(0)` in front of the next tile's matrix-core loop also waits for those
-// stores to complete, which a one-tile workgroup never does).  So: the cell kernel only, and only where the launch keeps the
-// chip busy for many rounds anyway (>= 8 rounds of 1024 resident workgroups after the division).  JAF_CONV_TPW forces a value.
-static void cd_set_tpw(ConvDArgs& a, bool lstm) {
-    static const int tpw_env = getenv("JAF_CONV_TPW") ? atoi(getenv("JAF_CONV_TPW")) : 0;
-    const long nblk1 = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
-    // fused-dz data gradients (sign-mask and partner-gradient loads, packed stores, a workgroup reduction in the epilogue): step
-    // 65.2 -> 64.9 ms on top of the cell kernel's 66.0 -> 65.2 (same box, two alternating pairs); JAF_CONV_TPW_DZ=0 switches it off
-    static const int dz_env = getenv("JAF_CONV_TPW_DZ") ? atoi(getenv("JAF_CONV_TPW_DZ")) : 1;
-    // every launch with a packed destination or LayerNorm statistics (the CRN forward layers): step 64.6 -> 63.9 ms (two pairs)
-    static const int dst_env = getenv("JAF_CONV_TPW_DST") ? atoi(getenv("JAF_CONV_TPW_DST")) : 1;
-    const bool walk = lstm || (dz_env && a.dz_mask) || (dst_env && (a.dst || a.stats));
-    int tpw = tpw_env > 0 ? tpw_env : (walk ? (int)(nblk1 / (1024L * 8)) : 1);
-    if (tpw > 4) tpw = 4;
-    if (tpw < 1) tpw = 1;
-    if (tpw > a.ntiles) tpw = a.ntiles;
-    if (a.d.precision == JAF_PREC_BF16X3) tpw = 1;                 // (conv_dma_split_kernel walks one tile)
-    a.tpw = tpw;
-    a.ntgroups = jaf_cdiv(a.ntiles, tpw);
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1371,7 +1311,6 @@ extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, 
     a.out = out;
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
-    cd_set_tpw(a, false);
     if (d->precision == JAF_PREC_BF16X3) {
         // split-bf16: same epilogue, but no packed destination / sign image (those are plain bf16 images)
         JAF_REQUIRE(!a.dst && !a.dz_mask);
@@ -1393,7 +1332,6 @@ extern "C" int jaf_conv2d_fwd_packed_stats(jaf_stream_t s, const jaf_conv_desc* 
     a.out = out;
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
-    cd_set_tpw(a, false);
     if (d->precision == JAF_PREC_BF16X3) return cd_split_launch(a, (hipStream_t)s, false);
     return cd_launch_mt<false>(a, (hipStream_t)s);
 }
@@ -1431,7 +1369,6 @@ extern "C" int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_de
     a.h_out = h_out;
     a.gates_out = (float*)gates_out;
     a.gates_bf16 = gates_bf16 ? 1 : 0;
-    cd_set_tpw(a, true);
     if (d->precision == JAF_PREC_BF16X3) {
         JAF_REQUIRE(!a.dst);
         return cd_split_launch(a, (hipStream_t)s, true);

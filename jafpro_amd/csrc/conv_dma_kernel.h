@@ -11,7 +11,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define CD_OOB 0x40000000
-#define CD_RED_BYTES 1024   // epilogue scratch: [4 waves][16 MT rows] floats at most
 #define CD_RPW 2          // patch DMA rounds per wave (4 waves x 2 rounds x 64 lanes = 512 slots max)
 
 struct ConvDArgs {
@@ -25,9 +24,8 @@ struct ConvDArgs {
     float* gates_out;
     jaf_conv_desc d;
     jaf_conv_plan p;
-    int off_w, off_tab, off_red;   // LDS byte offsets: weight image, slot table, the epilogue's reduction scratch (CD_RED_BYTES)
+    int off_w, off_tab;
     int ntiles, ngroups8;
-    int tpw, ntgroups;             // pixel tiles a workgroup walks; tile groups per (row block, image, group)
     float inv_pwp, inv_pwq, inv_twin;
     int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
