@@ -45,6 +45,7 @@ struct WgDArgs {
     int xng8;              // planes per (image, group) of the packed input image (>= ngin8)
     float inv_pwp;
     int lstmC;             // > 0: dz channels are the ConvLSTM's gate gradients, channel-major (4 c + gate): dW row gate * lstmC + c
+    int off_lo;            // SPLIT: byte offset of the lo tiles from the hi tiles inside a tile buffer (patch and dz alike)
 };
 
 // PAIR (Cin <= 8, i.e. one packed item per position): the 16 columns of an MFMA are TWO taps x 8 channels instead of one
@@ -59,7 +60,10 @@ struct WgDArgs {
 // XI: patch DMA instructions per wave and tile this instantiation provides for (4: stride 1 with up to 32 input channels per
 // workgroup, 8: stride 1 with 64, 11: stride 2).  Their per-lane constants (x_rc, x_goff) stay live across the whole loop: at
 // 11 for everybody the 48-row kernel took 175-181 registers (2 workgroups per CU), at 4 it fits 3.
-template <int MTW, int KS, bool PAIR, bool DB, int XI>
+// SPLIT (d.precision == JAF_PREC_BF16X3): both operands are split-bf16 images (hi plane of channel group cg at 2 cg, lo plane
+// at 2 cg + 1: jaf_conv2d_pack_input / jaf_conv2d_pack_dz_prec), the tile buffer holds [x hi][dz hi][x lo][dz lo], and a product is
+// dz_h x_h + dz_l x_h + dz_h x_l: three matrix-core instructions per fragment pair, fp32-grade gradients.
+template <int MTW, int KS, bool PAIR, bool DB, int XI, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
     constexpr int NTAP = KS * KS;
     constexpr int NACC = PAIR ? (NTAP + 1) / 2 : NTAP;
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         const int grp8 = (ci0 >> 3) + 2 * tci + half;
         const bool live = (i < nxi) && (r < a.PH) && (c < a.PW) && (grp8 < a.ngin8);
         x_rc[j] = live ? ((r << 16) | c) : -1;
-        x_goff[j] = (grp8 * HW + r * d.W + c) * 16;
+        x_goff[j] = ((SPLIT ? 2 * grp8 : grp8) * HW + r * d.W + c) * 16;
     }
     // dz: instruction (co tile j, chunk = wave) covers slots [64*wave, +64) of co tile j (256 slots)
     int z_yx, z_goff, z_half;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         z_half = (raw >> 4) & 1;
         const int y = k >> 4, x = k & 15;
         z_yx = (y << 16) | x;
-        z_goff = (z_half * OHW + y * d.OW + x) * 16;
+        z_goff = ((SPLIT ? 2 * z_half : z_half) * OHW + y * d.OW + x) * 16;
     }
 
     // ---- per-lane constants of the transposed reads: lane = 16q + 4q' + p supplies the address of
@@ -179,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
-    const int xbytes = a.xng8 * HW * 16;
-    const int zbytes = a.ngout8 * OHW * 16;
+    const int xbytes = a.xng8 * HW * 16 * (SPLIT ? 2 : 1);
+    const int zbytes = a.ngout8 * OHW * 16 * (SPLIT ? 2 : 1);
 
     // DMA of one tile (image, pixel tile) into the buffer at byte offset `boff`
     auto issue = [&](int item, int boff) {
@@ -203,12 +207,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 const int iy = iy0 + r, ix = ix0 + c;
                 const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
                 const int tci = i / a.nx;
-                if (DB)      // (from assembly: see jaf_dma16_async)
-                    jaf_dma16_async(rxa, lds0 + boff + tci * a.xplane + (i - tci * a.nx) * 1024, ok ? x_goff[j] + tbase : WD_OOB);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        rx, (__attribute__((address_space(3))) void*)(s_x + boff + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
-                        ok ? x_goff[j] + tbase : WD_OOB, 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < (SPLIT ? 2 : 1); ++h) {
+                    const int src = ok ? x_goff[j] + tbase + h * HW * 16 : WD_OOB;
+                    if (DB)      // (from assembly: see jaf_dma16_async)
+                        jaf_dma16_async(rxa, lds0 + boff + h * a.off_lo + tci * a.xplane + (i - tci * a.nx) * 1024, src);
+                    else
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rx, (__attribute__((address_space(3))) void*)(s_x + boff + h * a.off_lo + tci * a.xplane + (i - tci * a.nx) * 1024), 16,
+                            src, 0, 0, 0);
+                }
             }
         }
         const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(
@@ -221,12 +229,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         for (int mt = 0; mt < MTW; ++mt) {
             const int grp8 = (co0 >> 3) + 2 * mt + z_half;
             const bool ok = okp && (grp8 < a.ngout8);
-            if (DB)
-                jaf_dma16_async(rza, lds0 + a.off_dz + boff + mt * 4096 + wave * 1024, ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB);
-            else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rz, (__attribute__((address_space(3))) void*)(s_dz + boff + mt * 4096 + wave * 1024), 16,
-                    ok ? zb + ((co0 >> 3) + 2 * mt) * OHW * 16 : WD_OOB, 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < (SPLIT ? 2 : 1); ++h) {
+                const int src = ok ? zb + ((co0 >> 3) + 2 * mt) * (SPLIT ? 2 : 1) * OHW * 16 + h * OHW * 16 : WD_OOB;
+                if (DB)
+                    jaf_dma16_async(rza, lds0 + a.off_dz + boff + h * a.off_lo + mt * 4096 + wave * 1024, src);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rz, (__attribute__((address_space(3))) void*)(s_dz + boff + h * a.off_lo + mt * 4096 + wave * 1024), 16, src, 0, 0, 0);
+            }
         }
     };
 
@@ -248,13 +259,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         if (DB) cur ^= a.bufsz;
 
         for (int ks = wk; ks < 4; ks += WK) {
-            bf16x8 af[MTW];
+            bf16x8 af[MTW], al[SPLIT ? MTW : 1];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const unsigned char* ap = c_dz + mt * 4096 + ks * 1024;
                 const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[0]));
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + abase[1]));
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                if constexpr (SPLIT) {
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + a.off_lo + abase[0]));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ap + a.off_lo + abase[1]));
+                    al[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
             }
             if constexpr (PAIR) {
 #pragma unroll
@@ -263,6 +279,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                     bb[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + (padr[pr] & 0xffffu)));
                     bb[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + (padr[pr] >> 16)));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(bb[0], bb[1], 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (SPLIT) {
+                        const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a.off_lo + (padr[pr] & 0xffffu)));
+                        const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a.off_lo + (padr[pr] >> 16)));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) {
+                            acc[mt][pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bf, acc[mt][pr], 0, 0, 0);
+                            acc[mt][pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bl, acc[mt][pr], 0, 0, 0);
+                        }
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
                         acc[mt][pr] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][pr], 0, 0, 0);
@@ -278,6 +304,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                     const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a0));
                     const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a1));
                     const bf16x8 bf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (SPLIT) {
+                        const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a.off_lo + a0));
+                        const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(c_x + a.off_lo + a1));
+                        const bf16x8 bl = __builtin_bit_cast(bf16x8, __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                        for (int mt = 0; mt < MTW; ++mt) {
+                            acc[mt][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bf, acc[mt][ky * KS + kx], 0, 0, 0);
+                            acc[mt][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bl, acc[mt][ky * KS + kx], 0, 0, 0);
+                        }
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MTW; ++mt)
                         acc[mt][ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf, acc[mt][ky * KS + kx], 0, 0, 0);
@@ -351,9 +387,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
 static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 
-template <int MTW, int KS, bool PAIR, bool DB, int XI>
+template <int MTW, int KS, bool PAIR, bool DB, int XI, bool SPLIT>
 static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
-    auto k = conv_wgrad_dma_kernel<MTW, KS, PAIR, DB, XI>;
+    auto k = conv_wgrad_dma_kernel<MTW, KS, PAIR, DB, XI, SPLIT>;
     static int optin[JAF_MAX_DEVICES];
     static JafOcc occ[JAF_MAX_DEVICES][8];
     if (lds > 48 * 1024) {
@@ -368,7 +404,8 @@ static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long d
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
     const long nblk = outblocks * a.nsplit;
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
-    JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI);
+    if (SPLIT) JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d, true>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI);
+    else JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI);
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }
@@ -376,9 +413,18 @@ static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long d
 template <int MTW, int KS, bool PAIR, bool DB>
 static int wgd_launch(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
     const int need = jaf_cdiv(a.WC * a.nx, 4);
-    if (need <= 4) return wgd_launch_xi<MTW, KS, PAIR, DB, 4>(a, lds, items, outblocks, dw_floats, s);
-    if (need <= 8) return wgd_launch_xi<MTW, KS, PAIR, DB, 8>(a, lds, items, outblocks, dw_floats, s);
-    return wgd_launch_xi<MTW, KS, PAIR, DB, WD_XI>(a, lds, items, outblocks, dw_floats, s);
+    if (a.d.precision == JAF_PREC_BF16X3) {
+        if (need <= 4) return wgd_launch_xi<MTW, KS, PAIR, DB, 4, true>(a, lds, items, outblocks, dw_floats, s);
+        if constexpr (!DB) {        // (double-buffered split tiles are at most 40 KB: one 16-channel patch tile, 4 pieces per wave)
+            if (need <= 8) return wgd_launch_xi<MTW, KS, PAIR, false, 8, true>(a, lds, items, outblocks, dw_floats, s);
+            return wgd_launch_xi<MTW, KS, PAIR, false, WD_XI, true>(a, lds, items, outblocks, dw_floats, s);
+        } else {
+            return JAF_EINVAL;
+        }
+    }
+    if (need <= 4) return wgd_launch_xi<MTW, KS, PAIR, DB, 4, false>(a, lds, items, outblocks, dw_floats, s);
+    if (need <= 8) return wgd_launch_xi<MTW, KS, PAIR, DB, 8, false>(a, lds, items, outblocks, dw_floats, s);
+    return wgd_launch_xi<MTW, KS, PAIR, DB, WD_XI, false>(a, lds, items, outblocks, dw_floats, s);
 }
 
 extern "C" int jaf_conv2d_wgrad_packed(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x,
@@ -421,9 +467,18 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     a.PWp = rup_w(a.PW, 8);
     a.xplane = rup_w(a.PH * a.PWp * 32, 1024);
     a.nx = a.xplane / 1024;
+    const bool split = d->precision == JAF_PREC_BF16X3;
+    JAF_REQUIRE(d->precision == JAF_PREC_BF16 || split);
+    JAF_REQUIRE(!(split && hidden));            // (the channel-major gate gradients exist in bf16 only)
     a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
     // stride-2 patches are 22 KB per 16 channels: at most 32 channels per workgroup (more input-channel blocks instead)
     while (a.WC > 1 && jaf_cdiv(a.WC * a.nx, 4) > WD_XI) a.WC >>= 1;
+    // split-bf16: hi and lo tiles of both operands; keep two workgroups per CU (<= 80 KB) where the channel tiling allows
+    while (split && a.WC > 1 && 2 * (a.WC * a.xplane + MTW * 4096) > 80 * 1024) a.WC >>= 1;
+    // experiment hook: narrower input-channel tiles where that lets the split tile be double-buffered (<= 40 KB)
+    static const int split_db = getenv("JAF_WGRAD_SPLIT_DB") ? atoi(getenv("JAF_WGRAD_SPLIT_DB")) : 0;
+    if (split && split_db && d->stride == 1 && 2 * (a.xplane + MTW * 4096) <= 40 * 1024)
+        while (a.WC > 1 && 2 * (a.WC * a.xplane + MTW * 4096) > 40 * 1024) a.WC >>= 1;
     {   // launches that cannot fill the chip: smaller output blocks = more, shorter workgroups (see jafb_wgrad)
         const long items0 = (long)d->N * jaf_cdiv(d->OW, WD_TW) * jaf_cdiv(d->OH, WD_TH);
         const long sp = items0 < JAF_WGRAD_MAX_SPLIT ? items0 : JAF_WGRAD_MAX_SPLIT;
@@ -444,12 +499,14 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     a.ngout8 = jaf_cdiv(d->Cout, 8);
     a.xng8 = x_ng8_tot ? x_ng8_tot : a.ngin8;
     a.inv_pwp = 1.0f / (float)a.PWp;
-    JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 < WD_OOB);
+    JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 * (split ? 2 : 1) < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 * (split ? 2 : 1) < WD_OOB);
     int lds = a.off_dz + MTW * 4096;
+    a.off_lo = split ? lds : 0;
+    if (split) lds *= 2;
     // two tile buffers when two workgroups per CU still fit (see the kernel's header)
     static const int no_db = getenv("JAF_WGRAD_NO_DB") ? 1 : 0;
     static const int db_max = getenv("JAF_WGRAD_DB_MAX_KB") ? atoi(getenv("JAF_WGRAD_DB_MAX_KB")) : 40;      // experiment hook
-    const bool db = !no_db && lds <= db_max * 1024;
+    const bool db = (!split || split_db) && !no_db && lds <= db_max * 1024;
     a.bufsz = db ? lds : 0;
     if (db) lds *= 2;
     const int lds_ep = 4 * 16 * WD_EP * 4;

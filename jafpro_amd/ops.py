@@ -830,8 +830,7 @@ class _ConvFn(Function):
             xp is not None and use_img and m.dst is not None and m.dst.coff % 8 == 0 and m.act in (ACT_LRELU, ACT_RELU)
             and _Y_SIGN_FROM_IMAGE) or (y.stride(0) == 0 and y.numel() > 1) else None
         # the packed bf16 input is kept for the weight gradient when the packed wgrad kernel covers the layer
-        # (split-bf16: the weight gradient stays on the fp32-input split kernel, which reads the fp32 sources)
-        ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m) and _PRECISION == PREC_BF16) else None
+        ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.xp_ng8 = m.prepacked.ng8 if (use_img and m.prepacked is not None) else 0
         ctx.meta = m
         ctx.mode = (_PRECISION, _USE_PACKED)
@@ -1139,7 +1138,7 @@ class _ConvLSTMFn(Function):
                     xp = pack_input([x[t]] if first else [x[t], hprev], d)
                     if final_dst is not None and t + 1 == T and packed_active():
                         io = _io_struct(None, final_dst)
-                if keep and d.precision == PREC_BF16:        # (the packed weight gradient reads them; split-bf16: fp32-input kernel)
+                if keep:
                     xps.append(xp)
                 check(L.jaf_convlstm_cell_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
                                                         None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
@@ -1264,7 +1263,7 @@ class _ConvLSTMFn(Function):
                                                None if first else _p(cprev), _p(cs[t]), _p(dc_prev)),
                       "jaf_convlstm_gates_bwd")
                 ev = _PROF.begin() if _PROF is not None else None
-                if ctx.xps is not None and _packed_path(d) and d.precision == PREC_BF16:
+                if ctx.xps is not None and _packed_path(d):
                     gd = _make_desc(N, G, 4 * C, 1, H, W, H, W, 1, 1, 1, 0, 0, 1, gspec, 1, 0, G, 0, ACT_NONE, 0.0)
                     gtp = pack_input([gt], gd)
                     check(L.jaf_conv2d_wgrad_packed_ex(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
