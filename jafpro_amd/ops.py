@@ -356,7 +356,8 @@ def set_lazy_resize(flag: bool) -> bool:
 
 
 def lazy_resize_active() -> bool:
-    return _LAZY_RESIZE and _USE_PACKED and _PRECISION == PREC_BF16
+    # (split-bf16 too: jaf_conv2d_pack_input_resized writes hi + lo planes, and the weight gradient reads the packed image)
+    return _LAZY_RESIZE and _packed_path_now()
 
 
 def packed_active() -> bool:
