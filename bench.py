@@ -367,14 +367,20 @@ def main():
         # ... and the exact-fp32 arithmetic the north-star parity bar is stated in (v_mfma_f32_16x16x4_f32)
         for mode, key in (("bf16x3", "bf16x3_parity_mode"), ("f32", "f32_parity_mode")):
             ops.set_precision(mode)
-            trainer.train_step(batch)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.parity_mode_steps):
+            nsteps = args.parity_mode_steps if mode == "f32" else max(args.parity_mode_steps, 6)
+            for _ in range(1 if mode == "f32" else 3):      # the allocator's block pattern changes with the mode: let it settle
                 trainer.train_step(batch)
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / args.parity_mode_steps
-            result["config"][key] = {"ms_per_step": dt * 1e3, "frames_per_s": B / dt, "steps": args.parity_mode_steps}
+            ts = []
+            for _ in range(nsteps):
+                t1 = time.perf_counter()
+                trainer.train_step(batch)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            dt = float(np.mean(ts))
+            result["config"][key] = {"ms_per_step": dt * 1e3, "median_ms_per_step": float(np.median(ts)) * 1e3,
+                                     "frames_per_s": B / dt, "steps": nsteps,
+                                     "note": "each step synchronised (no run-ahead of the host): an upper bound of the back-to-back time"}
         ops.set_precision(args.precision)
     if rank == 0 and world == 1 and args.size == 256 and not args.no_config2:
         # BASELINE configs[1]: forward-only clip loop (test/conv_pro_test.py:219-279), B=2 clips x 30 target frames, fp32

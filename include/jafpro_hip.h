@@ -177,6 +177,11 @@ int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const float* y, con
 int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
                                   const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                   const float* c_cur, float* dc_prev, void* packed, float* dbias);
+/* Same with the packed image's arithmetic given (JAF_PREC_BF16 or JAF_PREC_BF16X3: hi + lo planes per channel group, see
+ * jaf_conv2d_pack_dz_prec); the saved gates may be fp32 (gates_bf16 = 0) in either. */
+int jaf_convlstm_gates_bwd_packed_prec(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
+                                       const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
+                                       const float* c_cur, float* dc_prev, void* packed, float* dbias, int precision);
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 /* flags: JAF_PLAN_NO_INTERLEAVE keeps a lane's pixel tiles 16 pixels apart (no pixel interleave): the layout that makes
  * the 16-byte items of a packed bf16 OUTPUT image (jaf_packed_io) contiguous across the lanes of a store -- for launches
@@ -311,6 +316,11 @@ int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, 
 int jaf_layernorm_lrelu_fwd_packed(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                                    const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
                                    int32_t N, int32_t C, int32_t HW, float slope);
+/* Same with the destination image's arithmetic given: JAF_PREC_BF16 (= jaf_layernorm_lrelu_fwd_packed) or JAF_PREC_BF16X3,
+ * a split image -- hi = bf16(v) and lo = bf16(v - hi) planes per channel group (see jaf_conv2d_pack_dz_prec). */
+int jaf_layernorm_lrelu_fwd_packed_prec(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
+                                        const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
+                                        int32_t N, int32_t C, int32_t HW, float slope, int precision);
 /* Backward through lrelu + affine + normalisation.  x is the conv output (pre-norm).
  * dgamma/dbeta are accumulated (+=).                                                            */
 int jaf_layernorm_lrelu_bwd(jaf_stream_t s, const float* dy, const float* x, const float* stats,

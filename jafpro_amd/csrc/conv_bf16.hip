@@ -615,7 +615,7 @@ static int jafb_pack_args(const jaf_conv_desc* d, const jaf_conv_plan* plan, int
         if (mode == JAF_PACK_LSTM) { JAF_REQUIRE((d->Cout & 3) == 0); a.lstmC = d->Cout >> 2; }
     } else if (mode == JAF_PACK_DGRAD || mode == JAF_PACK_DGRAD_LSTM) {
         JAF_REQUIRE(w_rows_tot >= d->Cin && d->w_cin_off + d->Cout <= d->w_cin_tot);
-        if (mode == JAF_PACK_DGRAD_LSTM) { JAF_REQUIRE((d->Cin & 3) == 0 && d->precision == JAF_PREC_BF16); a.redC = d->Cin >> 2; }
+        if (mode == JAF_PACK_DGRAD_LSTM) { JAF_REQUIRE((d->Cin & 3) == 0 && d->precision != JAF_PREC_F32); a.redC = d->Cin >> 2; }
         a.sg = (long)w_rows_tot * d->w_cin_tot * khw;
         a.srow = khw;
         a.sch = (long)d->w_cin_tot * khw;

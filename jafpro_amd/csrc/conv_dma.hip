@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
     float part[8];
     float ypk[8][V];       // y from the packed image: item (pixel i) holds this lane's 8 channels
     if (a.yp && live) {
-        const unsigned char* ip = a.yp + ((((long)n * a.G + g) * a.yp_ng8 + a.yp_cg0 + cg) * HW + (long)yy * a.W + x) * 16;
+        const unsigned char* ip = a.yp + cd_item_off(((long)n * a.G + g) * a.yp_ng8 + a.yp_cg0, 1, cg, HW, (long)yy * a.W + x, a.split);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const u32x4 w = *(const u32x4*)(ip + i * 16);
@@ -606,8 +606,7 @@ extern "C" int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const fl
     PackDzArgs a;
     a.dy = dy; a.y = y; a.out = (unsigned char*)packed; a.dz = dz; a.dbias = dbias;
     a.yp = (const unsigned char*)y_packed; a.yp_ng8 = y_ng8_tot; a.yp_cg0 = y_coff / 8;
-    a.split = precision == JAF_PREC_BF16X3 ? 1 : 0;
-    JAF_REQUIRE(!(a.split && y_packed));        // (the sign image of a split-mode layer is not a plain bf16 image)
+    a.split = precision == JAF_PREC_BF16X3 ? 1 : 0;       // (then y_packed is a split image too: the sign is read from its hi planes)
     const bool al = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
     if (al && W % 4 != 0 && ((long)H * W) % 4 == 0 && (long)H * W < (1L << 30)) { W = H * W; H = 1; }   // as in jaf_conv2d_pack_input
     a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;
@@ -646,7 +645,7 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C
                                                                     const float* __restrict__ dc_next, const GT* __restrict__ gates,
                                                                     const float* __restrict__ c_prev, const float* __restrict__ c_cur,
                                                                     float* __restrict__ dc_prev, unsigned char* __restrict__ packed,
-                                                                    float* __restrict__ dbias, int iters) {
+                                                                    float* __restrict__ dbias, int iters, int split) {
     const int kp = blockIdx.y;                     // hidden-channel pair 2 kp, 2 kp + 1 = item kp of every pixel
     const long ng = blockIdx.z;
     const int g = (int)(ng % G);
@@ -710,15 +709,12 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C
                 dc_prev[e] = dcp[0];
             }
         }
-        unsigned char* op = packed + ((ng * ng8 + kp) * (long)HW + pix) * 16;
+        unsigned char* op = packed + cd_item_off(ng, ng8, kp, HW, pix, split);        // (split-bf16: hi plane, lo plane behind it)
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            u32x4 w;
-            w[0] = cd_pack2(o[0][0][k], o[1][0][k]);
-            w[1] = cd_pack2(o[2][0][k], o[3][0][k]);
-            w[2] = cd_pack2(o[0][1][k], o[1][1][k]);
-            w[3] = cd_pack2(o[2][1][k], o[3][1][k]);
-            *(u32x4*)(op + k * 16) = w;
+            *(u32x4*)(op + k * 16) = cd_item8(o[0][0][k], o[1][0][k], o[2][0][k], o[3][0][k], o[0][1][k], o[1][1][k], o[2][1][k], o[3][1][k], false);
+            if (split)
+                *(u32x4*)(op + (long)HW * 16 + k * 16) = cd_item8(o[0][0][k], o[1][0][k], o[2][0][k], o[3][0][k], o[0][1][k], o[1][1][k], o[2][1][k], o[3][1][k], true);
 #pragma unroll
             for (int a = 0; a < 4; ++a) { sums[2 * a] += o[a][0][k]; sums[2 * a + 1] += o[a][1][k]; }
         }
@@ -740,7 +736,16 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C
 extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
                                              const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                              const float* c_cur, float* dc_prev, void* packed, float* dbias) {
+    return jaf_convlstm_gates_bwd_packed_prec(s, N, G, C, HW, dh, dc_next, gates, gates_bf16, c_prev, c_cur, dc_prev, packed, dbias,
+                                              JAF_PREC_BF16);
+}
+
+extern "C" int jaf_convlstm_gates_bwd_packed_prec(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
+                                                  const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
+                                                  const float* c_cur, float* dc_prev, void* packed, float* dbias, int precision) {
     JAF_REQUIRE(dh && gates && c_cur && dc_prev && packed && dbias && N >= 1 && G >= 1 && C >= 4 && HW >= 1);
+    JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    const int split = precision == JAF_PREC_BF16X3 ? 1 : 0;
     if (C % 4) return JAF_EUNSUPPORTED;
     JAF_REQUIRE(C / 2 <= 65535 && (long)N * G <= 65535);
     const uintptr_t al = ((uintptr_t)dh) | ((uintptr_t)gates) | ((uintptr_t)c_cur) | ((uintptr_t)dc_prev) |
@@ -756,7 +761,7 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
     const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 2, N * G);
 #define JAF_LGC(V_, T_)                                                                                          \
     hipLaunchKernelGGL((lstm_gates_bwd_cmajor_kernel<V_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
-                       (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters)
+                       (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters, split)
     if (gates_bf16) { if (v4) JAF_LGC(4, __bf16); else if (v2) JAF_LGC(2, __bf16); else JAF_LGC(1, __bf16); }
     else { if (v4) JAF_LGC(4, float); else if (v2) JAF_LGC(2, float); else JAF_LGC(1, float); }
 #undef JAF_LGC
@@ -1312,8 +1317,8 @@ extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, 
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
     if (d->precision == JAF_PREC_BF16X3) {
-        // split-bf16: same epilogue, but no packed destination / sign image (those are plain bf16 images)
-        JAF_REQUIRE(!a.dst && !a.dz_mask);
+        // split-bf16: same epilogue; a packed destination is a split image too (hi + lo planes); no fused activation backward
+        JAF_REQUIRE(!a.dz_mask);
         return cd_split_launch(a, (hipStream_t)s, false);
     }
     return cd_launch_mt<false>(a, (hipStream_t)s);
@@ -1370,7 +1375,6 @@ extern "C" int jaf_convlstm_cell_fwd_packed_io(jaf_stream_t s, const jaf_conv_de
     a.gates_out = (float*)gates_out;
     a.gates_bf16 = gates_bf16 ? 1 : 0;
     if (d->precision == JAF_PREC_BF16X3) {
-        JAF_REQUIRE(!a.dst);
         return cd_split_launch(a, (hipStream_t)s, true);
     }
     return cd_launch_mt<true>(a, (hipStream_t)s);

@@ -53,6 +53,16 @@ __device__ __forceinline__ unsigned char* cd_dst_ptr(unsigned char* base, long n
     return base + ((ng * ng8 + (dc >> 3)) * (long)OHW + pix) * 16 + (dc & 7) * 2;
 }
 
+// The same in a split-bf16 image (SP): channel group cg has its hi plane at 2 cg and its lo plane (`lo` = 1) right behind it.
+template <bool SP>
+__device__ __forceinline__ unsigned char* cd_dst_ptr_s(unsigned char* base, long ng, int ng8, int dc, int OHW, int pix, int lo) {
+    if (SP) return base + (((ng * ng8 + (dc >> 3)) * 2 + lo) * (long)OHW + pix) * 16 + (dc & 7) * 2;
+    return cd_dst_ptr(base, ng, ng8, dc, OHW, pix);
+}
+
+// v - bf16(v): what the lo plane of a split-bf16 image holds
+__device__ __forceinline__ float cd_resid(float v) { return v - (float)(__bf16)v; }
+
 __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
     f32x2 v = {a, b};
     bf16x2 r = __builtin_convertvector(v, bf16x2);
@@ -65,7 +75,9 @@ __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
 // DZ: the fused activation backward of jaf_packed_io.dz_mask.  A template parameter, not a run-time branch: with the dz
 // code in every instantiation the compiler kept its extra live ranges in ALL of them (conv_dma_kernel<4,4,false>: 160 -> 192
 // VGPRs, 3 -> 2 waves per SIMD, 9.5 -> 11.0 ms per step over its 94 launches).
-template <int MT, int NT, bool LSTM, bool DZ, bool PLAIN>
+// SPD: the packed destination is a split-bf16 image (conv_dma_split.hip): every packed store is issued twice, the hi words
+// into the group's first plane and the residual words into the plane behind it.  Never together with DZ.
+template <int MT, int NT, bool LSTM, bool DZ, bool PLAIN, bool SPD = false>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
                                             int n, int g, int mb, int q, int OHW, unsigned char* smem,
                                             const f32x4 (&cpre)[MT]) {
@@ -128,6 +140,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wsum[mt][j] = 0.f;
             const int cpad = a.dst_pad_tail ? ((a.dst_coff + dC + 7) & ~7) - a.dst_coff : dC;   // rows < cpad are written
+#pragma unroll
+            for (int sp = 0; sp < (SPD ? 2 : 1); ++sp)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int co0 = mb * MR + mt * 16 + q * 4;
@@ -211,15 +225,19 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     } else {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = (co0 + j < d.Cout) ? jaf_act(acc[mt][nt][j] + bv[j], d.act, d.slope) : 0.f;
+                        if (SPD && sp == 1) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = cd_resid(v[j]);
+                        }
                     }
                     wl[nt] = cd_pack2(v[0], v[1]);
                     wh[nt] = cd_pack2(v[2], v[3]);
                     if (pair_ok) continue;
                     if (co0 + 4 <= cpad || a.dst_pad_tail) {
                         const u32x2 w = {wl[nt], wh[nt]};
-                        *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]) = w;
+                        *(u32x2*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt], sp) = w;
                     } else {           // a 4-group that straddles the end of this source: channel by channel
-                        unsigned short* hp = (unsigned short*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt]);
+                        unsigned short* hp = (unsigned short*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt], sp);
                         const unsigned int ww[2] = {wl[nt], wh[nt]};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -238,11 +256,11 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     const int cbase = a.dst_coff + (co0 & ~4);
                     if (pA >= 0) {
                         const u32x4 w = {a0, a1, b0, b1};
-                        *(u32x4*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, cbase, OHW, pA) = w;
+                        *(u32x4*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, cbase, OHW, pA, sp) = w;
                     }
                     if (pB >= 0) {
                         const u32x4 w = {c0, c1, e0, e1};
-                        *(u32x4*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, cbase, OHW, pB) = w;
+                        *(u32x4*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, cbase, OHW, pB, sp) = w;
                     }
                 }
                 if (DZ && a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
@@ -391,14 +409,21 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                                      : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
                         if (live) {
                             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-                            const u32x2 w = {cd_pack2(__builtin_bit_cast(float, t0), __builtin_bit_cast(float, t1)),
-                                             cd_pack2(__builtin_bit_cast(float, t2), __builtin_bit_cast(float, t3))};
-                            *(u32x2*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + (ch - q), OHW, opix[0] + q) = w;
+                            const float f0 = __builtin_bit_cast(float, t0), f1 = __builtin_bit_cast(float, t1);
+                            const float f2 = __builtin_bit_cast(float, t2), f3 = __builtin_bit_cast(float, t3);
+                            const u32x2 w = {cd_pack2(f0, f1), cd_pack2(f2, f3)};
+                            *(u32x2*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + (ch - q), OHW, opix[0] + q, 0) = w;
+                            if (SPD) {
+                                const u32x2 wr = {cd_pack2(cd_resid(f0), cd_resid(f1)), cd_pack2(cd_resid(f2), cd_resid(f3))};
+                                *(u32x2*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + (ch - q), OHW, opix[0] + q, 1) = wr;
+                            }
                         }
                     } else {
 #pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            *(__bf16*)cd_dst_ptr(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt) = (__bf16)vh[nt];
+                        for (int nt = 0; nt < NT; ++nt) {
+                            *(__bf16*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt, 0) = (__bf16)vh[nt];
+                            if (SPD) *(__bf16*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + ch, OHW, opix[0] + nt, 1) = (__bf16)cd_resid(vh[nt]);
+                        }
                     }
                 }
                 if (a.gates_out && live) {
@@ -435,8 +460,10 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     a.c_out[hc + opix[nt]] = cc;
                     const float hv = go * jaf_tanh(cc);
                     if (!a.skip_f32) a.h_out[hc + opix[nt]] = hv;
-                    if (a.dst)
-                        *(__bf16*)cd_dst_ptr(a.dst, ((long)(n + a.dst_img_off)) * d.G + g, a.dst_ng8, a.dst_coff + ch, OHW, opix[nt]) = (__bf16)hv;
+                    if (a.dst) {
+                        *(__bf16*)cd_dst_ptr_s<SPD>(a.dst, ((long)(n + a.dst_img_off)) * d.G + g, a.dst_ng8, a.dst_coff + ch, OHW, opix[nt], 0) = (__bf16)hv;
+                        if (SPD) *(__bf16*)cd_dst_ptr_s<SPD>(a.dst, ((long)(n + a.dst_img_off)) * d.G + g, a.dst_ng8, a.dst_coff + ch, OHW, opix[nt], 1) = (__bf16)cd_resid(hv);
+                    }
                     if (a.gates_out) {
                         if (a.gates_bf16) {
                             __bf16* gp = (__bf16*)a.gates_out + gc + ((long)ch * OHW + opix[nt]) * 4;

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
         }
     }
 
-    cd_epilogue<MT, NT, LSTM, false, false>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
+    cd_epilogue<MT, NT, LSTM, false, false, true>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
 }
 
 template <int MT, int NT, bool LSTM>

@@ -150,7 +150,7 @@ template <int V>
 __global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   float* __restrict__ y, unsigned char* __restrict__ dst, int dst_ng8,
-                                                                  int dst_cg0, int C, int HW, float slope) {
+                                                                  int dst_cg0, int C, int HW, float slope, int split) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const float* _
             }
         }
     }
-    unsigned char* op = dst + (((long)n * dst_ng8 + dst_cg0 + cg) * (long)HW + pix) * 16;
+    // split-bf16 destination: group cg's hi plane at 2 cg, the residual plane (v - bf16(v)) right behind it
+    unsigned char* op = dst + ((((long)n * dst_ng8 + dst_cg0 + cg) * (split ? 2 : 1)) * (long)HW + pix) * 16;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         u32x4 w;
@@ -194,21 +195,38 @@ __global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const float* _
             w[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2));
         }
         *(u32x4*)(op + k * 16) = w;
+        if (split) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a0 = o[2 * u][k], a1 = o[2 * u + 1][k];
+                const f32x2 v2 = {a0 - (float)(__bf16)a0, a1 - (float)(__bf16)a1};
+                w[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2));
+            }
+            *(u32x4*)(op + (long)HW * 16 + k * 16) = w;
+        }
     }
 }
 
 extern "C" int jaf_layernorm_lrelu_fwd_packed(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                                               const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
                                               int32_t N, int32_t C, int32_t HW, float slope) {
+    return jaf_layernorm_lrelu_fwd_packed_prec(s, x, stats, gamma, beta, y, dst, dst_ng8_tot, dst_coff, N, C, HW, slope, JAF_PREC_BF16);
+}
+
+extern "C" int jaf_layernorm_lrelu_fwd_packed_prec(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
+                                              const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
+                                              int32_t N, int32_t C, int32_t HW, float slope, int precision) {
     JAF_REQUIRE(x && stats && gamma && beta && dst && N >= 1 && C >= 1 && HW >= 1 && N <= 65535);
+    JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    const int split = precision == JAF_PREC_BF16X3 ? 1 : 0;
     JAF_REQUIRE(dst_coff >= 0 && (dst_coff & 7) == 0 && dst_coff / 8 + jaf_cdiv(C, 8) <= dst_ng8_tot && jaf_cdiv(C, 8) <= 65535);
     const dim3 block(256);
     if ((HW % 4 == 0) && al16(x, y))
         hipLaunchKernelGGL(ln_lrelu_fwd_packed_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), jaf_cdiv(C, 8), N), block, 0, (hipStream_t)s, x,
-                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope);
+                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope, split);
     else
         hipLaunchKernelGGL(ln_lrelu_fwd_packed_kernel<1>, dim3(jaf_cdiv(HW, 256), jaf_cdiv(C, 8), N), block, 0, (hipStream_t)s, x,
-                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope);
+                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope, split);
     return jaf_launch_status();
 }
 

@@ -469,7 +469,6 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     a.nx = a.xplane / 1024;
     const bool split = d->precision == JAF_PREC_BF16X3;
     JAF_REQUIRE(d->precision == JAF_PREC_BF16 || split);
-    JAF_REQUIRE(!(split && hidden));            // (the channel-major gate gradients exist in bf16 only)
     a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
     // stride-2 patches are 22 KB per 16 channels: at most 32 channels per workgroup (more input-channel blocks instead)
     while (a.WC > 1 && jaf_cdiv(a.WC * a.nx, 4) > WD_XI) a.WC >>= 1;

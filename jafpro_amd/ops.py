@@ -304,20 +304,28 @@ class PackedImage:
     never built in fp32 and no separate packing pass exists (include/jafpro_hip.h, jaf_packed_io).  Only made while
     the packed bf16 path is active (`packed_active()`); module code passes None otherwise and everything falls back to
     jaf_conv2d_pack_input."""
-    __slots__ = ("buf", "N", "G", "C", "ng8", "H", "W")
+    __slots__ = ("buf", "N", "G", "C", "ng8", "H", "W", "split")
 
-    def __init__(self, N: int, G: int, C: int, H: int, W: int, device, zero: bool = False, buf: Optional[torch.Tensor] = None):
+    def __init__(self, N: int, G: int, C: int, H: int, W: int, device, zero: bool = False, buf: Optional[torch.Tensor] = None,
+                 split: Optional[bool] = None):
         self.N, self.G, self.C, self.H, self.W = int(N), int(G), int(C), int(H), int(W)
         self.ng8 = (self.C + 7) // 8
-        n = self.N * self.G * self.ng8 * self.H * self.W * 16
+        # split-bf16 (JAF_PREC_BF16X3): every channel group as a hi and a lo plane, [N][G][ng8][hi, lo][H*W][8] -- twice the bytes
+        self.split = (_PRECISION == PREC_BF16X3) if split is None else bool(split)
+        n = self.N * self.per_image
         if buf is None:
             buf = (torch.zeros if zero else torch.empty)(n, device=device, dtype=torch.uint8)
         self.buf = buf
 
+    @property
+    def per_image(self) -> int:
+        """Bytes of one image (all groups and planes)."""
+        return self.G * self.ng8 * self.H * self.W * 16 * (2 if self.split else 1)
+
     def images(self, n0: int, n: int) -> "PackedImage":
         """The sub-image holding images n0 .. n0+n (a view of the same memory)."""
-        per = self.G * self.ng8 * self.H * self.W * 16
-        return PackedImage(n, self.G, self.C, self.H, self.W, self.buf.device, buf=self.buf[n0 * per:(n0 + n) * per])
+        per = self.per_image
+        return PackedImage(n, self.G, self.C, self.H, self.W, self.buf.device, buf=self.buf[n0 * per:(n0 + n) * per], split=self.split)
 
     def slot(self, coff: int = 0, img_off: int = 0, pad_tail: bool = False) -> "PackedDst":
         return PackedDst(self, coff, img_off, pad_tail)
@@ -361,8 +369,9 @@ def lazy_resize_active() -> bool:
 
 
 def packed_active() -> bool:
-    """True while convolutions run on the packed-input bf16 kernels (the only mode PackedImages apply to)."""
-    return _PACKED_IMAGES and _USE_PACKED and _PRECISION == PREC_BF16
+    """True while convolutions run on the packed-input kernels (bf16, or split-bf16 with hi + lo planes): the modes
+    PackedImages apply to."""
+    return _PACKED_IMAGES and _packed_path_now()
 
 
 def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False,
@@ -386,6 +395,8 @@ def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_
 
 
 def _check_image(img: PackedImage, N, G, Cin, H, W, what: str):
+    if img.split != (_PRECISION == PREC_BF16X3):
+        raise RuntimeError("%s: packed image made in another arithmetic mode (split = %s)" % (what, img.split))
     if (img.N, img.G, img.H, img.W) != (N, G, H, W) or img.C < Cin:
         raise RuntimeError("%s: packed image [N=%d G=%d C=%d %dx%d] does not fit N=%d G=%d Cin=%d %dx%d"
                            % (what, img.N, img.G, img.C, img.H, img.W, N, G, Cin, H, W))
@@ -899,11 +910,11 @@ class _ConvFn(Function):
                 for n0, n1 in _n_chunks(m.N, m.G * ng8):
                     if yimg is not None:
                         img, ycoff, yoff = yimg
-                        yper = img.G * img.ng8 * img.H * img.W * 16
-                        check(L.jaf_conv2d_pack_dz_ex(_s(), _p(dy[n0:n1]), None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
-                                                      img.ng8, ycoff, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
-                                                      _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
-                                                      _p(dbt)), "jaf_conv2d_pack_dz_ex")
+                        yper = img.per_image
+                        check(L.jaf_conv2d_pack_dz_prec(_s(), _p(dy[n0:n1]), None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
+                                                        img.ng8, ycoff, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
+                                                        _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
+                                                        _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_prec")
                         continue
                     check(L.jaf_conv2d_pack_dz_prec(_s(), _p(dy[n0:n1]), _p(y[n0:n1]) if m.act != ACT_NONE else None, None, 0, 0,
                                                     n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
@@ -1203,7 +1214,8 @@ class _ConvLSTMFn(Function):
         w_inplace, b_inplace = _grad_inplace(weight), _grad_inplace(bias)
         dw = weight.grad if w_inplace else torch.empty_like(weight)
         # fused path: gate backward writes the packed bf16 gate gradients + the bias sums directly
-        fused = ctx.xps is not None and _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
+        # (split-bf16 too: the saved gates are fp32 there, the packed gate gradients carry hi + lo planes)
+        fused = ctx.xps is not None and _packed_path_now() and C % 4 == 0
         if (gates.dtype == torch.bfloat16 or ctx.h_skipped) and not fused:
             raise RuntimeError("convlstm: precision changed between forward and backward")
         if b_inplace:
@@ -1240,11 +1252,11 @@ class _ConvLSTMFn(Function):
             gspec = [(4 * C, 4 * GC, 0, 4 * C)]
             gtp = None       # packed gate gradients: shared by the weight gradient and the two data gradients
             if fused:
-                gtp = torch.empty(N * G * ng8 * H * W * 16, device=x.device, dtype=torch.uint8)
+                gtp = torch.empty(N * G * ng8 * H * W * 16 * (2 if _PRECISION == PREC_BF16X3 else 1), device=x.device, dtype=torch.uint8)
                 with _hbm("lstm_gates_bwd_pack_kernel", N * G * C * H * W * (4.0 * (4 if first else 5) + 4.0 * gt.element_size()) + gtp.numel()):
-                    check(L.jaf_convlstm_gates_bwd_packed(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                                          1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cprev), _p(cs[t]), _p(dc_prev), _p(gtp),
-                                                          _p(db)), "jaf_convlstm_gates_bwd_packed")
+                    check(L.jaf_convlstm_gates_bwd_packed_prec(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
+                                                               1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cprev), _p(cs[t]),
+                                                               _p(dc_prev), _p(gtp), _p(db), _PRECISION), "jaf_convlstm_gates_bwd_packed_prec")
                 wst = _WGRAD_STREAM if w_inplace else None      # see set_wgrad_stream
                 if wst is not None:
                     wst.wait_stream(torch.cuda.current_stream())
@@ -1372,8 +1384,9 @@ class _LayerNormLReLUFn(Function):
             # returned tensor is a storage-less autograd handle (the backward pass needs x and the statistics, not y)
             y = (torch.empty_like(x) if keep_f32 else
                  torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=torch.float32))
-            check(L.jaf_layernorm_lrelu_fwd_packed(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y) if keep_f32 else None, _p(dst.image.buf),
-                                                   dst.image.ng8, dst.coff, N, C, H * W, slope), "jaf_layernorm_lrelu_fwd_packed")
+            check(L.jaf_layernorm_lrelu_fwd_packed_prec(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y) if keep_f32 else None,
+                                                        _p(dst.image.buf), dst.image.ng8, dst.coff, N, C, H * W, slope, _PRECISION),
+                  "jaf_layernorm_lrelu_fwd_packed_prec")
         else:
             y = torch.empty_like(x)
             check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
