@@ -404,8 +404,7 @@ static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long d
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
     const long nblk = outblocks * a.nsplit;
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
-    if (SPLIT) JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d, true>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI);
-    else JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI);
+    JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d, %s>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI, SPLIT ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }
