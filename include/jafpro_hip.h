@@ -337,6 +337,12 @@ int jaf_layernorm_lrelu_bwd_packed(jaf_stream_t s, const float* dy, const float*
                                    const float* gamma, const float* beta, void* packed_dx, float* dgamma,
                                    float* dbeta, double* workspace /* 32*N doubles */, float* scratch, float* conv_dbias,
                                    int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps);
+/* Same with the packed dx image's arithmetic given (JAF_PREC_BF16 or JAF_PREC_BF16X3: hi + lo planes, see jaf_conv2d_pack_dz_prec). */
+int jaf_layernorm_lrelu_bwd_packed_prec(jaf_stream_t s, const float* dy, const float* x, const float* stats,
+                                        const float* gamma, const float* beta, void* packed_dx, float* dgamma,
+                                        float* dbeta, double* workspace, float* scratch, float* conv_dbias,
+                                        int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps,
+                                        int precision);
 
 /* BatchNorm2d in training mode (src/flow_net.py:13-51, src/networks.py:369-390; eps 1e-5,
  * momentum 0.1, biased var for normalisation, unbiased for running_var) + activation

@@ -374,7 +374,7 @@ template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                   const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, const double* __restrict__ ws,
-                                                                  unsigned char* __restrict__ dst, int C, int HW, float slope, float eps) {
+                                                                  unsigned char* __restrict__ dst, int C, int HW, float slope, float eps, int split) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const float* _
             }
         }
     }
-    unsigned char* op = dst + (((long)n * gridDim.y + cg) * (long)HW + pix) * 16;
+    // (split-bf16: hi plane of the group at 2 cg, the residual plane right behind it)
+    unsigned char* op = dst + ((((long)n * gridDim.y + cg) * (split ? 2 : 1)) * (long)HW + pix) * 16;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         u32x4 wv;
@@ -423,6 +424,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const float* _
             wv[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2));
         }
         *(u32x4*)(op + k * 16) = wv;
+        if (split) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a0 = o[2 * u][k], a1 = o[2 * u + 1][k];
+                const f32x2 v2 = {a0 - (float)(__bf16)a0, a1 - (float)(__bf16)a1};
+                wv[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(v2, bf16x2));
+            }
+            *(u32x4*)(op + (long)HW * 16 + k * 16) = wv;
+        }
     }
 }
 
@@ -449,7 +459,18 @@ extern "C" int jaf_layernorm_lrelu_bwd_packed(jaf_stream_t s_, const float* dy, 
                                               const float* gamma, const float* beta, void* packed_dx, float* dgamma,
                                               float* dbeta, double* workspace, float* scratch, float* conv_dbias,
                                               int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps) {
+    return jaf_layernorm_lrelu_bwd_packed_prec(s_, dy, x, stats, gamma, beta, packed_dx, dgamma, dbeta, workspace, scratch, conv_dbias,
+                                               accumulate_dbias, N, C, HW, slope, eps, JAF_PREC_BF16);
+}
+
+extern "C" int jaf_layernorm_lrelu_bwd_packed_prec(jaf_stream_t s_, const float* dy, const float* x, const float* stats,
+                                                   const float* gamma, const float* beta, void* packed_dx, float* dgamma,
+                                                   float* dbeta, double* workspace, float* scratch, float* conv_dbias,
+                                                   int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps,
+                                                   int precision) {
     JAF_REQUIRE(dy && x && stats && gamma && beta && packed_dx && dgamma && dbeta && workspace && scratch);
+    JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    const int split = precision == JAF_PREC_BF16X3 ? 1 : 0;
     JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535 && C <= 65535);
     hipStream_t s = (hipStream_t)s_;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * LN_BWD_SLOTS * N, s);
@@ -464,10 +485,10 @@ extern "C" int jaf_layernorm_lrelu_bwd_packed(jaf_stream_t s_, const float* dy, 
     hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
     if (v4)
         hipLaunchKernelGGL(ln_bwd_apply_packed_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), jaf_cdiv(C, 8), N), dim3(256), 0, s, dy, x, stats,
-                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps);
+                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps, split);
     else
         hipLaunchKernelGGL(ln_bwd_apply_packed_kernel<1>, dim3(jaf_cdiv(HW, 256), jaf_cdiv(C, 8), N), dim3(256), 0, s, dy, x, stats,
-                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps);
+                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps, split);
     if (conv_dbias)
         hipLaunchKernelGGL(ln_bwd_conv_bias_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, scratch, stats, workspace, conv_dbias, N, C,
                            HW, eps, accumulate_dbias ? 1 : 0);

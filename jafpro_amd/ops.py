@@ -1354,7 +1354,7 @@ def _ln_producer(x: torch.Tensor):
     if not _FUSED_DZ or fn is None or type(fn).__name__ != "_ConvFnBackward":
         return None
     pm = getattr(fn, "meta", None)
-    if pm is None or pm.act != ACT_NONE or pm.G != 1 or pm.Cout != x.shape[1] or getattr(fn, "mode", None) != (PREC_BF16, True):
+    if pm is None or pm.act != ACT_NONE or pm.G != 1 or pm.Cout != x.shape[1] or getattr(fn, "mode", None) != (_PRECISION, True):
         return None
     if getattr(fn, "y_img", None) is not None or (fn.needs_input_grad[0] and fn.xp is None):
         return None
@@ -1368,7 +1368,7 @@ class _LayerNormLReLUFn(Function):
         L = lib()
         # backward hand-over: x is a convolution's output and this LayerNorm its only reader -> dx goes back as that layer's
         # packed dz (+ bias gradient), no fp32 dx, no jaf_conv2d_pack_dz pass
-        ctx.prod = _ln_producer(x) if (sole and ctx.needs_input_grad[0] and _USE_PACKED and _PRECISION == PREC_BF16) else None
+        ctx.prod = _ln_producer(x) if (sole and ctx.needs_input_grad[0] and _packed_path_now()) else None
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
         if pre is not None and pre.filled:       # sums came out of the producing convolution's epilogue
             check(L.jaf_layernorm_finalize(_s(), _p(pre.sums), N, pre.slots, C * H * W, eps, _p(stats)), "jaf_layernorm_finalize")
@@ -1406,9 +1406,9 @@ class _LayerNormLReLUFn(Function):
         dbeta = beta.grad if bi else torch.zeros_like(beta)
         ws = torch.empty(32 * N, device=x.device, dtype=torch.float64)      # [N][16 slots][2], include/jafpro_hip.h
         prod = getattr(ctx, "prod", None)
-        if prod is not None and _PRECISION == PREC_BF16 and _USE_PACKED:
+        if prod is not None and _packed_path_now() and prod.mode == (_PRECISION, True):
             ctx.prod = None
-            dzp = torch.empty(N * ((C + 7) // 8) * H * W * 16, device=x.device, dtype=torch.uint8)
+            dzp = torch.empty(N * ((C + 7) // 8) * H * W * 16 * (2 if _PRECISION == PREC_BF16X3 else 1), device=x.device, dtype=torch.uint8)
             scratch = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)
             pb = prod.bias_ref
             db, dbt, acc = None, None, 0
@@ -1418,9 +1418,9 @@ class _LayerNormLReLUFn(Function):
                 else:
                     dbt = db = torch.empty(C, device=x.device, dtype=torch.float32)
             with _hbm("ln_bwd_apply_packed_kernel", x.numel() * 8.0 + dzp.numel()):
-                check(lib().jaf_layernorm_lrelu_bwd_packed(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dzp), _p(dgamma),
-                                                           _p(dbeta), _p(ws), _p(scratch), _p(dbt), acc, N, C, H * W, ctx.slope, ctx.eps),
-                      "jaf_layernorm_lrelu_bwd_packed")
+                check(lib().jaf_layernorm_lrelu_bwd_packed_prec(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dzp), _p(dgamma),
+                                                                _p(dbeta), _p(ws), _p(scratch), _p(dbt), acc, N, C, H * W, ctx.slope, ctx.eps,
+                                                                _PRECISION), "jaf_layernorm_lrelu_bwd_packed_prec")
             prod.fused = (dzp, db)
             FUSED_STATS["ln"] += 1
             dx = torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=torch.float32)     # placeholder
