@@ -1317,8 +1317,7 @@ extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, 
     a.stats = stats;
     a.stat_slots = stats ? stat_slots : 1;
     if (d->precision == JAF_PREC_BF16X3) {
-        // split-bf16: same epilogue; a packed destination is a split image too (hi + lo planes); no fused activation backward
-        JAF_REQUIRE(!a.dz_mask);
+        // split-bf16: same epilogue; a packed destination / sign image is a split image too (hi + lo planes)
         return cd_split_launch(a, (hipStream_t)s, false);
     }
     return cd_launch_mt<false>(a, (hipStream_t)s);

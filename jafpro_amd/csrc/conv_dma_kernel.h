@@ -76,7 +76,7 @@ __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
 // code in every instantiation the compiler kept its extra live ranges in ALL of them (conv_dma_kernel<4,4,false>: 160 -> 192
 // VGPRs, 3 -> 2 waves per SIMD, 9.5 -> 11.0 ms per step over its 94 launches).
 // SPD: the packed destination is a split-bf16 image (conv_dma_split.hip): every packed store is issued twice, the hi words
-// into the group's first plane and the residual words into the plane behind it.  Never together with DZ.
+// into the group's first plane and the residual words into the plane behind it (DZ: the sign mask is read from the hi plane).
 template <int MT, int NT, bool LSTM, bool DZ, bool PLAIN, bool SPD = false>
 __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&acc)[MT][NT], const int (&opix)[NT],
                                             int n, int g, int mb, int q, int OHW, unsigned char* smem,
@@ -160,8 +160,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     for (int nt = 0; nt < NT; ++nt) {
                         mk[nt][0] = mk[nt][1] = 0u;
                         if (opix[nt] >= 0) {
-                            const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
-                                                                                      a.dz_mask_coff + co0, OHW, opix[nt]);
+                            const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr_s<SPD>((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
+                                                                                             a.dz_mask_coff + co0, OHW, opix[nt], 0);
                             mk[nt][0] = xp2[0];
                             mk[nt][1] = xp2[1];
                         }
@@ -219,8 +219,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                                 if (a.acc_out) t += part[j][nt];
                                 t *= (xs[j] > 0.f) ? 1.f : a.dz_slope;
                             }
-                            v[j] = t;
-                            bsum[j] += t;
+                            if (!SPD || sp == 0) bsum[j] += t;
+                            v[j] = (SPD && sp == 1) ? cd_resid(t) : t;
                         }
                     } else {
 #pragma unroll
@@ -263,7 +263,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         *(u32x4*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, cbase, OHW, pB, sp) = w;
                     }
                 }
-                if (DZ && a.dz_dbias) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
+                if (DZ && a.dz_dbias && (!SPD || sp == 0)) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = bsum[j];

@@ -13,7 +13,7 @@
 // Tiling, slot table, pixel interleave, block -> tile mapping and the epilogue are those of conv_dma_kernel (conv_dma_kernel.h).
 #include "conv_dma_kernel.h"
 
-template <int MT, int NT, bool LSTM>
+template <int MT, int NT, bool LSTM, bool DZ>
 __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
         }
     }
 
-    cd_epilogue<MT, NT, LSTM, false, false, true>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
+    cd_epilogue<MT, NT, LSTM, DZ, false, true>(a, acc, opix, n, g, mb, q, OHW, smem, cpre);
 }
 
 template <int MT, int NT, bool LSTM>
@@ -212,13 +212,26 @@ static int cds_launch_one(const ConvDArgs& a, hipStream_t s) {
     const int lds = a.p.lds_bytes;
     const long nblk = (long)a.ntiles * a.p.mblocks * a.d.N * a.d.G;
     if (nblk < 1 || nblk > 0x7fffffffL) return JAF_EINVAL;
-    auto k = conv_dma_split_kernel<MT, NT, LSTM>;
+    if constexpr (!LSTM) {
+        if (a.dz_mask) {          // the fused activation backward has its own instantiation (see cd_epilogue)
+            auto kz = conv_dma_split_kernel<MT, NT, false, true>;
+            static int optin_z[JAF_MAX_DEVICES];
+            if (lds > 48 * 1024) {
+                const int e = jaf_lds_optin((const void*)kz, optin_z);
+                if (e) return e;
+            }
+            JAF_NOTE_KERNEL("conv_dma_split_kernel<%d, %d, false, true>", MT, NT);
+            hipLaunchKernelGGL(kz, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+            return jaf_launch_status();
+        }
+    }
+    auto k = conv_dma_split_kernel<MT, NT, LSTM, false>;
     static int optin[JAF_MAX_DEVICES];
     if (lds > 48 * 1024) {
         const int e = jaf_lds_optin((const void*)k, optin);
         if (e) return e;
     }
-    JAF_NOTE_KERNEL("conv_dma_split_kernel<%d, %d, %s>", MT, NT, LSTM ? "true" : "false");
+    JAF_NOTE_KERNEL("conv_dma_split_kernel<%d, %d, %s, false>", MT, NT, LSTM ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }

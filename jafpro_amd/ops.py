@@ -774,7 +774,7 @@ def _fusable_producer(t: torch.Tensor, spec):
     if fn is None or type(fn).__name__ != "_ConvFnBackward" or spec[3] == 0:
         return None
     pm = getattr(fn, "meta", None)
-    if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or getattr(fn, "mode", None) != (PREC_BF16, True):
+    if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or not _packed_path_now() or getattr(fn, "mode", None) != (_PRECISION, True):
         return None
     if pm.G * pm.Cout != t.shape[1] or spec[0] != pm.Cout:          # the whole output, group for group
         return None

@@ -318,7 +318,7 @@ def test_packed_images_are_bit_identical_to_the_packing_pass(mode):
     """Packed path (bf16, and split-bf16 with hi + lo planes): producers writing straight into the consumer's packed image
     (ops.PackedImage: encoder chains, the ConvLSTM [x, h] sequence images, h_t only as bf16 for t < T-1 in bf16 mode) must give the
     very numbers of the path that packs every layer's input with jaf_conv2d_pack_input -- outputs, input gradient and every
-    parameter gradient.  The data-gradient hand-over (fused dz) exists in bf16 mode only; the LayerNorm -> convolution one in both."""
+    parameter gradient.  The backward hand-overs (fused dz, LayerNorm -> convolution) exist in both modes."""
     from jafpro_amd import ops, synth
     from jafpro_amd.crn_model import CRN_smaller
     from jafpro_amd.networks import Accumulate_LSTM_no_loss, UNet_inpainter, VGG19_CRN
@@ -355,7 +355,7 @@ def test_packed_images_are_bit_identical_to_the_packing_pass(mode):
                     # two consumers: the ConvLSTM's d x launches / enc_{i+1}) and x2, x4, x6, x8 (one consumer: the stride-2
                     # layer that follows), in VGG the untapped conv -> conv edges;
                     # the reference path packs every dz in a pass of its own
-                    want = {Accumulate_LSTM_no_loss: 8, UNet_inpainter: 8, VGG19_CRN: 7, CRN_smaller: 0}[cls] if (images and mode == "bf16") else 0
+                    want = {Accumulate_LSTM_no_loss: 8, UNet_inpainter: 8, VGG19_CRN: 7, CRN_smaller: 0}[cls] if images else 0
                     assert ops.FUSED_STATS["dz"] - handed == want, (cls.__name__, images, ops.FUSED_STATS["dz"] - handed)
                     # every conv -> LayerNorm pair of the CRN gets its dz from the LayerNorm backward (packed bf16, with or without
                     # the images): 13 blocks x 2
