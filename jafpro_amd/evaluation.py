@@ -103,12 +103,30 @@ def l1_normalised(pred_u8: torch.Tensor, gt_u8: torch.Tensor) -> torch.Tensor:
 
 class VideoEvaluator(torch.nn.Module):
     """perceptual_criterion = VGGLoss_CRN(weights=[1/2.6, 1/4.8, 1/3.7, 1/5.6, 10/1.5]) (video_evaluation.py:66) plus the
-    closed-form metrics.  VGG weights come from load_state_dict (the ImageNet weights are not available offline)."""
+    closed-form metrics.  VGG weights come from load_state_dict (the ImageNet weights are not available offline).
+    `with_flow=True` adds the script's FlowNetSD temporal term (:66-67): its weights are the external FlowNet2-SD checkpoint --
+    until they have been loaded (`load_flow_weights`, or a load_state_dict that carries `flow_criterion.*` keys) the evaluator
+    reports NaN for "flow" instead of a number computed from the random initialisation."""
 
-    def __init__(self):
+    def __init__(self, with_flow: bool = True):
         super().__init__()
         self.perceptual_criterion = VGGLoss_CRN(weights=[1 / 2.6, 1 / 4.8, 1 / 3.7, 1 / 5.6, 10 / 1.5])
-        self.flow_criterion = FlowNetSD(args=[], batchNorm=False)        # left in train mode like the script: `[0]` = flow2
+        # left in train mode like the script: `[0]` = flow2
+        self.flow_criterion = FlowNetSD(args=[], batchNorm=False) if with_flow else None
+        self.flow_weights_loaded = False
+
+    def load_flow_weights(self, state_dict, strict: bool = True):
+        """FlowNet2-SD weights (the reference loads `FlowNet2-SD_checkpoint.pth.tar`['state_dict'], video_evaluation.py:67)."""
+        if self.flow_criterion is None:
+            raise RuntimeError("VideoEvaluator(with_flow=False) has no flow criterion")
+        r = self.flow_criterion.load_state_dict(state_dict, strict=strict)
+        self.flow_weights_loaded = True
+        return r
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        if any(k.startswith(prefix + "flow_criterion.") for k in state_dict):
+            self.flow_weights_loaded = True
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
     @torch.no_grad()
     def flow_error(self, pred_rgb: torch.Tensor, gt_rgb: torch.Tensor) -> float:
@@ -116,6 +134,8 @@ class VideoEvaluator(torch.nn.Module):
         RGB in (-1, 1), H and W multiples of 64.  The pairs of one video go through the network as one batch."""
         if pred_rgb.shape[0] < 2:
             return 0.0
+        if pred_rgb.shape[-2] % 64 or pred_rgb.shape[-1] % 64:
+            raise ValueError("flow_error: FlowNetSD needs frame sizes that are multiples of 64, got %dx%d" % tuple(pred_rgb.shape[-2:]))
         pp = flownet_preprocess(torch.cat([pred_rgb[:-1], pred_rgb[1:]], 1))
         gp = flownet_preprocess(torch.cat([gt_rgb[:-1], gt_rgb[1:]], 1))
         fp, fg = self.flow_criterion(pp)[0], self.flow_criterion(gp)[0]
@@ -148,5 +168,6 @@ class VideoEvaluator(torch.nn.Module):
         for i in range(F):                                         # the script scores frame by frame (:191)
             vgg += float(self.perceptual_criterion(self.vgg_preprocess_rgb(p[i:i + 1]), self.vgg_preprocess_rgb(g[i:i + 1])))
         out["vgg"] = vgg / F
-        out["flow"] = self.flow_error(p, g) / F                         # the script divides the F-1 terms by F (:220)
+        # the script divides the F-1 terms by F (:220); NaN while the FlowNet2-SD weights have not been loaded
+        out["flow"] = self.flow_error(p, g) / F if (self.flow_criterion is not None and self.flow_weights_loaded) else float("nan")
         return out

@@ -1,9 +1,11 @@
 """SMPLRenderer on the HIP kernels.  Mirrors src/nmr.py: orthographic_proj_withz_idrot (:10-28), render_fim_wim (:263-278),
 cal_bc_transform (:617-659) -- what float_estimate uses on the stage-4 path -- and, SURVEY 8(f1), the textured renderer:
 forward / render (:192-244), render_fim (:246-260), extract_tex / dynamic_sampler (:364-395), the sampler helpers
-(:397-495), lighting and background setters (:180-190).  The UV-map buffers the reference builds from `mapper.txt`
-(:146-159: img2uv_sampler, map_fn, front/back_map_fn) need that asset, which is not redistributable: they are
-only built when `uv_map_path` is given, and the methods that read them raise otherwise.
+(:397-495), lighting and background setters (:180-190).  The UV-map buffers the reference builds from `mapper.txt` and its
+JSON face lists (:144-161: img2uv_sampler, map_fn, back_map_fn, front_map_fn) need assets that are not redistributable (SURVEY
+F12) and are not shipped: they are built, by jafpro_amd.mesh, when the caller passes `uv_map_path` (+ the JSON paths, which
+default to the reference's relative paths); without them the methods that read the buffers -- forward(dynamic=False),
+encode_fim, encode_front_fim -- raise.
 """
 from __future__ import annotations
 
@@ -11,7 +13,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import mesh, ops
 
 
 def orthographic_proj_withz_idrot(X, cam, offset_z=0.):
@@ -27,7 +29,8 @@ def orthographic_proj_withz_idrot(X, cam, offset_z=0.):
 class SMPLRenderer(nn.Module):
     def __init__(self, face_path='../smpl_faces.npy', uv_map_path=None, map_name='uv_seg', tex_size=3,
                  image_size=256, anti_aliasing=True, fill_back=False, background_color=(0, 0, 0),
-                 viewing_angle=30, near=0.1, far=25.0, has_front=False, faces=None):
+                 viewing_angle=30, near=0.1, far=25.0, has_front=False, faces=None,
+                 part_info='../smpl_part_info.json', front_info='../front_facial.json', head_info='../head.json'):
         super().__init__()
         if faces is None:
             faces = np.load(face_path)
@@ -54,9 +57,17 @@ class SMPLRenderer(nn.Module):
         self.light_color_ambient = [1, 1, 1]
         self.light_color_directional = [1, 1, 1]
         self.light_direction = [0, 1, 0]
-        self.img2uv_sampler = None          # needs mapper.txt (mesh.create_uvsampler, :146): see the module docstring
+        # UV-map buffers (src/nmr.py:144-161), from the caller's assets: see the module docstring
+        self.img2uv_sampler = self.map_fn = self.back_map_fn = self.front_map_fn = None
         if uv_map_path is not None:
-            raise NotImplementedError("SMPLRenderer: the UV-map buffers (mapper.txt) are not built; use dynamic=True")
+            kw = dict(part_info=part_info, front_info=front_info, head_info=head_info, contain_bg=True, fill_back=fill_back)
+            del self.img2uv_sampler, self.map_fn, self.back_map_fn
+            self.register_buffer('img2uv_sampler', torch.tensor(mesh.create_uvsampler(uv_map_path, tex_size=tex_size)).float())
+            self.register_buffer('map_fn', torch.tensor(mesh.create_mapping(map_name, uv_map_path, **kw)).float())
+            self.register_buffer('back_map_fn', torch.tensor(mesh.create_mapping('back', uv_map_path, **kw)).float())
+            if has_front:
+                del self.front_map_fn
+                self.register_buffer('front_map_fn', torch.tensor(mesh.create_mapping('front', uv_map_path, **kw)).float())
 
     # --- src/nmr.py:180-190 --------------------------------------------------------------------
     def set_ambient_light(self, int_dir=0.3, int_amb=0.7, direction=(1, 0.5, 1)):
@@ -84,9 +95,13 @@ class SMPLRenderer(nn.Module):
 
     def forward(self, cam, vertices, uv_imgs, dynamic=True, get_fim=False):
         """(images [B,3,S,S], textures [B,NF,T,T,T,3][, fim]) -- src/nmr.py:192-210."""
-        if not dynamic:
-            raise NotImplementedError("SMPLRenderer.forward(dynamic=False) samples with img2uv_sampler, built from mapper.txt")
-        samplers = self.dynamic_sampler(cam, vertices, None)
+        if dynamic:
+            samplers = self.dynamic_sampler(cam, vertices, None)
+        else:
+            if self.img2uv_sampler is None:
+                raise NotImplementedError("SMPLRenderer.forward(dynamic=False) samples with img2uv_sampler: construct the "
+                                          "renderer with uv_map_path (the UV OBJ is not shipped, SURVEY F12)")
+            samplers = self.img2uv_sampler.repeat(cam.shape[0], 1, 1, 1)
         textures = self.extract_tex(uv_imgs, samplers)
         images, fim = self.render(cam, vertices, textures, None, get_fim=get_fim)
         return (images, textures, fim) if get_fim else (images, textures)
@@ -111,6 +126,33 @@ class SMPLRenderer(nn.Module):
     def render_fim(self, cam, vertices, faces=None):
         """src/nmr.py:246-260 (rasterize_face_index_map defaults: near 0.1, far 100)."""
         return self.render_fim_wim(cam, vertices, faces)[1]
+
+    # --- face-index encodings (src/nmr.py:312-352): lookups in the per-face tables of the UV-map assets ----------
+    def infer_face_index_map(self, cam, vertices):
+        raise NotImplementedError                    # as the reference (:312-313)
+
+    def _table(self, name):
+        t = getattr(self, name)
+        if t is None:
+            raise NotImplementedError("SMPLRenderer.%s is built from the UV-map assets: construct the renderer with uv_map_path%s "
+                                      "(not shipped, SURVEY F12)" % (name, " and has_front=True" if name == "front_map_fn" else ""))
+        return t
+
+    def encode_fim(self, cam, vertices, fim=None, transpose=True, map_fn=None):
+        """(map_fn[fim] as [B,C,S,S] (or [B,S,S,C]), fim): the background index -1 selects the table's last row."""
+        if fim is None:
+            fim = self.infer_face_index_map(cam, vertices)
+        table = map_fn if map_fn is not None else self._table('map_fn')
+        fim_enc = table[fim.long()]
+        if transpose:
+            fim_enc = fim_enc.permute(0, 3, 1, 2)
+        return fim_enc, fim
+
+    def encode_front_fim(self, fim, transpose=True, front_fn=True):
+        fim_enc = self._table('front_map_fn' if front_fn else 'back_map_fn')[fim.long()]
+        if transpose:
+            fim_enc = fim_enc.permute(0, 3, 1, 2)
+        return fim_enc
 
     # --- texture extraction (src/nmr.py:355-395) -------------------------------------------------
     def extract_tex_from_image(self, images, cam, vertices):

@@ -230,3 +230,52 @@ def stage4_raw(seed: int, B: int, T: int = 4, S: int = 256) -> Dict[str, np.ndar
     d["smpl_real_mask_u8"] = np.repeat(((d["tgt_IUV_u8"][..., 0] > 0) * 255).astype(np.uint8)[..., None], 3, -1)
     d["smpl_real_mask_u8"][:, ::7, ::5] = 131                 # soft edges: values other than 0 / 255
     return d
+
+
+def uv_assets(dirpath: str, seed: int = 0, faces: np.ndarray = None) -> Dict[str, str]:
+    """Synthetic stand-ins for the reference's UV-map assets (`mapper.txt` + three JSON face lists, SURVEY F12: not
+    redistributable), in the same file formats, for a given [F, 3] topology (default: a 12 x 9 grid of quads = 216 triangles):
+    an OBJ with `v`, `vn`, `vt` and `f v/vt/vn` records whose texture coordinates are seeded and partly OUTSIDE the unit square
+    (the sampler clips), a partition of the faces into 10 named parts, a `head` list and a `front` list inside it.
+    Returns {"obj", "part_info", "front_info", "head_info", "nf"}."""
+    import json
+    import os
+    r = _rng(seed, "uv_assets")
+    if faces is None:
+        gx, gy = 12, 9
+        idx = lambda i, j: i * (gy + 1) + j
+        quads = [(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)) for i in range(gx) for j in range(gy)]
+        faces = np.array([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))], dtype=np.int64)
+    faces = np.asarray(faces, dtype=np.int64)
+    nf, nv = int(faces.shape[0]), int(faces.max()) + 1
+    verts = r.uniform(-1, 1, (nv, 3)).astype(np.float32)
+    # one texture vertex per face corner (UV seams everywhere), a few of them shared again
+    nvt = 3 * nf
+    vts = r.uniform(-0.05, 1.05, (nvt, 2)).astype(np.float32)
+    fvt = np.arange(nvt, dtype=np.int64).reshape(nf, 3)
+    share = r.integers(0, nf, size=max(1, nf // 8))
+    fvt[share, 0] = fvt[(share + 1) % nf, 1]
+    os.makedirs(dirpath, exist_ok=True)
+    obj = os.path.join(dirpath, "mapper.txt")
+    with open(obj, "w") as fp:
+        for v in verts:
+            fp.write("v %.6f %.6f %.6f\n" % (v[0], v[1], v[2]))
+        for v in verts:
+            fp.write("vn %.6f %.6f %.6f\n" % (v[2], v[0], v[1]))
+        for t in vts:
+            fp.write("vt %.6f %.6f\n" % (t[0], t[1]))
+        for f, t in zip(faces, fvt):
+            fp.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (f[0] + 1, t[0] + 1, f[0] + 1, f[1] + 1, t[1] + 1, f[1] + 1,
+                                                        f[2] + 1, t[2] + 1, f[2] + 1))
+    part_of = r.integers(0, 10, size=nf)
+    part_of[:10] = np.arange(10)                     # no empty part
+    parts = {"part_%02d" % p: {"face": [int(i) for i in np.nonzero(part_of == p)[0]]} for p in range(10)}
+    head = sorted(int(i) for i in r.choice(nf, size=max(4, nf // 5), replace=False))
+    front = sorted(int(i) for i in r.choice(head, size=max(2, len(head) // 2), replace=False))
+    paths = {"obj": obj, "part_info": os.path.join(dirpath, "smpl_part_info.json"),
+             "front_info": os.path.join(dirpath, "front_facial.json"), "head_info": os.path.join(dirpath, "head.json")}
+    json.dump(parts, open(paths["part_info"], "w"))
+    json.dump({"face": front}, open(paths["front_info"], "w"))
+    json.dump({"face": head}, open(paths["head_info"], "w"))
+    paths["nf"] = nf
+    return paths

@@ -480,6 +480,47 @@ def g_data():
     np.savez_compressed(os.path.join(GOLD, "transfer_texture.npz"), **st)
 
 
+# ---- 14. UV-map asset builders of SMPLRenderer's static-UV branch (src/mesh.py:28-77,156-194,368-423,530-568) ----
+def g_mesh():
+    """src/mesh.py imports only numpy / torch / json: the reference's own create_uvsampler / create_mapping run here on
+    synthetic assets in the reference's file formats (jafpro_amd/synth.uv_assets: the real mapper.txt is not redistributable)
+    and pin jafpro_amd/mesh.py bit for bit."""
+    import tempfile
+    import src.mesh as RM
+    from jafpro_amd import mesh as M
+    st, checked = {}, 0
+    with tempfile.TemporaryDirectory() as td:
+        a = synth.uv_assets(td, seed=7)
+        for T_ in (2, 3, 6):
+            ref = RM.create_uvsampler(a["obj"], tex_size=T_)
+            mine = M.create_uvsampler(a["obj"], tex_size=T_)
+            assert ref.dtype == mine.dtype and np.array_equal(ref, mine), ("uvsampler", T_)
+            st["uvsampler.%d" % T_] = ref
+            checked += 1
+        ro, mo = RM.load_obj(a["obj"]), M.load_obj(a["obj"])
+        for k in ro:
+            assert ro[k].dtype == mo[k].dtype and np.array_equal(ro[k], mo[k]), k
+        for fb in (False, True):
+            assert np.array_equal(RM.get_f2vts(a["obj"], fill_back=fb), M.get_f2vts(a["obj"], fill_back=fb))
+            for name in ("uv", "seg", "uv_seg", "par", "front", "head", "back", "binary"):
+                if name == "par" and fb:
+                    continue        # (the reference's par mapping ignores fill_back and then fails its own face count)
+                kw = dict(part_info=a["part_info"], front_info=a["front_info"], head_info=a["head_info"], contain_bg=True, fill_back=fb)
+                ref = RM.create_mapping(name, a["obj"], **kw)
+                mine = M.create_mapping(name, a["obj"], **kw)
+                assert ref.dtype == mine.dtype and ref.shape == mine.shape and np.array_equal(ref, mine), (name, fb)
+                st["map.%s.%d" % (name, int(fb))] = ref
+                checked += 1
+        ref = RM.create_mapping("ids", a["obj"], contain_bg=False)           # (with the background row the reference raises)
+        assert np.array_equal(ref, M.create_mapping("ids", a["obj"], contain_bg=False))
+        st["map.ids.nobg"] = ref
+        st["nf"] = np.int64(a["nf"])
+        st["seed"] = np.int64(7)
+    print("  jafpro_amd.mesh vs reference src/mesh.py       %d tables bit-identical" % checked)
+    report["mesh_assets_tables"] = float(checked)
+    np.savez_compressed(os.path.join(GOLD, "mesh_assets.npz"), **st)
+
+
 # ---- 11. state_dict schema of the boundary modules (SURVEY Appendix A) -------------------------------
 def g_schema():
     mods = {"Accumulate_LSTM_no_loss": RN.Accumulate_LSTM_no_loss(), "UNet_inpainter": RN.UNet_inpainter(),

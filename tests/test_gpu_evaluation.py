@@ -47,7 +47,10 @@ def test_video_evaluator_end_to_end():
     from oracle import torch_oracle as O
     pred, gt = _video(1, F=2, S=192)
     ev = E.VideoEvaluator()
+    assert not ev.flow_weights_loaded          # "flow" is NaN until FlowNet2-SD weights arrive (random weights mean nothing)
     synth.load_synth(ev, 808)
+    assert ev.flow_weights_loaded
+    assert E.VideoEvaluator(with_flow=False).flow_criterion is None
     sd = {k: v.detach().clone() for k, v in ev.state_dict().items()}
     ev = ev.cuda()
     out = ev(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda())

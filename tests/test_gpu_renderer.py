@@ -355,3 +355,57 @@ def test_smpl_renderer_textured_forward_and_gradients():
     assert gi > 0 and (img_g.grad.cpu() - img_c.grad).abs().max().item() <= 1e-4 * gi
     gv = float(v_c.grad.abs().max())
     assert gv > 0 and (v_g.grad.cpu() - v_c.grad).abs().max().item() <= 1e-3 * gv
+
+
+def test_smpl_renderer_static_uv_branch(tmp_path):
+    """SMPLRenderer with the UV-map assets given (src/nmr.py:144-161,192-210,328-352): buffers built by jafpro_amd.mesh from a
+    caller-supplied UV OBJ + JSON face lists (synthetic stand-ins, synth.uv_assets), forward(dynamic=False) sampling the texture
+    image with img2uv_sampler, and the encode_fim / encode_front_fim lookups -- against the oracle's extract_tex + smpl_render and
+    NumPy indexing.  Without the assets the same calls raise."""
+    from oracle import raster_autograd as RA
+    from jafpro_amd import mesh, synth
+    from jafpro_amd.nmr import SMPLRenderer
+    B, S, T = 2, 64, 3
+    v, cam, fidx, _ = _mesh_faces(B, 67)
+    a = synth.uv_assets(str(tmp_path), seed=11, faces=fidx)
+    r = SMPLRenderer(faces=fidx, uv_map_path=a["obj"], map_name="par", tex_size=T, image_size=S, anti_aliasing=True,
+                     has_front=True, part_info=a["part_info"], front_info=a["front_info"], head_info=a["head_info"]).cuda()
+    nf = fidx.shape[0]
+    assert tuple(r.img2uv_sampler.shape) == (nf, T * T, 2) and tuple(r.map_fn.shape) == (nf + 1, 11)
+    assert tuple(r.back_map_fn.shape) == (nf + 1, 1) and tuple(r.front_map_fn.shape) == (nf + 1, 1)
+    assert np.array_equal(r.img2uv_sampler.cpu().numpy(), mesh.create_uvsampler(a["obj"], tex_size=T))
+    assert {"img2uv_sampler", "map_fn", "back_map_fn", "front_map_fn"} <= set(r.state_dict())
+    img = synth.uniform(67, "uv", (B, 3, 96, 80))
+    img_g = torch.from_numpy(img).cuda().requires_grad_(True)
+    v_g, cam_g = torch.from_numpy(v).cuda(), torch.from_numpy(cam).cuda()
+    images, textures, fim = r(cam_g, v_g, img_g, dynamic=False, get_fim=True)
+    proj = torch.from_numpy(synth.uniform(67, "p", (B, 3, S, S)))
+    (images * proj.cuda()).sum().backward()
+    # oracle: the static sampler repeated over the batch -> extract_tex -> SMPLRenderer.render
+    img_c = torch.from_numpy(img).requires_grad_(True)
+    sampler = torch.from_numpy(mesh.create_uvsampler(a["obj"], tex_size=T)).float()[None].repeat(B, 1, 1, 1)
+    tex_c = RA.extract_tex(img_c, sampler, T)
+    ref = RA.smpl_render(torch.from_numpy(cam), torch.from_numpy(v), tex_c, fidx, S, True, 0.1, 25.0)
+    (ref * proj).sum().backward()
+    assert (textures.cpu() - tex_c).abs().max().item() <= 1e-5
+    assert (images.cpu() - ref).abs().max().item() <= 1e-5
+    gi = float(img_c.grad.abs().max())
+    assert gi > 0 and (img_g.grad.cpu() - img_c.grad).abs().max().item() <= 1e-4 * gi
+    # encodings: table[fim], background (-1) -> the last row
+    assert 0.1 < float((fim >= 0).float().mean()) < 0.9 and int(fim.min()) == -1
+    enc, fim2 = r.encode_fim(cam_g, v_g, fim=fim)
+    assert fim2 is fim and tuple(enc.shape) == (B, 11, S, S)
+    assert np.array_equal(enc.permute(0, 2, 3, 1).cpu().numpy(), r.map_fn.cpu().numpy()[fim.cpu().numpy()])
+    assert float(enc[:, -1][fim < 0].min()) == 1.0                       # the `par` background class
+    fr = r.encode_front_fim(fim, transpose=False, front_fn=True)
+    bk = r.encode_front_fim(fim, transpose=True, front_fn=False)
+    assert np.array_equal(fr.cpu().numpy(), r.front_map_fn.cpu().numpy()[fim.cpu().numpy()]) and tuple(bk.shape) == (B, 1, S, S)
+    assert float(fr.sum()) > 0 and float(bk.sum()) > 0 and float((fr[..., 0] * bk[:, 0]).sum()) == 0.0     # front and back of the head are disjoint
+    # without the assets: the reference's default construction cannot be reproduced, the calls say why
+    r0 = SMPLRenderer(faces=fidx, image_size=S, tex_size=T).cuda()
+    with pytest.raises(NotImplementedError):
+        r0(cam_g, v_g, img_g, dynamic=False)
+    with pytest.raises(NotImplementedError):
+        r0.encode_fim(cam_g, v_g, fim=fim)
+    with pytest.raises(NotImplementedError):
+        r.infer_face_index_map(cam_g, v_g)

@@ -140,3 +140,34 @@ def test_face_bbox_host_logic_and_transfer_texture_oracle():
     raw = synth.stage4_raw(3, 1, S=64)
     b = data_oracle.stage4_batch(raw)
     assert b["src_texture_im"].min() >= -1 and b["src_texture_im"].max() <= 1 and b["smpl_real_mask"].max() == 1.0
+
+
+def test_uv_map_asset_builders_equal_the_reference(tmp_path, golden_dir):
+    """jafpro_amd.mesh (SMPLRenderer's static-UV branch, src/mesh.py:28-77,156-194,368-423,530-568) on regenerated synthetic
+    assets against tests/golden/mesh_assets.npz, which oracle/make_golden.py g_mesh made by running the reference's own
+    create_uvsampler / create_mapping on the same files: bit for bit, every table."""
+    import numpy as np
+    from jafpro_amd import mesh, synth
+    gold = np.load(os.path.join(golden_dir, "mesh_assets.npz"))
+    a = synth.uv_assets(str(tmp_path), seed=int(gold["seed"]))
+    assert a["nf"] == int(gold["nf"])
+    for T_ in (2, 3, 6):
+        got = mesh.create_uvsampler(a["obj"], tex_size=T_)
+        assert got.shape == (a["nf"], T_ * T_, 2) and got.dtype == np.float32
+        assert np.array_equal(got, gold["uvsampler.%d" % T_]), T_
+        assert got.min() >= -1.0 and got.max() <= 1.0
+    kw = dict(part_info=a["part_info"], front_info=a["front_info"], head_info=a["head_info"], contain_bg=True)
+    n = 0
+    for fb in (False, True):
+        for name in ("uv", "seg", "uv_seg", "par", "front", "head", "back", "binary"):
+            key = "map.%s.%d" % (name, int(fb))
+            if key not in gold:
+                continue
+            got = mesh.create_mapping(name, a["obj"], fill_back=fb, **kw)
+            assert got.dtype == gold[key].dtype and np.array_equal(got, gold[key]), key
+            assert got.shape[0] == a["nf"] * (2 if fb else 1) + 1        # + the background row
+            n += 1
+    assert n == 15
+    assert np.array_equal(mesh.create_mapping("ids", a["obj"], contain_bg=False), gold["map.ids.nobg"])
+    with pytest.raises(ValueError):
+        mesh.create_mapping("nope", a["obj"], **kw)
