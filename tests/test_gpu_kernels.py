@@ -678,3 +678,66 @@ def test_launches_split_over_the_batch_beyond_the_grid_z_extent(monkeypatch):
         assert len(ops._n_chunks(5, 6)) == 1
         for a, r in zip(got, ref):
             assert maxerr(a, r) <= 1e-5 * max(1.0, float(r.abs().max())), mode
+
+
+@pytest.mark.parametrize("N,G,cins,H,W", [(2, 3, [5, 12], 20, 28), (1, 1, [3], 9, 7), (3, 24, [12, 12], 10, 10)])
+def test_split_packed_image_is_hi_plus_residual(N, G, cins, H, W):
+    """jaf_conv2d_pack_input with d.precision = JAF_PREC_BF16X3: the image holds, per group of 8 channels, a hi plane
+    bf16(v) and right behind it a lo plane bf16(v - hi), [N][G][ng8][hi, lo][H*W][8]; hi is bit for bit the bf16 image
+    of the same call in bf16 mode, hi + lo reproduces v to 2^-16 relative, channels beyond Cin are zero in both planes."""
+    ops = _ops()
+    from jafpro_amd.ops import _make_desc
+    srcs = [dev(R(880 + i, N, G * c, H, W, lo=-3.0, hi=3.0)) for i, c in enumerate(cins)]
+    Cin = sum(cins)
+    specs = [(c, G * c, 0, c) for c in cins]
+    ng8 = (Cin + 7) // 8
+    imgs = {}
+    for mode in ("bf16", "bf16x3"):
+        prev = ops.set_precision(mode)
+        try:
+            d = _make_desc(N, G, Cin, 8, H, W, H, W, 3, 3, 1, 1, 1, 1, specs, Cin, 0, G * 8, 0, 0, 0.0)
+            imgs[mode] = ops.pack_input(srcs, d).clone()
+        finally:
+            ops.set_precision(prev)
+    torch.cuda.synchronize()
+    plain = imgs["bf16"].view(torch.bfloat16).view(N, G, ng8, H * W, 8)
+    split = imgs["bf16x3"].view(torch.bfloat16).view(N, G, ng8, 2, H * W, 8)
+    assert imgs["bf16x3"].numel() == 2 * imgs["bf16"].numel()
+    assert torch.equal(split[:, :, :, 0], plain)
+    x = torch.cat([t.view(N, G, c, H * W) for t, c in zip(srcs, cins)], 2)                      # [N, G, Cin, HW]
+    xp = torch.zeros(N, G, ng8 * 8, H * W, device="cuda")
+    xp[:, :, :Cin] = x
+    xp = xp.view(N, G, ng8, 8, H * W).permute(0, 1, 2, 4, 3)
+    hi, lo = split[:, :, :, 0].float(), split[:, :, :, 1].float()
+    assert torch.equal(hi, xp.to(torch.bfloat16).float())
+    assert torch.equal(lo, (xp - hi).to(torch.bfloat16).float())
+    assert (hi + lo - xp).abs().max().item() <= 2.0 ** -16 * 3.0
+    if Cin % 8:
+        assert float(split[:, :, -1, :, :, Cin % 8:].float().abs().max()) == 0.0
+
+
+def test_kernel_names_come_from_the_launch():
+    """jaf_kernel_names / jaf_last_kernel_name: while a profiler is set, every convolution-family launch reports the
+    instantiation it picked, in rocprofv3's spelling; the rows of bench.py's roofline are keyed by these strings."""
+    import re
+    ops = _ops()
+    x = dev(R(1, 2, 24, 40, 40))
+    w = dev(R(2, 32, 24, 3, 3, lo=-0.1, hi=0.1)).requires_grad_(True)
+    seen = {}
+    for mode in ("f32", "bf16", "bf16x3"):
+        prev = ops.set_precision(mode)
+        prof = ops.KernelProfiler()
+        ops.set_profiler(prof)
+        try:
+            y = ops.conv2d(x.clone().requires_grad_(True), w, None, stride=1, pad=1, act=1, slope=0.2)
+            y.sum().backward()
+        finally:
+            ops.set_profiler(None)
+            ops.set_precision(prev)
+        seen[mode] = sorted(prof.summary())
+    assert any(re.fullmatch(r"conv_mfma_kernel<\d, \d, \d, false>", k) for k in seen["f32"]), seen["f32"]
+    assert any(re.fullmatch(r"conv_dma_kernel<\d, \d, false, (true|false), (true|false)>", k) for k in seen["bf16"]), seen["bf16"]
+    assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, false>", k) for k in seen["bf16"]), seen["bf16"]
+    assert any(re.fullmatch(r"conv_dma_split_kernel<\d, \d, false, (true|false)>", k) for k in seen["bf16x3"]), seen["bf16x3"]
+    assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, true>", k) for k in seen["bf16x3"]), seen["bf16x3"]
+    assert "conv_pack_dz_kernel" in seen["bf16"] and "conv_pack_input_kernel" in seen["bf16x3"]
