@@ -3,7 +3,7 @@ sys.path.insert(0, ".")
 import bench
 from jafpro_amd import ops, synth
 from jafpro_amd.step import Stage4Trainer, _to_dev
-ops.set_precision("bf16")
+ops.set_precision(sys.argv[2] if len(sys.argv) > 2 else "bf16")
 _, fidx = synth.body_mesh()
 M, mods = bench.build_models(fidx); M = M.cuda()
 tr = Stage4Trainer(M)
