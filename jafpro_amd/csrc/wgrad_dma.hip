@@ -45,6 +45,7 @@ struct WgDArgs {
     int xng8;              // planes per (image, group) of the packed input image (>= ngin8)
     float inv_pwp;
     int lstmC;             // > 0: dz channels are the ConvLSTM's gate gradients, channel-major (4 c + gate): dW row gate * lstmC + c
+    int step_n, step_ty, step_tx;      // conv_wgrad_fast_kernel: nsplit tiles further = (images, tile rows, tile columns)
     int off_lo;            // SPLIT: byte offset of the lo tiles from the hi tiles inside a tile buffer (patch and dz alike)
 };
 
@@ -385,6 +386,254 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
     }
 }
 
+// The stride-1 3 x 3 layers on their own kernel (WC = 4 / 2 / 1 input-channel tiles of 16 per workgroup; a wave owns tile wave % WC
+// and walks the k-steps wave / WC + (4 / WC) i).  Same tiles, same LDS images, same arithmetic and summation order as conv_wgrad_dma_kernel; what
+// differs is the instruction count around the matrix-core steps (profiles/round3_k_pmc_instmix.txt: 3.6 VALU and 1.4 SALU
+// instructions per MFMA, the SIMD's issue slots about as busy with them as with the MFMAs):
+//  * stride, patch pitch and the channel tiling are compile-time constants, so every transposed LDS read is one of 8 per-lane bases
+//    plus an immediate offset (the bit-7 swizzle commutes with the row offset, a multiple of 256): no address arithmetic in the loop;
+//  * B fragments are requested three taps ahead of the MFMAs that consume them;
+//  * the tile walk is incremental (no divisions per tile), and a tile whose patch lies inside the image skips the per-piece bounds
+//    logic: one add per DMA piece.
+template <int MTW, bool DB, int WC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a) {
+    constexpr int NW = 4, WK = 4 / WC, XI = 2 * WC, PWP = 24, PH = 10, PW = 18, XPLANE = 8192;
+    constexpr int LA = (MTW == 4 && DB) ? 2 : 3;      // taps the B fragments run ahead (registers: 64 rows double-buffered spill at 3)
+    typedef __attribute__((address_space(3))) unsigned char* ldsb;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const jaf_conv_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int q = lane >> 4;
+    const int wc = wave % WC, wk = wave / WC;
+    const ldsb lb = (ldsb)smem;
+    const unsigned lds0 = (unsigned)(uintptr_t)lb;
+
+    int L;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, j = bid >> 3, qn = nblk >> 3, rn = nblk & 7;
+        L = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
+    }
+    const int cib = L % a.ciblocks;
+    L /= a.ciblocks;
+    const int cob = L % a.coblocks;
+    L /= a.coblocks;
+    const int split = L % a.nsplit;
+    const int g = L / a.nsplit;
+    const int ci0 = cib * 16 * WC;
+    const int co0 = cob * 16 * MTW;
+    const int HW = d.H * d.W;
+    const int OHW = d.OH * d.OW;
+
+    // ---- DMA lane constants (as in conv_wgrad_dma_kernel; a dead slot carries the out-of-range offset itself) ----
+    // (row, column) of the patch position behind slot (piece i, lane): needed again only by tiles that cross the image border
+    auto slot_rc = [&](int i, int& r, int& c, int& hf) {
+        const int addr = ((i & 7) * 64 + lane) * 16;
+        const int posq = addr >> 5;
+        const int rq = (int)(((float)posq + 0.5f) * (1.0f / PWP));
+        const int cq = posq - rq * PWP;
+        const int raw = addr ^ ((cq & 8) << 4);
+        const int pos = raw >> 5;
+        hf = (raw >> 4) & 1;
+        r = (int)(((float)pos + 0.5f) * (1.0f / PWP));
+        c = pos - r * PWP;
+    };
+    int x_goff[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int i = wave + NW * j;
+        int r, c, hf;
+        slot_rc(i, r, c, hf);
+        const int grp8 = (ci0 >> 3) + 2 * (i >> 3) + hf;
+        const bool live = (r < PH) && (c < PW) && (grp8 < a.ngin8);
+        x_goff[j] = live ? (grp8 * HW + r * d.W + c) * 16 : WD_OOB;
+    }
+    int z_yx, z_goff, z_half;
+    {
+        const int addr = (wave * 64 + lane) * 16;
+        const int kq = addr >> 5;
+        const int raw = addr ^ ((kq & 8) << 4);
+        const int k = raw >> 5;
+        z_half = (raw >> 4) & 1;
+        const int y = k >> 4, x = k & 15;
+        z_yx = (y << 16) | x;
+        z_goff = (z_half * OHW + y * d.OW + x) * 16;
+    }
+
+    // ---- per-lane bases of the transposed reads (byte offsets inside a tile buffer) ----
+    const int qp = (lane >> 2) & 3;
+    const int pp = lane & 3;
+    unsigned bx[2][3], ax[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c0h = 8 * (q & 1) + 4 * h + qp;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int col = c0h + kx;
+            bx[h][kx] = (unsigned)(((((q >> 1) * PWP + col) * 32 + pp * 8) ^ ((col & 8) << 4)) + wc * XPLANE + wk * (2 * PWP * 32));
+        }
+        const int k = 8 * q + 4 * h + qp;
+        ax[h] = (unsigned)((((k * 32) ^ ((k & 8) << 4)) + pp * 8) + a.off_dz + wk * 1024);
+    }
+
+    f32x4 acc[MTW][9];
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int tiles = a.tiles_x * a.tiles_y;
+    const int items = d.N * tiles;
+    const int xbytes = a.xng8 * HW * 16;
+    const int zbytes = a.ngout8 * OHW * 16;
+    const int count = split < items ? (items - split + a.nsplit - 1) / a.nsplit : 0;       // tiles of this pixel split
+
+    // the next tile to fetch: (image, tile row, tile column), advanced by nsplit tiles without divisions
+    int in_n = split / tiles, in_ty, in_tx;
+    {
+        const int t0 = split - in_n * tiles;
+        in_ty = t0 / a.tiles_x;
+        in_tx = t0 - in_ty * a.tiles_x;
+    }
+    auto issue = [&](int boff) {
+        const int oy0 = in_ty * WD_TH, ox0 = in_tx * WD_TW;
+        const int iy0 = oy0 - d.pad_t, ix0 = ox0 - d.pad_l;
+        const jaf_u32x4 rxa = jaf_make_rsrc(a.xp + ((long)in_n * d.G + g) * (long)xbytes, (unsigned)xbytes);
+        const int tbase = (iy0 * d.W + ix0) * 16;
+        const unsigned dstx = lds0 + boff + wave * 1024;
+        if (iy0 >= 0 && ix0 >= 0 && iy0 + PH <= d.H && ix0 + PW <= d.W) {     // (uniform) the whole patch is inside the image
+#pragma unroll
+            for (int j = 0; j < XI; ++j) jaf_dma16_async(rxa, dstx + NW * j * 1024, x_goff[j] + tbase);
+        } else {
+#pragma unroll
+            for (int j = 0; j < XI; ++j) {
+                int r, c, hf;
+                slot_rc(wave + NW * j, r, c, hf);
+                const int iy = iy0 + r, ix = ix0 + c;
+                const bool ok = (x_goff[j] != WD_OOB) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
+                jaf_dma16_async(rxa, dstx + NW * j * 1024, ok ? x_goff[j] + tbase : WD_OOB);
+            }
+        }
+        const jaf_u32x4 rza = jaf_make_rsrc(a.dzp + ((long)in_n * d.G + g) * (long)zbytes, (unsigned)zbytes);
+        const bool okp = (oy0 + (z_yx >> 16) < d.OH) && (ox0 + (z_yx & 0xffff) < d.OW);
+        const int zb = z_goff + (oy0 * d.OW + ox0) * 16 + (co0 >> 3) * OHW * 16;
+        const unsigned dstz = lds0 + a.off_dz + boff + wave * 1024;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const bool ok = okp && ((co0 >> 3) + 2 * mt + z_half < a.ngout8);
+            jaf_dma16_async(rza, dstz + mt * 4096, ok ? zb + 2 * mt * OHW * 16 : WD_OOB);
+        }
+        in_n += a.step_n;
+        in_tx += a.step_tx;
+        in_ty += a.step_ty;
+        if (in_tx >= a.tiles_x) { in_tx -= a.tiles_x; ++in_ty; }
+        if (in_ty >= a.tiles_y) { in_ty -= a.tiles_y; ++in_n; }
+    };
+
+    int cur = 0;
+    if (DB && count > 0) issue(0);
+    for (int it = 0; it < count; ++it) {
+        if (DB) {
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (it + 1 < count) issue(cur ^ a.bufsz);
+            __builtin_amdgcn_sched_barrier(0);      // (the DMA set-up interleaved with the first LDS reads of the tile spilled 36-60 registers at 64 rows)
+        } else {
+            __syncthreads();
+            issue(0);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+        }
+        if (DB) asm volatile("" : "+s"(cur));      // (one add per base and tile; both buffers' bases kept live cost 8 registers and spills at 64 rows)
+        const ldsb pa0 = lb + cur + ax[0], pa1 = lb + cur + ax[1];
+        ldsb pb[2][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) pb[h][kx] = lb + cur + bx[h][kx];
+        if (DB) cur ^= a.bufsz;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks += WK) {          // (the wave's k-steps are wk + ks: wk sits in the bases)
+            bf16x8 af[MTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa0 + mt * 4096 + ks * 1024));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa1 + mt * 4096 + ks * 1024));
+                af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+            bf16x8 bf[9];
+#pragma unroll
+            for (int t = 0; t < 9 + LA; ++t) {
+                if (t < 9) {
+                    const int off = (2 * ks + t / 3) * (PWP * 32);
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb[0][t % 3] + off));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb[1][t % 3] + off));
+                    bf[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                if (t >= LA) {
+#pragma unroll
+                    for (int mt = 0; mt < MTW; ++mt)
+                        acc[mt][t - LA] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[t - LA], acc[mt][t - LA], 0, 0, 0);
+                }
+                // 64 rows double-buffered: keep the source order (the scheduler otherwise requests a whole k-step's fragments at once and
+                // the register allocator spills the DMA constants, whose reloads then wait on the DMA in flight: vmcnt is shared)
+                if constexpr (MTW == 4 && DB) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: as conv_wgrad_dma_kernel's 3 x 3 branch ----
+    const int cit = ci0 + wc * 16;
+    float* s_ep = (float*)smem + wave * (16 * WD_EP);
+    const int nrem = (d.Cin - cit) * 9;
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_ep[(q * 4 + j) * WD_EP + li * 9 + t] = acc[mt][t][j];
+        for (int row = 0; row < 16; ++row) {
+            const int co = co0 + mt * 16 + row;
+            if (co >= d.Cout) break;
+            const int cod = a.lstmC > 0 ? (co & 3) * a.lstmC + (co >> 2) : co;
+            float* prow = a.dw + (((long)(g * d.Cout + cod) * d.w_cin_tot) + d.w_cin_off + cit) * 9;
+            const float* srow = s_ep + row * WD_EP;
+#pragma unroll
+            for (int rem = lane; rem < 144; rem += 64)
+                if (rem < nrem) atomicAdd(prow + rem, srow[rem]);
+        }
+    }
+}
+
+template <int MTW, bool DB, int WC>
+static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
+    auto k = conv_wgrad_fast_kernel<MTW, DB, WC>;
+    static int optin[JAF_MAX_DEVICES];
+    static JafOcc occ[JAF_MAX_DEVICES][8];
+    if (lds > 48 * 1024) {
+        const int e = jaf_lds_optin((const void*)k, optin);
+        if (e) return e;
+    }
+    static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
+    const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
+    a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
+                                     : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
+    const int tiles = a.tiles_x * a.tiles_y;
+    a.step_n = a.nsplit / tiles;
+    const int dt = a.nsplit - a.step_n * tiles;
+    a.step_ty = dt / a.tiles_x;
+    a.step_tx = dt - a.step_ty * a.tiles_x;
+    const long nblk = outblocks * a.nsplit;
+    if (nblk > 0x7fffffffL) return JAF_EINVAL;
+    JAF_NOTE_KERNEL("conv_wgrad_fast_kernel<%d, %s, %d>", MTW, DB ? "true" : "false", WC);
+    hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+    return jaf_launch_status();
+}
+
 static inline int rup_w(int v, int m) { return (v + m - 1) / m * m; }
 
 template <int MTW, int KS, bool PAIR, bool DB, int XI, bool SPLIT>
@@ -515,6 +764,16 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
     const long dw_floats = (long)d->G * d->Cout * d->Cin * KS * KS;
+    // the stride-1 3 x 3 layers: conv_wgrad_fast_kernel, in the buffering the rules above give each tiling (JAF_WGRAD_FAST=0, or a
+    // JAF_WGRAD_* experiment hook that changes the buffering, falls back to the general kernel)
+    static const int fast_env = getenv("JAF_WGRAD_FAST") ? atoi(getenv("JAF_WGRAD_FAST")) : 1;
+    if (fast_env && !split && KS == 3 && d->stride == 1 && a.nx == 8 && a.PWp == 24) {
+#define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_>(a, lds, items, outblocks, dw_floats, s)
+        JAF_WGF(1, true, 4); JAF_WGF(2, true, 4); JAF_WGF(3, false, 4); JAF_WGF(4, false, 4);
+        JAF_WGF(1, true, 2); JAF_WGF(2, true, 2); JAF_WGF(3, true, 2); JAF_WGF(4, true, 2);
+        JAF_WGF(1, true, 1); JAF_WGF(2, true, 1); JAF_WGF(3, true, 1); JAF_WGF(4, true, 1);
+#undef JAF_WGF
+    }
 #define JAF_WGD(MT_, KS_) JAF_WGDP(MT_, KS_, false)
 #define JAF_WGDP(MT_, KS_, PAIR_) \
     return db ? wgd_launch<MT_, KS_, PAIR_, true>(a, lds, items, outblocks, dw_floats, s) \

@@ -45,6 +45,11 @@ CONV_CASES = [
     (1, 1, [128], 72, 33, 31, 3, 2, 1, 1),             # stride 2, >32 input channels, odd sizes
     (2, 3, [3], 12, 40, 44, 5, 1, 2, 1),               # 5x5 with <= 8 input channels: paired-tap weight gradient (enc_0)
     (1, 2, [8], 12, 30, 30, 5, 1, 2, 0),
+    # wide stride-1 3x3 layers (64 input channels per workgroup: conv_wgrad_fast_kernel).  No activation: with ~10^6 outputs one
+    # of them lies within rounding distance of 0, where the LeakyReLU masks of the kernel and of the fp32 CPU reference disagree
+    (2, 1, [70, 58], 128, 72, 70, 3, 1, 1, 0),
+    (1, 1, [64], 256, 64, 64, 3, 1, 1, 0),
+    (1, 2, [40], 48, 66, 50, 3, 1, 1, 0),              # ... 48 and 32 rows per workgroup, two groups, ragged last tile
 ]
 
 
@@ -737,7 +742,19 @@ def test_kernel_names_come_from_the_launch():
         seen[mode] = sorted(prof.summary())
     assert any(re.fullmatch(r"conv_mfma_kernel<\d, \d, \d, false>", k) for k in seen["f32"]), seen["f32"]
     assert any(re.fullmatch(r"conv_dma_kernel<\d, \d, false, (true|false), (true|false)>", k) for k in seen["bf16"]), seen["bf16"]
-    assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, false>", k) for k in seen["bf16"]), seen["bf16"]
+    assert any(re.fullmatch(r"conv_wgrad_fast_kernel<\d, (true|false), \d>", k) for k in seen["bf16"]), seen["bf16"]     # stride-1 3 x 3
     assert any(re.fullmatch(r"conv_dma_split_kernel<\d, \d, false, (true|false)>", k) for k in seen["bf16x3"]), seen["bf16x3"]
     assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, true>", k) for k in seen["bf16x3"]), seen["bf16x3"]
     assert "conv_pack_dz_kernel" in seen["bf16"] and "conv_pack_input_kernel" in seen["bf16x3"]
+    # a stride-2 layer stays on the general weight-gradient kernel
+    x = dev(R(3, 1, 24, 40, 40))
+    w = dev(R(4, 32, 24, 3, 3, lo=-0.1, hi=0.1)).requires_grad_(True)
+    prev = ops.set_precision("bf16")
+    prof = ops.KernelProfiler()
+    ops.set_profiler(prof)
+    try:
+        ops.conv2d(x.clone().requires_grad_(True), w, None, stride=2, pad=1, act=0).sum().backward()
+    finally:
+        ops.set_profiler(None)
+        ops.set_precision(prev)
+    assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, false>", k) for k in prof.summary()), sorted(prof.summary())
