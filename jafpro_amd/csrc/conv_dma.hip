@@ -157,6 +157,7 @@ struct PackLazyArgs {
     int lazy[3], sh[3], sw[3], align[3];
     float sy[3], sx[3];
     int cap;               // LDS-staged form: floats per channel of the staged source tile
+    int cg0, cgn;          // this launch covers the channel groups [cg0, cg0 + cgn) (the others: conv_pack_up_kernel)
 };
 
 __device__ __forceinline__ void cd_resize_src(int o, float scale, int in, int align, int& i0, int& i1, float& l) {
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_kernel(const PackLaz
     const int y = blockIdx.y * blockDim.y + threadIdx.y;
     if (x >= d.W || y >= d.H) return;
     int z = blockIdx.z;
-    const int cg = z % a.b.ngroups8;
-    z /= a.b.ngroups8;
+    const int cg = a.cg0 + z % a.cgn;
+    z /= a.cgn;
     const int g = z % d.G;
     const int n = z / d.G;
     const int c0 = d.src_c[0];
@@ -237,8 +238,8 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const Pac
     const int x = blockIdx.x * PL_TW + tx * V;
     const int yb = blockIdx.y * PL_TH;
     int z = blockIdx.z;
-    const int cg = z % a.b.ngroups8;
-    z /= a.b.ngroups8;
+    const int cg = a.cg0 + z % a.cgn;
+    z /= a.cgn;
     const int g = z % d.G;
     const int n = z / d.G;
     const int c0 = d.src_c[0];
@@ -416,6 +417,120 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const Pac
     }
 }
 
+// Channel groups that lie inside ONE up-sampled source (the bulk of a decoder's input: 256-512 channels of `up(net)` next to a few
+// label / skip channels) on a kernel of their own.  conv_pack_input_lazy_lds_kernel serves any mix of three sources, pays for it
+// with per-channel source selection, and reads its four taps per output value as four 4-byte LDS loads (instruction mix in
+// profiles/round3_k_pmc_instmix.txt: 912 VALU + 877 SALU + 95 LDS instructions per wave for 32 outputs per lane, 1 TB/s on the
+// 256-channel 128 -> 256 layer).  Here the staged source tile is CHANNEL-INNERMOST, [position][8 channels] fp32, so a tap of all
+// eight channels is two 16-byte LDS reads and the lane's four pixels take 32 reads for 32 outputs; the 16-byte chunks are
+// XOR-swizzled so that lanes two source columns apart (2x up-sampling) fall into different banks.  Same expression tree
+// hy (hx a + lx b) + ly (hx c + lx d) as the other two kernels.  A lane = 4 consecutive pixels of one row; the 1024-pixel tile is as
+// wide as the image allows (LX lanes along x: 256 x 4, 128 x 8 or 64 x 16 outputs), so that a workgroup's stores are few long runs
+// of the plane (a whole 16 KB at W = 256) instead of sixteen 1 KB pieces.
+struct PackUpArgs {
+    const float* src;          // the source's tensor [N][ctot][sh][sw]
+    unsigned char* out;
+    int ctot, coff, gstride;   // its channel geometry (jaf_conv_desc.src_*)
+    int cbase;                 // concatenated channel of the source's channel 0
+    int cend;                  // channels >= cend of a group are padding (zeros)
+    int cg0, cgn;              // channel groups [cg0, cg0 + cgn) of the ngroups8 planes per (image, group)
+    int ngroups8, G, H, W, sh, sw, align, split;
+    float sy, sx;
+};
+
+__device__ __forceinline__ int pu_chunk(int pos, int h) {       // 16-byte chunk of (position, channel half) in the staged tile
+    const int c = pos * 2 + h;
+    return c ^ ((c >> 4) & 3);
+}
+
+template <int LX>
+__global__ __launch_bounds__(256) void conv_pack_up_kernel(const PackUpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float s_up[];      // [position][8] fp32, chunk-swizzled
+    constexpr int TW = LX * 4, TH = 256 / LX;
+    const int tid = threadIdx.x;
+    const int tx = tid % LX, ty = tid / LX;
+    const int xb = blockIdx.x * TW, yb = blockIdx.y * TH;
+    const int x = xb + tx * 4, y = yb + ty;
+    int z = blockIdx.z;
+    const int cg = a.cg0 + z % a.cgn;
+    z /= a.cgn;
+    const int g = z % a.G;
+    const int n = z / a.G;
+    const long HW = (long)a.H * a.W;
+    const long pl = (long)a.sh * a.sw;
+    const int xl = min(xb + TW - 1, a.W - 1), yl = min(yb + TH - 1, a.H - 1);
+    int ys0, xs0, tw, th;
+    {
+        int i0, i1; float l;
+        cd_resize_src(yb, a.sy, a.sh, a.align, ys0, i1, l);
+        cd_resize_src(xb, a.sx, a.sw, a.align, xs0, i1, l);
+        cd_resize_src(xl, a.sx, a.sw, a.align, i0, i1, l);
+        tw = i1 - xs0 + 1;
+        cd_resize_src(yl, a.sy, a.sh, a.align, i0, i1, l);
+        th = i1 - ys0 + 1;
+    }
+    // stage: position e = (row, column) of the tile's source region, 8 channels per lane and position; two positions' loads
+    // (16) are in flight before the first LDS store
+    const int npos = tw * th;
+    const float inv_tw = 1.0f / (float)tw;
+    const int cl0 = cg * 8 - a.cbase;                   // source-local channel of this group's channel 0
+    const float* sbase = a.src + ((long)n * a.ctot + a.coff + (long)g * a.gstride + cl0) * pl;
+    const int nch = min(8, a.cend - cg * 8);            // live channels of this group
+    for (int e0 = tid; e0 < npos; e0 += 512) {
+        float v[2][8];
+        int pe[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + 256 * u;
+            pe[u] = e < npos ? e : -1;
+            int r = (int)(((float)e + 0.5f) * inv_tw);
+            int q = e - r * tw;
+            if (q < 0) { --r; q += tw; }
+            if (q >= tw) { ++r; q -= tw; }
+            const float* p = sbase + (long)(ys0 + r) * a.sw + xs0 + q;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] = (pe[u] >= 0 && j < nch) ? p[j * pl] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (pe[u] >= 0) {
+                *(f32x4*)(s_up + pu_chunk(pe[u], 0) * 4) = (f32x4){v[u][0], v[u][1], v[u][2], v[u][3]};
+                *(f32x4*)(s_up + pu_chunk(pe[u], 1) * 4) = (f32x4){v[u][4], v[u][5], v[u][6], v[u][7]};
+            }
+    }
+    __syncthreads();
+    if (x >= a.W || y >= a.H) return;
+    int r0, r1;
+    float ly;
+    {
+        int y0, y1;
+        cd_resize_src(y, a.sy, a.sh, a.align, y0, y1, ly);
+        r0 = (y0 - ys0) * tw - xs0;
+        r1 = (y1 - ys0) * tw - xs0;
+    }
+    const float hy = 1.f - ly;
+    unsigned char* o = a.out + cd_item_off((long)n * a.G + g, a.ngroups8, cg, HW, (long)y * a.W + x, a.split);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int x0, x1;
+        float lx;
+        cd_resize_src(x + i, a.sx, a.sw, a.align, x0, x1, lx);
+        const float hx = 1.f - lx;
+        // (the second half of a position is the neighbouring chunk: pu_chunk(p, 1) == pu_chunk(p, 0) ^ 1)
+        const int ia = pu_chunk(r0 + x0, 0), ib = pu_chunk(r0 + x1, 0), ic = pu_chunk(r1 + x0, 0), id = pu_chunk(r1 + x1, 0);
+        float v[8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f32x4 ta = *(const f32x4*)(s_up + (ia ^ h) * 4), tb = *(const f32x4*)(s_up + (ib ^ h) * 4);
+            const f32x4 tc = *(const f32x4*)(s_up + (ic ^ h) * 4), td = *(const f32x4*)(s_up + (id ^ h) * 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * h + k] = hy * (hx * ta[k] + lx * tb[k]) + ly * (hx * tc[k] + lx * td[k]);
+        }
+        *(u32x4*)(o + i * 16) = cd_item8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], false);
+        if (a.split) *(u32x4*)(o + HW * 16 + i * 16) = cd_item8(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], true);
+    }
+}
+
 extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
                                              const float* src2, const int32_t* src_h, const int32_t* src_w,
                                              const int32_t* align_corners, void* packed) {
@@ -453,24 +568,76 @@ extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc
             if (th * tw > cap) cap = th * tw;
         }
     if (cap > PL_CAP) staged = false;
-    if (staged) {
-        a.cap = (int)((cap + 31) / 32 * 32);
-        const size_t lds = (size_t)8 * a.cap * sizeof(float);       // <= 40 KB
-        const dim3 grid(jaf_cdiv(d->W, PL_TW), jaf_cdiv(d->H, PL_TH), (unsigned)nz);
-        const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
-        JAF_NOTE_KERNEL("conv_pack_input_lazy_lds_kernel<%d>", (al && d->W % 4 == 0) ? 4 : 1);
-        if (al && d->W % 4 == 0) hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<4>, grid, dim3(256), lds, (hipStream_t)s, a);
-        else hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, a);
-        return jaf_launch_status();
+    const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
+    // Channel groups inside one resized source: conv_pack_up_kernel; the others (label / skip channels, groups that straddle two
+    // sources): the general kernels over the remaining group ranges.  JAF_PACK_UP=0 sends everything through the general kernels.
+    static const int up_env = getenv("JAF_PACK_UP") ? atoi(getenv("JAF_PACK_UP")) : 1;
+    const bool up_ok = up_env && staged && d->W % 4 == 0;
+    const int cb[4] = {0, d->src_c[0], d->src_c[0] + (d->nsrc > 1 ? d->src_c[1] : 0), d->Cin};
+    const float* srcs[3] = {src0, src1, src2};
+    auto cls = [&](int cg) {      // the resized source that holds all live channels of group cg, or -1
+        if (!up_ok) return -1;
+        const int lo = cg * 8, hi = (cg * 8 + 8 < d->Cin ? cg * 8 + 8 : d->Cin) - 1;
+        for (int i = 0; i < d->nsrc; ++i) {
+            const int e = (i + 1 < d->nsrc) ? cb[i + 1] : d->Cin;
+            if (a.lazy[i] && lo >= cb[i] && hi < e) return i;
+        }
+        return -1;
+    };
+    for (int cg0 = 0; cg0 < a.b.ngroups8;) {
+        const int c = cls(cg0);
+        int cg1 = cg0 + 1;
+        while (cg1 < a.b.ngroups8 && cls(cg1) == c) ++cg1;
+        const int cgn = cg1 - cg0;
+        const unsigned gz = (unsigned)((long)d->N * d->G * cgn);
+        if (c >= 0) {
+            PackUpArgs u;
+            u.src = srcs[c];
+            u.out = (unsigned char*)packed;
+            u.ctot = d->src_ctot[c]; u.coff = d->src_coff[c]; u.gstride = d->src_gstride[c];
+            u.cbase = cb[c];
+            u.cend = d->Cin;
+            u.cg0 = cg0; u.cgn = cgn;
+            u.ngroups8 = a.b.ngroups8; u.G = d->G; u.H = d->H; u.W = d->W;
+            u.sh = a.sh[c]; u.sw = a.sw[c]; u.align = a.align[c]; u.split = a.b.split;
+            u.sy = a.sy[c]; u.sx = a.sx[c];
+            int lx = d->W >= 192 ? 64 : (d->W >= 96 ? 32 : 16);
+            long th = 0, tw = 0;
+            for (;; lx >>= 1) {          // (a wide tile of a source that is not up-sampled may not fit the staging buffer)
+                th = (long)ceilf(u.sy * (256 / lx)) + 3;
+                tw = (long)ceilf(u.sx * (lx * 4)) + 3;
+                if (th * tw <= PL_CAP || lx == 16) break;
+            }
+            const size_t lds = (size_t)((th * tw + 7) / 8 * 8) * 32;      // [position][8] fp32; <= 40 KB (PL_CAP)
+            const dim3 grid(jaf_cdiv(d->W, lx * 4), jaf_cdiv(d->H, 256 / lx), gz);
+            JAF_NOTE_KERNEL("conv_pack_up_kernel<%d>", lx);
+            if (lx == 64) hipLaunchKernelGGL(conv_pack_up_kernel<64>, grid, dim3(256), lds, (hipStream_t)s, u);
+            else if (lx == 32) hipLaunchKernelGGL(conv_pack_up_kernel<32>, grid, dim3(256), lds, (hipStream_t)s, u);
+            else hipLaunchKernelGGL(conv_pack_up_kernel<16>, grid, dim3(256), lds, (hipStream_t)s, u);
+        } else {
+            a.cg0 = cg0;
+            a.cgn = cgn;
+            if (staged) {
+                a.cap = (int)((cap + 31) / 32 * 32);
+                const size_t lds = (size_t)8 * a.cap * sizeof(float);       // <= 40 KB
+                const dim3 grid(jaf_cdiv(d->W, PL_TW), jaf_cdiv(d->H, PL_TH), gz);
+                JAF_NOTE_KERNEL("conv_pack_input_lazy_lds_kernel<%d>", (al && d->W % 4 == 0) ? 4 : 1);
+                if (al && d->W % 4 == 0) hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<4>, grid, dim3(256), lds, (hipStream_t)s, a);
+                else hipLaunchKernelGGL(conv_pack_input_lazy_lds_kernel<1>, grid, dim3(256), lds, (hipStream_t)s, a);
+            } else {
+                a.cap = 0;
+                int tx = 64;
+                while (tx > 8 && (tx >> 1) >= d->W) tx >>= 1;
+                const int ty = 256 / tx;
+                JAF_NOTE_KERNEL("conv_pack_input_lazy_kernel");
+                hipLaunchKernelGGL(conv_pack_input_lazy_kernel, dim3(jaf_cdiv(d->W, tx), jaf_cdiv(d->H, ty), gz), dim3(tx, ty), 0, (hipStream_t)s, a);
+            }
+        }
+        const int rc = jaf_launch_status();
+        if (rc != JAF_OK) return rc;
+        cg0 = cg1;
     }
-    a.cap = 0;
-    int tx = 64;
-    while (tx > 8 && (tx >> 1) >= d->W) tx >>= 1;
-    const int ty = 256 / tx;
-    JAF_NOTE_KERNEL("conv_pack_input_lazy_kernel");
-    hipLaunchKernelGGL(conv_pack_input_lazy_kernel, dim3(jaf_cdiv(d->W, tx), jaf_cdiv(d->H, ty), (unsigned)nz), dim3(tx, ty), 0,
-                       (hipStream_t)s, a);
-    return jaf_launch_status();
+    return JAF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
