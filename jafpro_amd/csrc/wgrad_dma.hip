@@ -395,10 +395,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 //  * B fragments are requested three taps ahead of the MFMAs that consume them;
 //  * the tile walk is incremental (no divisions per tile), and a tile whose patch lies inside the image skips the per-piece bounds
 //    logic: one add per DMA piece.
-template <int MTW, bool DB, int WC>
+template <int MTW, bool DB, int WC, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a) {
     constexpr int NW = 4, WK = 4 / WC, XI = 2 * WC, PWP = 24, PH = 10, PW = 18, XPLANE = 8192;
-    constexpr int LA = (MTW == 4 && DB) ? 2 : 3;      // taps the B fragments run ahead (registers: 64 rows double-buffered spill at 3)
+    constexpr int LA = ((MTW == 4 && DB) || SPLIT) ? 2 : 3;      // taps the B fragments run ahead (registers: 64 rows double-buffered spill at 3)
     typedef __attribute__((address_space(3))) unsigned char* ldsb;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
         slot_rc(i, r, c, hf);
         const int grp8 = (ci0 >> 3) + 2 * (i >> 3) + hf;
         const bool live = (r < PH) && (c < PW) && (grp8 < a.ngin8);
-        x_goff[j] = live ? (grp8 * HW + r * d.W + c) * 16 : WD_OOB;
+        x_goff[j] = live ? ((SPLIT ? 2 * grp8 : grp8) * HW + r * d.W + c) * 16 : WD_OOB;
     }
     int z_yx, z_goff, z_half;
     {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
         z_half = (raw >> 4) & 1;
         const int y = k >> 4, x = k & 15;
         z_yx = (y << 16) | x;
-        z_goff = (z_half * OHW + y * d.OW + x) * 16;
+        z_goff = ((SPLIT ? 2 * z_half : z_half) * OHW + y * d.OW + x) * 16;
     }
 
     // ---- per-lane bases of the transposed reads (byte offsets inside a tile buffer) ----
@@ -487,8 +487,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
-    const int xbytes = a.xng8 * HW * 16;
-    const int zbytes = a.ngout8 * OHW * 16;
+    const int xbytes = a.xng8 * HW * 16 * (SPLIT ? 2 : 1);
+    const int zbytes = a.ngout8 * OHW * 16 * (SPLIT ? 2 : 1);
     const int count = split < items ? (items - split + a.nsplit - 1) / a.nsplit : 0;       // tiles of this pixel split
 
     // the next tile to fetch: (image, tile row, tile column), advanced by nsplit tiles without divisions
@@ -506,7 +506,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
         const unsigned dstx = lds0 + boff + wave * 1024;
         if (iy0 >= 0 && ix0 >= 0 && iy0 + PH <= d.H && ix0 + PW <= d.W) {     // (uniform) the whole patch is inside the image
 #pragma unroll
-            for (int j = 0; j < XI; ++j) jaf_dma16_async(rxa, dstx + NW * j * 1024, x_goff[j] + tbase);
+            for (int j = 0; j < XI; ++j) {
+                jaf_dma16_async(rxa, dstx + NW * j * 1024, x_goff[j] + tbase);
+                if constexpr (SPLIT) jaf_dma16_async(rxa, dstx + a.off_lo + NW * j * 1024, x_goff[j] + tbase + HW * 16);      // (the residual plane follows the hi plane)
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < XI; ++j) {
@@ -515,16 +518,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
                 const int iy = iy0 + r, ix = ix0 + c;
                 const bool ok = (x_goff[j] != WD_OOB) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
                 jaf_dma16_async(rxa, dstx + NW * j * 1024, ok ? x_goff[j] + tbase : WD_OOB);
+                if constexpr (SPLIT) jaf_dma16_async(rxa, dstx + a.off_lo + NW * j * 1024, ok ? x_goff[j] + tbase + HW * 16 : WD_OOB);
             }
         }
         const jaf_u32x4 rza = jaf_make_rsrc(a.dzp + ((long)in_n * d.G + g) * (long)zbytes, (unsigned)zbytes);
         const bool okp = (oy0 + (z_yx >> 16) < d.OH) && (ox0 + (z_yx & 0xffff) < d.OW);
-        const int zb = z_goff + (oy0 * d.OW + ox0) * 16 + (co0 >> 3) * OHW * 16;
+        const int zb = z_goff + (oy0 * d.OW + ox0) * 16 + (co0 >> 3) * (SPLIT ? 2 : 1) * OHW * 16;
         const unsigned dstz = lds0 + a.off_dz + boff + wave * 1024;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
             const bool ok = okp && ((co0 >> 3) + 2 * mt + z_half < a.ngout8);
-            jaf_dma16_async(rza, dstz + mt * 4096, ok ? zb + 2 * mt * OHW * 16 : WD_OOB);
+            jaf_dma16_async(rza, dstz + mt * 4096, ok ? zb + 2 * mt * (SPLIT ? 2 : 1) * OHW * 16 : WD_OOB);
+            if constexpr (SPLIT) jaf_dma16_async(rza, dstz + a.off_lo + mt * 4096, ok ? zb + 4 * mt * OHW * 16 + OHW * 16 : WD_OOB);
         }
         in_n += a.step_n;
         in_tx += a.step_tx;
@@ -557,14 +562,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
         if (DB) cur ^= a.bufsz;
 #pragma unroll
         for (int ks = 0; ks < 4; ks += WK) {          // (the wave's k-steps are wk + ks: wk sits in the bases)
-            bf16x8 af[MTW];
+            bf16x8 af[MTW], al[SPLIT ? MTW : 1];
 #pragma unroll
             for (int mt = 0; mt < MTW; ++mt) {
                 const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa0 + mt * 4096 + ks * 1024));
                 const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa1 + mt * 4096 + ks * 1024));
                 af[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                if constexpr (SPLIT) {
+                    const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa0 + a.off_lo + mt * 4096 + ks * 1024));
+                    const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pa1 + a.off_lo + mt * 4096 + ks * 1024));
+                    al[mt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
             }
-            bf16x8 bf[9];
+            bf16x8 bf[9], bl[SPLIT ? 9 : 1];
 #pragma unroll
             for (int t = 0; t < 9 + LA; ++t) {
                 if (t < 9) {
@@ -572,15 +582,25 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
                     const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb[0][t % 3] + off));
                     const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb[1][t % 3] + off));
                     bf[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    if constexpr (SPLIT) {
+                        const s16x4 c0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb[0][t % 3] + a.off_lo + off));
+                        const s16x4 c1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(pb[1][t % 3] + a.off_lo + off));
+                        bl[t] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(c0, c1, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
                 }
                 if (t >= LA) {
 #pragma unroll
-                    for (int mt = 0; mt < MTW; ++mt)
+                    for (int mt = 0; mt < MTW; ++mt) {
+                        if constexpr (SPLIT) {      // dz_l x_h + dz_h x_l + dz_h x_h, in the general kernel's order
+                            acc[mt][t - LA] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bf[t - LA], acc[mt][t - LA], 0, 0, 0);
+                            acc[mt][t - LA] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bl[t - LA], acc[mt][t - LA], 0, 0, 0);
+                        }
                         acc[mt][t - LA] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], bf[t - LA], acc[mt][t - LA], 0, 0, 0);
+                    }
                 }
                 // 64 rows double-buffered: keep the source order (the scheduler otherwise requests a whole k-step's fragments at once and
                 // the register allocator spills the DMA constants, whose reloads then wait on the DMA in flight: vmcnt is shared)
-                if constexpr (MTW == 4 && DB) __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((MTW == 4 && DB) || SPLIT) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -609,9 +629,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
     }
 }
 
-template <int MTW, bool DB, int WC>
+template <int MTW, bool DB, int WC, bool SPLIT = false>
 static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
-    auto k = conv_wgrad_fast_kernel<MTW, DB, WC>;
+    auto k = conv_wgrad_fast_kernel<MTW, DB, WC, SPLIT>;
     static int optin[JAF_MAX_DEVICES];
     static JafOcc occ[JAF_MAX_DEVICES][8];
     if (lds > 48 * 1024) {
@@ -629,7 +649,7 @@ static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long
     a.step_tx = dt - a.step_ty * a.tiles_x;
     const long nblk = outblocks * a.nsplit;
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
-    JAF_NOTE_KERNEL("conv_wgrad_fast_kernel<%d, %s, %d>", MTW, DB ? "true" : "false", WC);
+    JAF_NOTE_KERNEL("conv_wgrad_fast_kernel<%d, %s, %d, %s>", MTW, DB ? "true" : "false", WC, SPLIT ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
     return jaf_launch_status();
 }
@@ -772,6 +792,13 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
         JAF_WGF(1, true, 4); JAF_WGF(2, true, 4); JAF_WGF(3, false, 4); JAF_WGF(4, false, 4);
         JAF_WGF(1, true, 2); JAF_WGF(2, true, 2); JAF_WGF(3, true, 2); JAF_WGF(4, true, 2);
         JAF_WGF(1, true, 1); JAF_WGF(2, true, 1); JAF_WGF(3, true, 1); JAF_WGF(4, true, 1);
+#undef JAF_WGF
+    }
+    // split-bf16: the tilings the LDS rules above produce (64 rows: 32 or 16 channels single-buffered; fewer rows: 16 channels double-buffered)
+    static const int fast_split_env = getenv("JAF_WGRAD_FAST_SPLIT") ? atoi(getenv("JAF_WGRAD_FAST_SPLIT")) : 1;
+    if (fast_env && fast_split_env && split && KS == 3 && d->stride == 1 && a.nx == 8 && a.PWp == 24) {
+#define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_, true>(a, lds, items, outblocks, dw_floats, s)
+        JAF_WGF(4, false, 2); JAF_WGF(4, false, 1); JAF_WGF(3, true, 1); JAF_WGF(2, true, 1); JAF_WGF(1, true, 2); JAF_WGF(1, true, 1);
 #undef JAF_WGF
     }
 #define JAF_WGD(MT_, KS_) JAF_WGDP(MT_, KS_, false)

@@ -742,9 +742,9 @@ def test_kernel_names_come_from_the_launch():
         seen[mode] = sorted(prof.summary())
     assert any(re.fullmatch(r"conv_mfma_kernel<\d, \d, \d, false>", k) for k in seen["f32"]), seen["f32"]
     assert any(re.fullmatch(r"conv_dma_kernel<\d, \d, false, (true|false), (true|false)>", k) for k in seen["bf16"]), seen["bf16"]
-    assert any(re.fullmatch(r"conv_wgrad_fast_kernel<\d, (true|false), \d>", k) for k in seen["bf16"]), seen["bf16"]     # stride-1 3 x 3
+    assert any(re.fullmatch(r"conv_wgrad_fast_kernel<\d, (true|false), \d, false>", k) for k in seen["bf16"]), seen["bf16"]     # stride-1 3 x 3
     assert any(re.fullmatch(r"conv_dma_split_kernel<\d, \d, false, (true|false)>", k) for k in seen["bf16x3"]), seen["bf16x3"]
-    assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, true>", k) for k in seen["bf16x3"]), seen["bf16x3"]
+    assert any(re.fullmatch(r"conv_wgrad_fast_kernel<\d, (true|false), \d, true>", k) for k in seen["bf16x3"]), seen["bf16x3"]
     assert "conv_pack_dz_kernel" in seen["bf16"] and "conv_pack_input_kernel" in seen["bf16x3"]
     # a stride-2 layer stays on the general weight-gradient kernel
     x = dev(R(3, 1, 24, 40, 40))
