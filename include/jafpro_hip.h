@@ -264,6 +264,15 @@ int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s, const jaf_conv_desc* d, const voi
  * them (channel 4*c + gate): row gate*hidden + c of dW receives channel 4*c + gate (hidden = 0: jaf_conv2d_wgrad_packed_ex). */
 int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
                                  const void* packed_dz, float* dw, int accumulate, int32_t hidden);
+/* The same with a caller-owned workspace for split-K partial sums: where the atomic traffic of a launch (pixel splits x dW) is
+ * large, every pixel split stores its block of dW to its own copy in `workspace` and one reduction pass adds the copies to dW --
+ * stores and loads at HBM rate instead of fp32 atomics at the memory side's ~1.3 TB/s, and a fixed summation order (bit-stable
+ * weight gradients for those layers).  jaf_conv2d_wgrad_packed_ws_bytes: the bytes such a launch uses (0: the layer stays on atomics;
+ * a smaller or NULL workspace also falls back to atomics).  The workspace is scratch: no contents survive the call's stream work. */
+int64_t jaf_conv2d_wgrad_packed_ws_bytes(const jaf_conv_desc* d, int32_t hidden);
+int jaf_conv2d_wgrad_packed_ws(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
+                               const void* packed_dz, float* dw, int accumulate, int32_t hidden, void* workspace,
+                               int64_t workspace_bytes);
 
 /* dW[G][Cout][w_cin_tot][KH][KW] (+)= sum over n,pixels of dz * input patch; dz is laid out as
  * the forward output (out_ctot/out_coff).  accumulate=0 zeroes the touched slice first.        */

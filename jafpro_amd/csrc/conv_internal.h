@@ -36,8 +36,7 @@ static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, 
 // measured on the 24 -> 48 @ 200 x 200 ConvLSTM layer (2 workgroups per CU by registers), 22 splits (528 workgroups, what the
 // continuous model picks for 512 slots) 0.59 ms, 32 splits (768 = 1.5 rounds) 0.46 ms, 21 splits (504, one round) 0.36 ms.
 static inline long jaf_wgrad_nsplit_rounds(long items, long outblocks, long dw_floats, double slots, double t_item = 2.5e-6,
-                                           long max_split = JAF_WGRAD_MAX_SPLIT) {
-    const double atomics_per_s = 3e11;
+                                           long max_split = JAF_WGRAD_MAX_SPLIT, double atomics_per_s = 3e11) {
     long best = 1;
     double best_t = 1e30;
     const long hi = items < max_split ? items : max_split;

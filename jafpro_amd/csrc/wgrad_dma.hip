@@ -46,6 +46,8 @@ struct WgDArgs {
     float inv_pwp;
     int lstmC;             // > 0: dz channels are the ConvLSTM's gate gradients, channel-major (4 c + gate): dW row gate * lstmC + c
     int step_n, step_ty, step_tx;      // conv_wgrad_fast_kernel: nsplit tiles further = (images, tile rows, tile columns)
+    float* ws;             // conv_wgrad_fast_kernel: split-K partials [nsplit][dW layout] (plain stores) instead of atomics into dw; NULL: atomics
+    long ws_stride;        // floats of one partial = G * Cout * w_cin_tot * 9
     int off_lo;            // SPLIT: byte offset of the lo tiles from the hi tiles inside a tile buffer (patch and dz alike)
 };
 
@@ -620,17 +622,51 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
             const int co = co0 + mt * 16 + row;
             if (co >= d.Cout) break;
             const int cod = a.lstmC > 0 ? (co & 3) * a.lstmC + (co >> 2) : co;
-            float* prow = a.dw + (((long)(g * d.Cout + cod) * d.w_cin_tot) + d.w_cin_off + cit) * 9;
+            const long roff = (((long)(g * d.Cout + cod) * d.w_cin_tot) + d.w_cin_off + cit) * 9;
             const float* srow = s_ep + row * WD_EP;
+            if (a.ws) {         // this (pixel split, k-step share)'s own copy of dW: plain stores, summed by wgrad_reduce_kernel
+                float* prow = a.ws + (long)(split * WK + wk) * a.ws_stride + roff;
 #pragma unroll
-            for (int rem = lane; rem < 144; rem += 64)
-                if (rem < nrem) atomicAdd(prow + rem, srow[rem]);
+                for (int rem = lane; rem < 144; rem += 64)
+                    if (rem < nrem) prow[rem] = srow[rem];
+            } else if (WK == 1 && a.nsplit == 1) {      // the only writer of these elements: plain read-modify-write, no atomics
+                float* prow = a.dw + roff;
+#pragma unroll
+                for (int rem = lane; rem < 144; rem += 64)
+                    if (rem < nrem) prow[rem] += srow[rem];
+            } else {
+                float* prow = a.dw + roff;
+#pragma unroll
+                for (int rem = lane; rem < 144; rem += 64)
+                    if (rem < nrem) atomicAdd(prow + rem, srow[rem]);
+            }
         }
     }
 }
 
+// dW += sum over the pixel splits of their partial copies (rows of dW = (group, output channel), `seg` floats of each row starting
+// at `off`: the input-channel slice this launch produced).  grid (column blocks, rows).
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int seg, int pitch, int off, long stride, int nsplit) {
+    const long base = (long)blockIdx.y * pitch + off;
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < seg; c += gridDim.x * blockDim.x) {
+        float acc = 0.f;
+        for (int sidx = 0; sidx < nsplit; ++sidx) acc += ws[(long)sidx * stride + base + c];
+        dw[base + c] += acc;
+    }
+}
+
+// Split-K partials instead of atomics: where a launch's atomic traffic nsplit x dW is large -- the ConvLSTM's
+// 25 x 25 / 13 x 13 levels (24 groups x 384 x 192 x 9 floats of dW, 6 splits: 127 MB of fp32 atomics at the memory side's ~1.3 TB/s =
+// 98 us of a 123 us launch), the CRN's 512-channel layers at 4 x 4 .. 64 x 64 -- every pixel split stores its block to its own copy
+// of dW and one reduction pass adds the copies: stores and loads at HBM rate, and the sum order is fixed (bit-stable gradients).
+struct WgWs {
+    float* ws;
+    long ws_bytes;
+    long* need;          // query: bytes the launch would use (0: it stays on atomics); nothing is launched
+};
+
 template <int MTW, bool DB, int WC, bool SPLIT = false>
-static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s) {
+static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long dw_floats, hipStream_t s, const WgWs* wr) {
     auto k = conv_wgrad_fast_kernel<MTW, DB, WC, SPLIT>;
     static int optin[JAF_MAX_DEVICES];
     static JafOcc occ[JAF_MAX_DEVICES][8];
@@ -642,6 +678,18 @@ static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long
     const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
     a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
+    a.ws = nullptr;
+    a.ws_stride = (long)a.d.G * a.d.Cout * a.d.w_cin_tot * 9;
+    if (wr) {
+        // a split costs a store + a load of dW at HBM rate instead of an atomic pass (~4x cheaper): the optimum has more splits
+        static const double part_rate = getenv("JAF_WGRAD_PART_RATE") ? atof(getenv("JAF_WGRAD_PART_RATE")) : 1.0e12;
+        static const long part_min = getenv("JAF_WGRAD_PART_MIN") ? atol(getenv("JAF_WGRAD_PART_MIN")) : 6000000L;      // floats of atomic traffic
+        const int nsp = (int)jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots, 2.5e-6, JAF_WGRAD_MAX_SPLIT, part_rate);
+        constexpr int WKC = 4 / WC;        // waves that share an input-channel tile hold partial sums over their own k-steps: one copy each
+        const long need = (nsp >= 2 && (long)a.nsplit * dw_floats >= part_min) ? (long)nsp * WKC * a.ws_stride * 4 : 0;
+        if (wr->need) { *wr->need = need; return JAF_OK; }
+        if (need > 0 && wr->ws && need <= wr->ws_bytes) { a.nsplit = nsp; a.ws = wr->ws; }
+    }
     const int tiles = a.tiles_x * a.tiles_y;
     a.step_n = a.nsplit / tiles;
     const int dt = a.nsplit - a.step_n * tiles;
@@ -651,6 +699,12 @@ static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
     JAF_NOTE_KERNEL("conv_wgrad_fast_kernel<%d, %s, %d, %s>", MTW, DB ? "true" : "false", WC, SPLIT ? "true" : "false");
     hipLaunchKernelGGL(k, dim3((unsigned)nblk), dim3(256), (size_t)lds, s, a);
+    if (a.ws) {
+        const int seg = a.d.Cin * 9, rows = a.d.G * a.d.Cout;
+        int bx = jaf_cdiv(seg, 256);
+        if (bx > 8) bx = 8;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bx, rows), dim3(256), 0, s, a.ws, a.dw, seg, a.d.w_cin_tot * 9, a.d.w_cin_off * 9, a.ws_stride, a.nsplit * (4 / WC));
+    }
     return jaf_launch_status();
 }
 
@@ -671,6 +725,7 @@ static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long d
     const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
     a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
+    a.ws = nullptr;
     const long nblk = outblocks * a.nsplit;
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
     JAF_NOTE_KERNEL("conv_wgrad_dma_kernel<%d, %d, %s, %s, %d, %s>", MTW, KS, PAIR ? "true" : "false", DB ? "true" : "false", XI, SPLIT ? "true" : "false");
@@ -705,16 +760,41 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
     return jaf_conv2d_wgrad_packed_lstm(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, 0);
 }
 
+static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot, const void* packed_dz, float* dw,
+                    int accumulate, int32_t hidden, const WgWs* wr);
+
 extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
                                             const void* packed_dz, float* dw, int accumulate, int32_t hidden) {
     JAF_REQUIRE(d && packed_x && packed_dz && dw);
+    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, nullptr);
+}
+
+extern "C" int64_t jaf_conv2d_wgrad_packed_ws_bytes(const jaf_conv_desc* d, int32_t hidden) {
+    if (!d) return JAF_EINVAL;
+    long need = 0;
+    const WgWs wr = {nullptr, 0, &need};
+    const int rc = wgd_core(nullptr, d, nullptr, 0, nullptr, nullptr, 1, hidden, &wr);
+    return rc == JAF_OK ? (int64_t)need : (int64_t)rc;
+}
+
+extern "C" int jaf_conv2d_wgrad_packed_ws(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
+                                          const void* packed_dz, float* dw, int accumulate, int32_t hidden, void* workspace,
+                                          int64_t workspace_bytes) {
+    JAF_REQUIRE(d && packed_x && packed_dz && dw);
+    const WgWs wr = {(float*)workspace, (long)workspace_bytes, nullptr};
+    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, workspace ? &wr : nullptr);
+}
+
+static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot, const void* packed_dz, float* dw,
+                    int accumulate, int32_t hidden, const WgWs* wr) {
+    const bool query = wr && wr->need;
     JAF_REQUIRE(hidden == 0 || (hidden > 0 && d->KH == 3 && d->Cout == 4 * hidden));
     JAF_REQUIRE(x_ng8_tot == 0 || x_ng8_tot >= jaf_cdiv(d->Cin, 8));
     JAF_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5) && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
     const int KS = d->KH;
     JAF_REQUIRE(d->N >= 1 && d->G >= 1 && d->Cin >= 1 && d->Cout >= 1 && d->w_cin_off >= 0 && d->w_cin_off + d->Cin <= d->w_cin_tot);
     hipStream_t s = (hipStream_t)s_;
-    if (!accumulate) {
+    if (!accumulate && !query) {
         hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->G * d->Cout * d->w_cin_tot * KS * KS, s);
         if (e != hipSuccess) return (int)e;
     }
@@ -788,7 +868,7 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     // JAF_WGRAD_* experiment hook that changes the buffering, falls back to the general kernel)
     static const int fast_env = getenv("JAF_WGRAD_FAST") ? atoi(getenv("JAF_WGRAD_FAST")) : 1;
     if (fast_env && !split && KS == 3 && d->stride == 1 && a.nx == 8 && a.PWp == 24) {
-#define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_>(a, lds, items, outblocks, dw_floats, s)
+#define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_>(a, lds, items, outblocks, dw_floats, s, wr)
         JAF_WGF(1, true, 4); JAF_WGF(2, true, 4); JAF_WGF(3, false, 4); JAF_WGF(4, false, 4);
         JAF_WGF(1, true, 2); JAF_WGF(2, true, 2); JAF_WGF(3, true, 2); JAF_WGF(4, true, 2);
         JAF_WGF(1, true, 1); JAF_WGF(2, true, 1); JAF_WGF(3, true, 1); JAF_WGF(4, true, 1);
@@ -797,10 +877,11 @@ extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc
     // split-bf16: the tilings the LDS rules above produce (64 rows: 32 or 16 channels single-buffered; fewer rows: 16 channels double-buffered)
     static const int fast_split_env = getenv("JAF_WGRAD_FAST_SPLIT") ? atoi(getenv("JAF_WGRAD_FAST_SPLIT")) : 1;
     if (fast_env && fast_split_env && split && KS == 3 && d->stride == 1 && a.nx == 8 && a.PWp == 24) {
-#define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_, true>(a, lds, items, outblocks, dw_floats, s)
+#define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_, true>(a, lds, items, outblocks, dw_floats, s, wr)
         JAF_WGF(4, false, 2); JAF_WGF(4, false, 1); JAF_WGF(3, true, 1); JAF_WGF(2, true, 1); JAF_WGF(1, true, 2); JAF_WGF(1, true, 1);
 #undef JAF_WGF
     }
+    if (query) { *wr->need = 0; return JAF_OK; }          // (the general kernel keeps its atomics)
 #define JAF_WGD(MT_, KS_) JAF_WGDP(MT_, KS_, false)
 #define JAF_WGDP(MT_, KS_, PAIR_) \
     return db ? wgd_launch<MT_, KS_, PAIR_, true>(a, lds, items, outblocks, dw_floats, s) \

@@ -502,6 +502,46 @@ def refresh_packed_weights(params) -> None:
 
 
 _BATCHED_REPACK = os.environ.get("JAF_NO_BATCHED_REPACK") is None
+
+# Split-K partial sums of the packed weight-gradient kernel (include/jafpro_hip.h, jaf_conv2d_wgrad_packed_ws): one scratch buffer per
+# stream that launches weight gradients (launches on a stream run one after the other, and the reduction pass of a launch has read the
+# partials before the next launch overwrites them).  Opt-in (JAF_WGRAD_PARTIALS=1 / set_wgrad_partials): measured neutral on the step
+# (profiles/experiments/round4_x4.log); what it buys is a fixed summation order -- bit-reproducible weight gradients -- on the layers
+# whose atomic traffic is large enough for the library to take the workspace.
+_WGRAD_PARTIALS = os.environ.get("JAF_WGRAD_PARTIALS", "0") == "1"
+_WGRAD_WS: dict = {}            # stream handle -> uint8 tensor
+_WGRAD_WS_OLD: list = []        # outgrown buffers stay allocated (a launch enqueued earlier may still use them)
+_WGRAD_WS_NEED: dict = {}       # (descriptor identity, hidden) -> bytes (0: the layer stays on atomics)
+
+
+def set_wgrad_partials(on: bool) -> bool:
+    """Split-K partial sums instead of fp32 atomics where the library's cost model takes them; returns the previous setting."""
+    global _WGRAD_PARTIALS
+    prev, _WGRAD_PARTIALS = _WGRAD_PARTIALS, bool(on)
+    return prev
+
+
+def _wgrad_workspace(d, hidden: int, stream_handle: int, device):
+    """(pointer or None, bytes) for jaf_conv2d_wgrad_packed_ws."""
+    if not _WGRAD_PARTIALS:
+        return None, 0
+    key = (id(d), hidden)
+    need = _WGRAD_WS_NEED.get(key)
+    if need is None:
+        need = int(lib().jaf_conv2d_wgrad_packed_ws_bytes(ctypes.byref(d), hidden))
+        need = max(need, 0)
+        if len(_WGRAD_WS_NEED) > 8192:
+            _WGRAD_WS_NEED.clear()
+        _WGRAD_WS_NEED[key] = need
+    if need == 0:
+        return None, 0
+    buf = _WGRAD_WS.get(stream_handle)
+    if buf is None or buf.numel() < need or buf.device != device:
+        if buf is not None:
+            _WGRAD_WS_OLD.append(buf)
+        buf = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device)
+        _WGRAD_WS[stream_handle] = buf
+    return _p(buf), buf.numel()
 _REPACK_TABLES: dict = {}
 
 
@@ -811,8 +851,9 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool, stream=None):
             dzd = _make_desc(m.N, m.G, m.Cout, 1, m.OH, m.OW, m.OH, m.OW, 1, 1, 1, 0, 0, 1,
                              [(m.Cout, m.G * m.Cout, 0, m.Cout)], 1, 0, m.G, 0, ACT_NONE, 0.0)
             dzp = pack_input([dz], dzd)
-        check(L.jaf_conv2d_wgrad_packed_ex(sh, ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
-                                           1 if inplace else 0), "jaf_conv2d_wgrad_packed_ex")
+        wsp, wsb = _wgrad_workspace(d, 0, sh.value if stream is not None else torch.cuda.current_stream().cuda_stream, dw.device)
+        check(L.jaf_conv2d_wgrad_packed_ws(sh, ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
+                                           1 if inplace else 0, 0, wsp, wsb), "jaf_conv2d_wgrad_packed_ws")
         wname = _launched() if ev is not None else ""
     else:
         check(L.jaf_conv2d_wgrad(sh, ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
@@ -1263,8 +1304,9 @@ class _ConvLSTMFn(Function):
                 with torch.cuda.stream(wst if wst is not None else torch.cuda.current_stream()):
                     ev = _PROF.begin() if _PROF is not None else None
                     # (the packed gate gradients are channel-major, 4 c + gate: the kernel permutes the rows of dW)
-                    check(L.jaf_conv2d_wgrad_packed_lstm(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
-                                                         1 if w_inplace else acc, C), "jaf_conv2d_wgrad_packed_lstm")
+                    wsp, wsb = _wgrad_workspace(d, C, torch.cuda.current_stream().cuda_stream, dw.device)
+                    check(L.jaf_conv2d_wgrad_packed_ws(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
+                                                       1 if w_inplace else acc, C, wsp, wsb), "jaf_conv2d_wgrad_packed_ws")
                     if ev is not None:
                         _PROF.end(_launched(), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:

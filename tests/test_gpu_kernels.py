@@ -758,3 +758,33 @@ def test_kernel_names_come_from_the_launch():
         ops.set_profiler(None)
         ops.set_precision(prev)
     assert any(re.fullmatch(r"conv_wgrad_dma_kernel<\d, 3, false, (true|false), \d+, false>", k) for k in prof.summary()), sorted(prof.summary())
+
+
+def test_weight_gradient_partials_are_bit_reproducible():
+    """jaf_conv2d_wgrad_packed_ws: with a workspace the pixel splits of a large layer store their blocks of dW to their own copies and
+    one pass adds them in a fixed order -- the same bits on every run, and the atomics' result to rounding."""
+    ops = _ops()
+    x = dev(R(1, 2, 24 * 96, 25, 25))
+    w = dev(R(2, 24 * 192, 96, 3, 3, lo=-0.05, hi=0.05))
+    proj = dev(R(3, 2, 24 * 192, 25, 25))
+
+    def grad(partials):
+        prev_p, prev = ops.set_wgrad_partials(partials), ops.set_precision("bf16")
+        try:
+            wd = w.clone().requires_grad_(True)
+            y = ops.conv2d(x.clone().requires_grad_(True), wd, None, stride=1, pad=1, act=0, groups=24)
+            (y * proj).sum().backward()
+            torch.cuda.synchronize()
+            return wd.grad.clone()
+        finally:
+            ops.set_precision(prev)
+            ops.set_wgrad_partials(prev_p)
+
+    a, b, c = grad(True), grad(True), grad(False)
+    import ctypes
+    prev = ops.set_precision("bf16")
+    d = ops._make_desc(2, 24, 96, 192, 25, 25, 25, 25, 3, 3, 1, 1, 1, 1, [(96, 24 * 96, 0, 96)], 96, 0, 24 * 192, 0, 0, 0.0)
+    ops.set_precision(prev)
+    assert ops.lib().jaf_conv2d_wgrad_packed_ws_bytes(ctypes.byref(d), 0) > 0      # this layer does take the workspace
+    assert torch.equal(a, b)                                        # fixed summation order
+    assert maxerr(a, c) <= 1e-4 * max(1.0, c.abs().max().item())    # same sums as the atomics, to fp32 rounding
