@@ -375,6 +375,16 @@ int jaf_batchnorm_act_bwd(jaf_stream_t s, const float* dy, const float* x, const
                           float* dbias, int32_t N, int32_t C, int32_t HW, int act, float slope,
                           int training, double* workspace /* 2*C doubles */,
                           int accumulate /* 1: dweight/dbias += (parameter .grad buffers) */);
+/* `parts` (<= 4) equal chunks of the batch, each normalised with its own batch statistics, the running statistics updated chunk after
+ * chunk -- what `parts` successive training-mode calls of the two functions above on the chunks compute (the reference runs its
+ * discriminators on the real and on the generated images in separate calls, train/4.convLSTM_flowpro_interval.py:380-394) -- in ONE launch,
+ * bit-identical to the per-chunk calls.  stats: [parts][2*C].  JAF_EUNSUPPORTED above 65536 elements per channel and chunk. */
+int jaf_batchnorm_act_fwd_split(jaf_stream_t s, const float* x, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                float* running_mean, float* running_var, float* stats, const float* weight, const float* bias,
+                                float* y, int act, float slope, int32_t parts);
+int jaf_batchnorm_act_bwd_split(jaf_stream_t s, const float* dy, const float* x, const float* y, const float* stats,
+                                const float* weight, float* dx, float* dweight, float* dbias, int32_t N, int32_t C, int32_t HW,
+                                int act, float slope, int training, int accumulate, int32_t parts);
 
 /* ------------------------------------------------------------------------------------------
  * Resampling.

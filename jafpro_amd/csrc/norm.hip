@@ -690,6 +690,90 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* x, int N
     }
 }
 
+// `parts` equal chunks of the batch, each normalised with ITS OWN batch statistics, the running statistics updated chunk after chunk
+// (what `parts` successive calls on the chunks compute: the discriminators' real / generated halves, ops._SplitBatchNormActFn), in ONE
+// launch: 256 threads per chunk do exactly what bn_fwd_small_kernel's workgroup does on it -- same per-thread strides, same reduction
+// order, the chunks finalised in order by thread 0 -- so the results are bit-identical to the per-chunk launches.
+template <int V>
+__global__ __launch_bounds__(1024) void bn_fwd_small_parts_kernel(const float* x, int n, int C, int HW, float eps, float momentum,
+                                                                  float* running_mean, float* running_var, float* stats, const float* w,
+                                                                  const float* b, float* y, int act, float slope, int parts) {
+    const int c = blockIdx.x;
+    const int part = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const long poff = (long)part * n * C * HW;
+    double s = 0.0, ss = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = x + poff + ((long)i * C + c) * HW;
+        if (V == 4) {
+            for (int e = tid * 4; e < HW; e += 1024) {
+                const f32x4 v = *(const f32x4*)(p + e);
+                s += (double)((v[0] + v[1]) + (v[2] + v[3]));
+                ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+            }
+        } else {
+            for (int e = tid; e < HW; e += 256) {
+                const double v = (double)p[e];
+                s += v;
+                ss += v * v;
+            }
+        }
+    }
+    __shared__ double rs[4][4], rss[4][4];
+    __shared__ float sh[4][2];
+    s = jaf_wave_sum(s);
+    ss = jaf_wave_sum(ss);
+    if ((tid & 63) == 0) { rs[part][tid >> 6] = s; rss[part][tid >> 6] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < parts; ++k) {
+            const double cnt = (double)n * (double)HW;
+            const double mean = ((rs[k][0] + rs[k][1]) + (rs[k][2] + rs[k][3])) / cnt;
+            double var = ((rss[k][0] + rss[k][1]) + (rss[k][2] + rss[k][3])) / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            sh[k][0] = (float)mean;
+            sh[k][1] = (float)(1.0 / sqrt(var + (double)eps));
+            stats[(long)k * 2 * C + c] = sh[k][0];
+            stats[(long)k * 2 * C + C + c] = sh[k][1];
+            if (running_mean) {
+                const double unbiased = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    __syncthreads();
+    const float mean = sh[part][0], sc = sh[part][1] * w[c], bb = b[c];
+    for (int i = 0; i < n; ++i) {
+        const long base = poff + ((long)i * C + c) * HW;
+        if (V == 4) {
+            for (int e = tid * 4; e < HW; e += 1024) {
+                const f32x4 xv = *(const f32x4*)(x + base + e);
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[k] - mean) * sc + bb, act, slope) + 0.f;
+                *(f32x4*)(y + base + e) = o;
+            }
+        } else {
+            for (int e = tid; e < HW; e += 256) y[base + e] = jaf_act((x[base + e] - mean) * sc + bb, act, slope);
+        }
+    }
+}
+
+extern "C" int jaf_batchnorm_act_fwd_split(jaf_stream_t s_, const float* x, int32_t N, int32_t C, int32_t HW, float eps, float momentum,
+                                           float* running_mean, float* running_var, float* stats, const float* weight,
+                                           const float* bias, float* y, int act, float slope, int32_t parts) {
+    JAF_REQUIRE(x && stats && weight && bias && y && N >= 1 && C >= 1 && HW >= 1 && C <= 65535 && parts >= 1 && parts <= 4 && N % parts == 0);
+    const int n = N / parts;
+    if ((long)n * HW > BN_SMALL_MAX) return JAF_EUNSUPPORTED;
+    if ((HW % 4 == 0) && al16(x, y))
+        hipLaunchKernelGGL(bn_fwd_small_parts_kernel<4>, dim3(C), dim3(256 * parts), 0, (hipStream_t)s_, x, n, C, HW, eps, momentum,
+                           running_mean, running_var, stats, weight, bias, y, act, slope, parts);
+    else
+        hipLaunchKernelGGL(bn_fwd_small_parts_kernel<1>, dim3(C), dim3(256 * parts), 0, (hipStream_t)s_, x, n, C, HW, eps, momentum,
+                           running_mean, running_var, stats, weight, bias, y, act, slope, parts);
+    return jaf_launch_status();
+}
+
 extern "C" int jaf_batchnorm_act_fwd_fused(jaf_stream_t s_, const float* x, int32_t N, int32_t C, int32_t HW, float eps,
                                            float momentum, float* running_mean, float* running_var, float* stats,
                                            int training, double* workspace, const float* weight, const float* bias,
@@ -864,6 +948,102 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* dy, cons
             }
         }
     }
+}
+
+// The backward counterpart for `parts` chunks in one launch (see bn_fwd_small_parts_kernel): bit-identical to bn_bwd_small_kernel
+// called chunk after chunk with accumulate = 1 from the second chunk on.
+template <int V>
+__global__ __launch_bounds__(1024) void bn_bwd_small_parts_kernel(const float* dy, const float* x, const float* y, const float* stats,
+                                                                  const float* w, float* dx, float* dweight, float* dbias, int n, int C,
+                                                                  int HW, int act, float slope, int training, int accumulate, int parts) {
+    const int c = blockIdx.x;
+    const int part = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const long poff = (long)part * n * C * HW;
+    const float mean = stats[(long)part * 2 * C + c], r = stats[(long)part * 2 * C + C + c];
+    double sa = 0.0, sb = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const long base = poff + ((long)i * C + c) * HW;
+        if (V == 4) {
+            for (int e = tid * 4; e < HW; e += 1024) {
+                const f32x4 dv = *(const f32x4*)(dy + base + e), xv = *(const f32x4*)(x + base + e);
+                const f32x4 yv = *(const f32x4*)(y + base + e);
+                float pa = 0.f, pb = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = bn_dz(dv[k], yv[k], act, slope);
+                    pa += dz;
+                    pb += dz * ((xv[k] - mean) * r);
+                }
+                sa += (double)pa;
+                sb += (double)pb;
+            }
+        } else {
+            for (int e = tid; e < HW; e += 256) {
+                const float dz = bn_dz(dy[base + e], y[base + e], act, slope);
+                sa += (double)dz;
+                sb += (double)dz * (double)((x[base + e] - mean) * r);
+            }
+        }
+    }
+    __shared__ double ra[4][4], rb[4][4];
+    __shared__ float sh[4][2];
+    sa = jaf_wave_sum(sa);
+    sb = jaf_wave_sum(sb);
+    if ((tid & 63) == 0) { ra[part][tid >> 6] = sa; rb[part][tid >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float db_run = accumulate ? dbias[c] : 0.f, dw_run = accumulate ? dweight[c] : 0.f;
+        for (int k = 0; k < parts; ++k) {
+            const double a = (ra[k][0] + ra[k][1]) + (ra[k][2] + ra[k][3]), bsum = (rb[k][0] + rb[k][1]) + (rb[k][2] + rb[k][3]);
+            db_run = db_run + (float)a;
+            dw_run = dw_run + (float)bsum;
+            const float inv_cnt = 1.0f / ((float)n * (float)HW);
+            sh[k][0] = training ? (float)a * inv_cnt : 0.f;
+            sh[k][1] = training ? (float)bsum * inv_cnt : 0.f;
+        }
+        dbias[c] = db_run;
+        dweight[c] = dw_run;
+    }
+    __syncthreads();
+    const float db = sh[part][0], dw = sh[part][1], wr = w[c] * r;
+    for (int i = 0; i < n; ++i) {
+        const long base = poff + ((long)i * C + c) * HW;
+        if (V == 4) {
+            for (int e = tid * 4; e < HW; e += 1024) {
+                const f32x4 dv = *(const f32x4*)(dy + base + e), xv = *(const f32x4*)(x + base + e);
+                const f32x4 yv = *(const f32x4*)(y + base + e);
+                f32x4 o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dz = bn_dz(dv[k], yv[k], act, slope);
+                    o[k] = wr * (dz - db - (xv[k] - mean) * r * dw);
+                }
+                *(f32x4*)(dx + base + e) = o;
+            }
+        } else {
+            for (int e = tid; e < HW; e += 256) {
+                const float dz = bn_dz(dy[base + e], y[base + e], act, slope);
+                dx[base + e] = wr * (dz - db - (x[base + e] - mean) * r * dw);
+            }
+        }
+    }
+}
+
+extern "C" int jaf_batchnorm_act_bwd_split(jaf_stream_t s_, const float* dy, const float* x, const float* y, const float* stats,
+                                           const float* weight, float* dx, float* dweight, float* dbias, int32_t N, int32_t C, int32_t HW,
+                                           int act, float slope, int training, int accumulate, int32_t parts) {
+    JAF_REQUIRE(dy && x && y && stats && weight && dx && dweight && dbias && N >= 1 && C >= 1 && HW >= 1 && C <= 65535);
+    JAF_REQUIRE(parts >= 1 && parts <= 4 && N % parts == 0);
+    const int n = N / parts;
+    if ((long)n * HW > BN_SMALL_MAX) return JAF_EUNSUPPORTED;
+    hipStream_t s = (hipStream_t)s_;
+    if ((HW % 4 == 0) && al16(dy, x, y, dx))
+        hipLaunchKernelGGL(bn_bwd_small_parts_kernel<4>, dim3(C), dim3(256 * parts), 0, s, dy, x, y, stats, weight, dx, dweight, dbias, n, C, HW,
+                           act, slope, training, accumulate, parts);
+    else
+        hipLaunchKernelGGL(bn_bwd_small_parts_kernel<1>, dim3(C), dim3(256 * parts), 0, s, dy, x, y, stats, weight, dx, dweight, dbias, n, C, HW,
+                           act, slope, training, accumulate, parts);
+    return jaf_launch_status();
 }
 
 extern "C" int jaf_batchnorm_act_bwd(jaf_stream_t s_, const float* dy, const float* x, const float* y,

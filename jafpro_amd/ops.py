@@ -1518,6 +1518,9 @@ class _BatchNormActFn(Function):
             (dy if has_res else None), None, None
 
 
+_SPLIT_BN_ONE_LAUNCH = os.environ.get("JAF_SPLIT_BN_ONE_LAUNCH", "1") != "0"
+
+
 class _SplitBatchNormActFn(Function):
     """BatchNorm (+ activation) of `parts` equal chunks of the batch, each with ITS OWN batch statistics, the running
     statistics updated chunk after chunk: what `parts` successive calls of the module on the chunks compute (the reference
@@ -1531,9 +1534,14 @@ class _SplitBatchNormActFn(Function):
         n = N // parts
         L = lib()
         stats = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float32)
-        ws = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float64)
         y = torch.empty_like(x)
-        for k in range(parts):
+        # all chunks in ONE launch where a chunk's channel fits a workgroup (bit-identical to the per-chunk calls below)
+        rc = L.jaf_batchnorm_act_fwd_split(_s(), _p(x), N, C, H * W, eps, momentum, _p(running_mean), _p(running_var), _p(stats),
+                                           _p(weight), _p(bias), _p(y), act, slope, parts) if (training and _SPLIT_BN_ONE_LAUNCH) else -2
+        if rc not in (0, -2):
+            check(rc, "jaf_batchnorm_act_fwd_split")
+        ws = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float64) if rc != 0 else None
+        for k in range(parts if rc != 0 else 0):
             check(L.jaf_batchnorm_act_fwd_fused(_s(), _p(x[k * n:(k + 1) * n]), n, C, H * W, eps, momentum, _p(running_mean),
                                                 _p(running_var), _p(stats[k]), 1 if training else 0, _p(ws[k]), _p(weight),
                                                 _p(bias), None, _p(y[k * n:(k + 1) * n]), act, slope),
@@ -1555,8 +1563,12 @@ class _SplitBatchNormActFn(Function):
         inplace = _grad_inplace(weight) and bias is not None and _grad_inplace(bias)
         dw = weight.grad if inplace else torch.empty_like(weight)
         db = bias.grad if inplace else torch.empty_like(weight)
-        ws = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float64)
-        for k in range(parts):
+        rc = lib().jaf_batchnorm_act_bwd_split(_s(), _p(dy), _p(x), _p(y), _p(stats), _p(weight), _p(dx), _p(dw), _p(db), N, C, H * W, act,
+                                               slope, 1 if training else 0, 1 if inplace else 0, parts) if _SPLIT_BN_ONE_LAUNCH else -2
+        if rc not in (0, -2):
+            check(rc, "jaf_batchnorm_act_bwd_split")
+        ws = torch.empty(parts, 2 * C, device=x.device, dtype=torch.float64) if rc != 0 else None
+        for k in range(parts if rc != 0 else 0):
             sl = slice(k * n, (k + 1) * n)
             check(lib().jaf_batchnorm_act_bwd(_s(), _p(dy[sl]), _p(x[sl]), _p(y[sl]), _p(stats[k]), _p(weight), _p(dx[sl]), _p(dw),
                                               _p(db), n, C, H * W, act, slope, 1 if training else 0, _p(ws[k]),

@@ -788,3 +788,29 @@ def test_weight_gradient_partials_are_bit_reproducible():
     assert ops.lib().jaf_conv2d_wgrad_packed_ws_bytes(ctypes.byref(d), 0) > 0      # this layer does take the workspace
     assert torch.equal(a, b)                                        # fixed summation order
     assert maxerr(a, c) <= 1e-4 * max(1.0, c.abs().max().item())    # same sums as the atomics, to fp32 rounding
+
+
+def test_split_batchnorm_one_launch_is_bit_identical_to_per_chunk_calls():
+    """jaf_batchnorm_act_{fwd,bwd}_split: the chunks of a batch (the discriminators' real / generated halves) normalised in ONE launch
+    give the bits of the per-chunk launches: outputs, batch and running statistics, input / weight / bias gradients."""
+    ops = _ops()
+    for (N, C, H, W, parts) in ((16, 64, 64, 64, 2), (6, 24, 9, 7, 3), (8, 256, 4, 4, 2)):
+        x0 = dev(R(1, N, C, H, W))
+        w0, b0 = dev(R(2, C, lo=0.5, hi=1.5)), dev(R(3, C))
+        g = dev(R(4, N, C, H, W))
+        res = []
+        for one in (True, False):
+            prev = ops._SPLIT_BN_ONE_LAUNCH
+            ops._SPLIT_BN_ONE_LAUNCH = one
+            try:
+                x = x0.clone().requires_grad_(True)
+                w, b = w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+                rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+                y = ops.batchnorm_act(x, w, b, rm, rv, True, ops.ACT_LRELU, 0.2, batch_parts=parts)
+                y.backward(g)
+                torch.cuda.synchronize()
+                res.append([t.detach().clone() for t in (y, rm, rv, x.grad, w.grad, b.grad)])
+            finally:
+                ops._SPLIT_BN_ONE_LAUNCH = prev
+        for a, r, name in zip(res[0], res[1], ("y", "running_mean", "running_var", "dx", "dweight", "dbias")):
+            assert torch.equal(a, r), (N, C, H, W, parts, name)
