@@ -596,11 +596,21 @@ int jaf_l1_loss_bwd(jaf_stream_t s, const float* a, const float* b, int64_t n, f
 int jaf_bce_fwd(jaf_stream_t s, const float* p, int32_t n, float target, float* loss);
 int jaf_bce_bwd(jaf_stream_t s, const float* p, int32_t n, float target, const float* dloss,
                 float* dp);
+/* Two BCE terms of one vector (entries [0, n1) against t1, [n1, n) against t2: the discriminators' real / generated halves of one
+ * batched pass, train/4...py:380-394) and their sum in one launch; backward for any of the three incoming gradients (NULL = absent). */
+int jaf_bce_pair_fwd(jaf_stream_t s, const float* p, int32_t n1, int32_t n, float t1, float t2, float* loss1, float* loss2,
+                     float* loss_sum);
+int jaf_bce_pair_bwd(jaf_stream_t s, const float* p, int32_t n1, int32_t n, float t1, float t2, const float* g1, const float* g2,
+                     const float* gsum, float* dp);
 /* nn.Linear (+ act): y[N,O] = act(x[N,I] @ W[O,I]^T + b) (src/networks.py:408-410). */
 int jaf_linear_fwd(jaf_stream_t s, const float* x, const float* w, const float* b, float* y,
                    int32_t N, int32_t I, int32_t O, int act, float slope);
 int jaf_linear_bwd(jaf_stream_t s, const float* dz, const float* x, const float* w, float* dx,
                    float* dw, float* db, int32_t N, int32_t I, int32_t O);
+/* The same with the activation backward folded in (dy and the layer's output y instead of dz) and, with `accumulate`, the parameter
+ * gradients added to the caller's buffers (one add per element, as an accumulation pass would). */
+int jaf_linear_bwd_fused(jaf_stream_t s, const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw,
+                         float* db, int32_t N, int32_t I, int32_t O, int act, float slope, int accumulate);
 /* torch.optim.Adam defaults (betas .9/.999, eps 1e-8, no weight decay, train/4...py:169-175)
  * over one flat parameter buffer. step is the 1-based step count. */
 int jaf_adam_step(jaf_stream_t s, float* p, const float* g, float* m, float* v, int64_t n,

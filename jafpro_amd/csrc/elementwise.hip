@@ -348,6 +348,56 @@ extern "C" int jaf_bce_bwd(jaf_stream_t s, const float* p, int32_t n, float targ
     return jaf_launch_status();
 }
 
+// Two BCE terms of one probability vector -- the first n1 entries against t1, the rest against t2 (the discriminators' real / generated
+// halves of one batched pass, train/4...py:380-394) -- and their sum, in one launch; out = (term 1, term 2, sum).  One wave per term, the
+// arithmetic of bce_fwd_kernel.
+__global__ void bce_pair_fwd_kernel(const float* p, int n1, int n, float t1, float t2, float* o1, float* o2, float* osum) {
+    __shared__ float part[2];
+    const int which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lo = which ? n1 : 0, hi = which ? n : n1;
+    const float target = which ? t2 : t1;
+    float acc = 0.f;
+    for (int i = lo + lane; i < hi; i += 64) {
+        const float lp = fmaxf(__logf(p[i]), -100.f);
+        const float lq = fmaxf(__logf(1.f - p[i]), -100.f);
+        acc += -(target * lp + (1.f - target) * lq);
+    }
+    acc = jaf_wave_sum(acc);
+    if (lane == 0) part[which] = acc / (float)(hi - lo);
+    __syncthreads();
+    if (threadIdx.x == 0) { o1[0] = part[0]; o2[0] = part[1]; osum[0] = part[0] + part[1]; }
+}
+
+extern "C" int jaf_bce_pair_fwd(jaf_stream_t s, const float* p, int32_t n1, int32_t n, float t1, float t2, float* loss1, float* loss2,
+                                float* loss_sum) {
+    JAF_REQUIRE(p && loss1 && loss2 && loss_sum && n1 >= 1 && n > n1);
+    hipLaunchKernelGGL(bce_pair_fwd_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, p, n1, n, t1, t2, loss1, loss2, loss_sum);
+    return jaf_launch_status();
+}
+
+// d(g1 term1 + g2 term2 + gs (term1 + term2)) / dp; g1 / g2 / gs nullable (absent = 0), device scalars.
+__global__ void bce_pair_bwd_kernel(const float* p, int n1, int n, float t1, float t2, const float* g1, const float* g2, const float* gs,
+                                    float* dp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool first = i < n1;
+    const float target = first ? t1 : t2;
+    const float* gp = first ? g1 : g2;
+    const float dl = (gp ? gp[0] : 0.f) + (gs ? gs[0] : 0.f);
+    const float pv = p[i];
+    float g = 0.f;
+    if (__logf(pv) > -100.f) g += -target / pv;
+    if (__logf(1.f - pv) > -100.f) g += (1.f - target) / (1.f - pv);
+    dp[i] = g * dl / (float)(first ? n1 : n - n1);
+}
+
+extern "C" int jaf_bce_pair_bwd(jaf_stream_t s, const float* p, int32_t n1, int32_t n, float t1, float t2, const float* g1, const float* g2,
+                                const float* gsum, float* dp) {
+    JAF_REQUIRE(p && dp && n1 >= 1 && n > n1 && (g1 || g2 || gsum));
+    hipLaunchKernelGGL(bce_pair_bwd_kernel, dim3(jaf_cdiv(n, 64)), dim3(64), 0, (hipStream_t)s, p, n1, n, t1, t2, g1, g2, gsum, dp);
+    return jaf_launch_status();
+}
+
 // ------------------------------------------------------------------ optimiser
 __global__ void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
                             float eps, float bc1, float bc2_sqrt) {

@@ -58,3 +58,52 @@ extern "C" int jaf_linear_bwd(jaf_stream_t s, const float* dz, const float* x, c
     hipLaunchKernelGGL(linear_bwd_kernel, dim3(jaf_ew_grid(work)), dim3(256), 0, (hipStream_t)s, dz, x, w, dx, dw, db, N, I, O);
     return jaf_launch_status();
 }
+
+// The same with the activation backward folded in (dz = dy * act'(y), recomputed where it is used: N x O is a few hundred values) and
+// the parameter gradients ADDED to their buffers when `accumulate`: one launch instead of act_bwd + linear_bwd + two accumulation adds per
+// classifier layer of the discriminators' dependent chain.  Same arithmetic: dz as jaf_act_bwd makes it, one add per gradient element.
+__device__ __forceinline__ float lin_act_grad(float yv, int act, float slope) {
+    switch (act) {
+        case JAF_ACT_LRELU: return yv > 0.f ? 1.f : slope;
+        case JAF_ACT_RELU: return yv > 0.f ? 1.f : 0.f;
+        case JAF_ACT_SIGMOID: return yv * (1.f - yv);
+        case JAF_ACT_TANH: return 1.f - yv * yv;
+        default: return 1.f;
+    }
+}
+
+__global__ void linear_bwd_fused_kernel(const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw, float* db,
+                                        int N, int I, int O, int act, float slope, int accumulate) {
+#pragma clang fp contract(off)      // dz = dy * act'(y) is rounded as jaf_act_bwd stores it (HIP's __fmul_rn is a plain product: it would fuse into the sums)
+    const long gs = (long)gridDim.x * blockDim.x;
+    const long t0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (dx) {
+        for (long e = t0; e < (long)N * I; e += gs) {
+            const int n = (int)(e / I), i = (int)(e % I);
+            float acc = 0.f;
+            for (int o = 0; o < O; ++o) acc = fmaf(__fmul_rn(dy[n * O + o], lin_act_grad(y[n * O + o], act, slope)), w[(long)o * I + i], acc);
+            dx[e] = acc;
+        }
+    }
+    for (long e = t0; e < (long)O * I; e += gs) {
+        const int o = (int)(e / I), i = (int)(e % I);
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc = fmaf(__fmul_rn(dy[n * O + o], lin_act_grad(y[n * O + o], act, slope)), x[(long)n * I + i], acc);
+        dw[e] = accumulate ? dw[e] + acc : acc;
+    }
+    for (long e = t0; e < O; e += gs) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += __fmul_rn(dy[n * O + e], lin_act_grad(y[n * O + e], act, slope));      // (dz rounded as jaf_act_bwd stores it: no contraction into the sum)
+        db[e] = accumulate ? db[e] + acc : acc;
+    }
+}
+
+extern "C" int jaf_linear_bwd_fused(jaf_stream_t s, const float* dy, const float* y, const float* x, const float* w, float* dx, float* dw,
+                                    float* db, int32_t N, int32_t I, int32_t O, int act, float slope, int accumulate) {
+    JAF_REQUIRE(dy && y && x && w && dw && db && N >= 1 && I >= 1 && O >= 1);
+    long work = (long)O * I;
+    if ((long)N * I > work) work = (long)N * I;
+    hipLaunchKernelGGL(linear_bwd_fused_kernel, dim3(jaf_ew_grid(work)), dim3(256), 0, (hipStream_t)s, dy, y, x, w, dx, dw, db, N, I, O, act,
+                       slope, accumulate);
+    return jaf_launch_status();
+}

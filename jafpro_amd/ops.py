@@ -1945,6 +1945,51 @@ def bce_loss(p, target: float):
     return _BCEFn.apply(_chk(p, "bce p"), float(target))
 
 
+class _BCEPairFn(Function):
+    @staticmethod
+    def forward(ctx, p, n1: int, t1: float, t2: float):
+        l1 = torch.empty(1, device=p.device, dtype=torch.float32)
+        l2 = torch.empty(1, device=p.device, dtype=torch.float32)
+        ls = torch.empty(1, device=p.device, dtype=torch.float32)
+        check(lib().jaf_bce_pair_fwd(_s(), _p(p), n1, p.numel(), t1, t2, _p(l1), _p(l2), _p(ls)), "jaf_bce_pair_fwd")
+        ctx.cfg = (n1, t1, t2)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(p)
+        return l1, l2, ls
+
+    @staticmethod
+    def backward(ctx, g1, g2, gs):
+        (p,) = ctx.saved_tensors
+        n1, t1, t2 = ctx.cfg
+        dp = torch.empty_like(p)
+        c = lambda t: None if t is None else _p(_c(t))
+        check(lib().jaf_bce_pair_bwd(_s(), _p(p), n1, p.numel(), t1, t2, c(g1), c(g2), c(gs), _p(dp)), "jaf_bce_pair_bwd")
+        return dp, None, None, None
+
+
+def bce_pair(p, n1: int, t1: float = 1.0, t2: float = 0.0):
+    """(BCE(p[:n1], t1), BCE(p[n1:], t2), their sum) of one probability vector in one launch each way (the discriminators' real and
+    generated halves of a batched pass)."""
+    p = _chk(p, "bce_pair p")
+    if not (1 <= n1 < p.numel()):
+        raise RuntimeError("bce_pair: n1 must split the %d probabilities" % p.numel())
+    return _BCEPairFn.apply(p, int(n1), float(t1), float(t2))
+
+
+_SEED_ONE: dict = {}
+
+
+def backward_from(loss: torch.Tensor) -> None:
+    """loss.backward() with a cached one as the seed gradient (autograd otherwise launches a fill for it on every call)."""
+    one = _SEED_ONE.get(loss.device)
+    if one is None:
+        one = _SEED_ONE[loss.device] = torch.ones(1, device=loss.device, dtype=torch.float32)
+    torch.autograd.backward([loss], [one.view_as(loss)])
+
+
+_LINEAR_FUSED_BWD = os.environ.get("JAF_LINEAR_FUSED_BWD", "1") != "0"
+
+
 class _LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, act, slope):
@@ -1953,12 +1998,16 @@ class _LinearFn(Function):
         y = torch.empty((N, O), device=x.device, dtype=torch.float32)
         check(lib().jaf_linear_fwd(_s(), _p(x), _p(w), _p(b), _p(y), N, I, O, act, slope), "jaf_linear_fwd")
         ctx.cfg = (act, slope)
+        ctx.bias_ref = b
         ctx.save_for_backward(x, w, y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
+        b = ctx.bias_ref
+        if _LINEAR_FUSED_BWD and b is not None and _grad_inplace(w) and _grad_inplace(b):
+            return _LinearFn._backward_fused(ctx, dy)
         act, slope = ctx.cfg
         N, I = x.shape
         O = w.shape[0]
@@ -1974,6 +2023,19 @@ class _LinearFn(Function):
         db = torch.empty(O, device=x.device, dtype=torch.float32)
         check(L.jaf_linear_bwd(_s(), _p(dz), _p(x), _p(w), _p(dx), _p(dw), _p(db), N, I, O), "jaf_linear_bwd")
         return dx, dw, db, None, None
+
+    @staticmethod
+    def _backward_fused(ctx, dy):
+        # activation backward inside the kernel, parameter gradients added to their .grad buffers: one launch
+        x, w, y = ctx.saved_tensors
+        act, slope = ctx.cfg
+        N, I = x.shape
+        O = w.shape[0]
+        b = ctx.bias_ref
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        check(lib().jaf_linear_bwd_fused(_s(), _p(_c(dy)), _p(y), _p(x), _p(w), _p(dx), _p(w.grad), _p(b.grad), N, I, O, act, slope, 1),
+              "jaf_linear_bwd_fused")
+        return dx, None, None, None, None
 
 
 def linear(x, w, b, act=ACT_NONE, slope=0.0):

@@ -125,6 +125,8 @@ PREP_AT = os.environ.get("JAF_PREP_AT", "d")
 D_BATCHED = os.environ.get("JAF_D_BATCHED", "1") == "1"
 # the VGG + L1 loss and its gradient w.r.t. the generated frame on side stream 3, beside the discriminator phase
 VGG_SIDE = os.environ.get("JAF_VGG_SIDE", "1") != "0"
+# the two BCE terms of a batched discriminator pass (and their sum) in one launch each way; 0: two bce_loss calls on slices
+BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -430,10 +432,16 @@ class Stage4Trainer:
             # real and generated crops through the face discriminator as ONE batch of 2n (see the image discriminator below)
             nfc = face_real.shape[0]
             pf = M.F_Discriminator([torch.cat([face_real, face_pred_d]), torch.cat([face_IUV, face_IUV])], batch_parts=2)
-            F_errD_real = ops.bce_loss(pf[:nfc], 1.0)
-            F_errD_fake = ops.bce_loss(pf[nfc:], 0.0)
-            fsum = F_errD_real + F_errD_fake
-            (fsum if fw == 1.0 else fsum * fw).backward()
+            if BCE_PAIR:        # both terms and their sum in one launch each way, seeded with a cached one (ops.bce_pair)
+                F_errD_real, F_errD_fake, fsum = ops.bce_pair(pf, nfc, 1.0, 0.0)
+            else:
+                F_errD_real = ops.bce_loss(pf[:nfc], 1.0)
+                F_errD_fake = ops.bce_loss(pf[nfc:], 0.0)
+                fsum = F_errD_real + F_errD_fake
+            if fw == 1.0 and BCE_PAIR:
+                ops.backward_from(fsum)
+            else:
+                (fsum if fw == 1.0 else fsum * fw).backward()
         elif face_pred is not None:
             F_errD_real = ops.bce_loss(M.F_Discriminator([face_real, face_IUV]), 1.0)
             (F_errD_real if fw == 1.0 else F_errD_real * fw).backward()
@@ -459,9 +467,13 @@ class Stage4Trainer:
         for _ in range(3):
             if D_BATCHED:
                 pd = M.discriminator(d_in, batch_parts=2)
-                errD_real = ops.bce_loss(pd[:nb_], 1.0)
-                errD_fake = ops.bce_loss(pd[nb_:], 0.0)
-                (errD_real + errD_fake).backward()
+                if BCE_PAIR:
+                    errD_real, errD_fake, dsum = ops.bce_pair(pd, nb_, 1.0, 0.0)
+                    ops.backward_from(dsum)
+                else:
+                    errD_real = ops.bce_loss(pd[:nb_], 1.0)
+                    errD_fake = ops.bce_loss(pd[nb_:], 0.0)
+                    (errD_real + errD_fake).backward()
             else:
                 errD_real = ops.bce_loss(M.discriminator([target_d, src0_d]), 1.0)
                 errD_real.backward()

@@ -814,3 +814,36 @@ def test_split_batchnorm_one_launch_is_bit_identical_to_per_chunk_calls():
                 ops._SPLIT_BN_ONE_LAUNCH = prev
         for a, r, name in zip(res[0], res[1], ("y", "running_mean", "running_var", "dx", "dweight", "dbias")):
             assert torch.equal(a, r), (N, C, H, W, parts, name)
+
+
+def test_bce_pair_and_fused_linear_backward_equal_the_separate_launches():
+    """ops.bce_pair (two BCE terms of one vector + their sum, one launch each way) against two ops.bce_loss calls on slices, and the
+    classifier's fused backward (activation backward + in-place parameter gradients) against act_bwd + linear_bwd + accumulation: same bits."""
+    ops = _ops()
+    x0 = dev(R(1, 16, 300))
+    w0, b0 = dev(R(2, 100, 300, lo=-0.1, hi=0.1)), dev(R(3, 100, lo=-0.1, hi=0.1))
+    w1, b1 = dev(R(4, 1, 100, lo=-0.3, hi=0.3)), dev(R(5, 1))
+    res = []
+    for fused in (True, False):
+        prev = ops._LINEAR_FUSED_BWD
+        ops._LINEAR_FUSED_BWD = fused
+        try:
+            ps = [t.clone().requires_grad_(True) for t in (w0, b0, w1, b1)]
+            for t in ps:
+                t.grad = torch.full_like(t, 0.25)            # the trainers' gradients live in pre-existing buffers
+            x = x0.clone().requires_grad_(True)
+            h = ops.linear(x, ps[0], ps[1], ops.ACT_LRELU, 0.2)
+            p = ops.linear(h, ps[2], ps[3], ops.ACT_SIGMOID, 0.0)
+            if fused:
+                l1, l2, ls = ops.bce_pair(p, 8, 1.0, 0.0)
+                ops.backward_from(ls)
+            else:
+                l1, l2 = ops.bce_loss(p[:8], 1.0), ops.bce_loss(p[8:], 0.0)
+                ls = l1 + l2
+                ls.backward()
+            torch.cuda.synchronize()
+            res.append([t.detach().clone() for t in (l1, l2, ls, x.grad, ps[0].grad, ps[1].grad, ps[2].grad, ps[3].grad)])
+        finally:
+            ops._LINEAR_FUSED_BWD = prev
+    for a, r, name in zip(res[0], res[1], ("real", "fake", "sum", "dx", "dw0", "db0", "dw1", "db1")):
+        assert torch.equal(a, r), (name, (a - r).abs().max().item())
