@@ -622,6 +622,16 @@ extern "C" int jaf_batchnorm_act_fwd(jaf_stream_t s, const float* x, const float
 // takes the statistics and applies them, the second pass over its <= 256 KB coming from L2.  Same fp64 sums and the same
 // finalisation arithmetic as the three-kernel path.
 #define BN_SMALL_MAX 65536      // elements per channel (N * HW)
+// The 16-byte walk of the small kernels: a channel's n x (HW / 4) float4 of a chunk as ONE index space (image = q / hw4), thread t takes
+// q = t, t + 256, ... and keeps FOUR loads in flight -- with one workgroup per channel the kernels are latency chains (the per-image loop
+// they replace left 3/4 of the lanes idle on the 8 x 8 .. 16 x 16 maps and issued one load at a time on the 64 x 64 ones).  Every small
+// kernel walks this way, so the one-launch split form and the per-chunk form stay bit-identical.
+struct BnWalk { int hw4, tot4; float inv; };
+__device__ __forceinline__ BnWalk bn_walk(int n, int HW) { BnWalk w; w.hw4 = HW >> 2; w.tot4 = n * w.hw4; w.inv = 1.0f / (float)w.hw4; return w; }
+__device__ __forceinline__ long bn_off4(const BnWalk& w, int q, int C, int HW) {
+    const int i = (int)(((float)q + 0.5f) * w.inv);
+    return ((long)i * C) * HW + (long)(q - i * w.hw4) * 4;
+}
 template <int V>
 __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* x, int N, int C, int HW, float eps, float momentum,
                                                            float* running_mean, float* running_var, float* stats,
@@ -629,15 +639,24 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* x, int N
                                                            int act, float slope) {
     const int c = blockIdx.x;
     double s = 0.0, ss = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float* p = x + ((long)n * C + c) * HW;
-        if (V == 4) {
-            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                const f32x4 v = *(const f32x4*)(p + i);
-                s += (double)((v[0] + v[1]) + (v[2] + v[3]));
-                ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
-            }
-        } else {
+    if (V == 4) {
+        const BnWalk wk = bn_walk(N, HW);
+        const float* p0 = x + (long)c * HW;
+        for (int q0 = threadIdx.x; q0 < wk.tot4; q0 += 1024) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) v[u] = *(const f32x4*)(p0 + bn_off4(wk, q0 + 256 * u, C, HW));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    s += (double)((v[u][0] + v[u][1]) + (v[u][2] + v[u][3]));
+                    ss += (double)((v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]));
+                }
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const float* p = x + ((long)n * C + c) * HW;
             for (int i = threadIdx.x; i < HW; i += 256) {
                 const double v = (double)p[i];
                 s += v;
@@ -668,19 +687,33 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(const float* x, int N
     }
     __syncthreads();
     const float mean = sh[0], sc = sh[1] * w[c], bb = b[c];
-    for (int n = 0; n < N; ++n) {
-        const long base = ((long)n * C + c) * HW;
-        if (V == 4) {
-            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                const f32x4 xv = *(const f32x4*)(x + base + i);
-                f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-                if (residual) rv = *(const f32x4*)(residual + base + i);
-                f32x4 o;
+    if (V == 4) {
+        const BnWalk wk = bn_walk(N, HW);
+        const long c0 = (long)c * HW;
+        for (int q0 = threadIdx.x; q0 < wk.tot4; q0 += 1024) {
+            f32x4 xv[4], rv[4];
+            long off[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[k] - mean) * sc + bb, act, slope) + rv[k];
-                *(f32x4*)(y + base + i) = o;
+            for (int u = 0; u < 4; ++u) {
+                rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (q0 + 256 * u < wk.tot4) {
+                    off[u] = c0 + bn_off4(wk, q0 + 256 * u, C, HW);
+                    xv[u] = *(const f32x4*)(x + off[u]);
+                    if (residual) rv[u] = *(const f32x4*)(residual + off[u]);
+                }
             }
-        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[u][k] - mean) * sc + bb, act, slope) + rv[u][k];
+                    *(f32x4*)(y + off[u]) = o;
+                }
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const long base = ((long)n * C + c) * HW;
             for (int i = threadIdx.x; i < HW; i += 256) {
                 float v = jaf_act((x[base + i] - mean) * sc + bb, act, slope);
                 if (residual) v += residual[base + i];
@@ -702,15 +735,24 @@ __global__ __launch_bounds__(1024) void bn_fwd_small_parts_kernel(const float* x
     const int part = threadIdx.x >> 8, tid = threadIdx.x & 255;
     const long poff = (long)part * n * C * HW;
     double s = 0.0, ss = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const float* p = x + poff + ((long)i * C + c) * HW;
-        if (V == 4) {
-            for (int e = tid * 4; e < HW; e += 1024) {
-                const f32x4 v = *(const f32x4*)(p + e);
-                s += (double)((v[0] + v[1]) + (v[2] + v[3]));
-                ss += (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
-            }
-        } else {
+    if (V == 4) {
+        const BnWalk wk = bn_walk(n, HW);
+        const float* p0 = x + poff + (long)c * HW;
+        for (int q0 = tid; q0 < wk.tot4; q0 += 1024) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) v[u] = *(const f32x4*)(p0 + bn_off4(wk, q0 + 256 * u, C, HW));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    s += (double)((v[u][0] + v[u][1]) + (v[u][2] + v[u][3]));
+                    ss += (double)((v[u][0] * v[u][0] + v[u][1] * v[u][1]) + (v[u][2] * v[u][2] + v[u][3] * v[u][3]));
+                }
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const float* p = x + poff + ((long)i * C + c) * HW;
             for (int e = tid; e < HW; e += 256) {
                 const double v = (double)p[e];
                 s += v;
@@ -743,17 +785,30 @@ __global__ __launch_bounds__(1024) void bn_fwd_small_parts_kernel(const float* x
     }
     __syncthreads();
     const float mean = sh[part][0], sc = sh[part][1] * w[c], bb = b[c];
-    for (int i = 0; i < n; ++i) {
-        const long base = poff + ((long)i * C + c) * HW;
-        if (V == 4) {
-            for (int e = tid * 4; e < HW; e += 1024) {
-                const f32x4 xv = *(const f32x4*)(x + base + e);
-                f32x4 o;
+    if (V == 4) {
+        const BnWalk wk = bn_walk(n, HW);
+        const long c0 = poff + (long)c * HW;
+        for (int q0 = tid; q0 < wk.tot4; q0 += 1024) {
+            f32x4 xv[4];
+            long off[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[k] - mean) * sc + bb, act, slope) + 0.f;
-                *(f32x4*)(y + base + e) = o;
-            }
-        } else {
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    off[u] = c0 + bn_off4(wk, q0 + 256 * u, C, HW);
+                    xv[u] = *(const f32x4*)(x + off[u]);
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) o[k] = jaf_act((xv[u][k] - mean) * sc + bb, act, slope) + 0.f;
+                    *(f32x4*)(y + off[u]) = o;
+                }
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const long base = poff + ((long)i * C + c) * HW;
             for (int e = tid; e < HW; e += 256) y[base + e] = jaf_act((x[base + e] - mean) * sc + bb, act, slope);
         }
     }
@@ -887,23 +942,34 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* dy, cons
     const int c = blockIdx.x;
     const float mean = stats[c], r = stats[C + c];
     double sa = 0.0, sb = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const long base = ((long)n * C + c) * HW;
-        if (V == 4) {
-            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                const f32x4 dv = *(const f32x4*)(dy + base + i), xv = *(const f32x4*)(x + base + i);
-                const f32x4 yv = *(const f32x4*)(y + base + i);
-                float pa = 0.f, pb = 0.f;
+    if (V == 4) {
+        const BnWalk wk = bn_walk(N, HW);
+        const long c0 = (long)c * HW;
+        for (int q0 = threadIdx.x; q0 < wk.tot4; q0 += 512) {       // (three operands: two float4 triples in flight)
+            f32x4 dv[2], xv[2], yv[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dz = bn_dz(dv[k], yv[k], act, slope);
-                    pa += dz;
-                    pb += dz * ((xv[k] - mean) * r);
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    const long off = c0 + bn_off4(wk, q0 + 256 * u, C, HW);
+                    dv[u] = *(const f32x4*)(dy + off); xv[u] = *(const f32x4*)(x + off); yv[u] = *(const f32x4*)(y + off);
                 }
-                sa += (double)pa;
-                sb += (double)pb;
-            }
-        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    float pa = 0.f, pb = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = bn_dz(dv[u][k], yv[u][k], act, slope);
+                        pa += dz;
+                        pb += dz * ((xv[u][k] - mean) * r);
+                    }
+                    sa += (double)pa;
+                    sb += (double)pb;
+                }
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const long base = ((long)n * C + c) * HW;
             for (int i = threadIdx.x; i < HW; i += 256) {
                 const float dz = bn_dz(dy[base + i], y[base + i], act, slope);
                 sa += (double)dz;
@@ -927,21 +993,33 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(const float* dy, cons
     }
     __syncthreads();
     const float db = sh[0], dw = sh[1], wr = w[c] * r;
-    for (int n = 0; n < N; ++n) {
-        const long base = ((long)n * C + c) * HW;
-        if (V == 4) {
-            for (int i = threadIdx.x * 4; i < HW; i += 1024) {
-                const f32x4 dv = *(const f32x4*)(dy + base + i), xv = *(const f32x4*)(x + base + i);
-                const f32x4 yv = *(const f32x4*)(y + base + i);
-                f32x4 o;
+    if (V == 4) {
+        const BnWalk wk = bn_walk(N, HW);
+        const long c0 = (long)c * HW;
+        for (int q0 = threadIdx.x; q0 < wk.tot4; q0 += 512) {
+            f32x4 dv[2], xv[2], yv[2];
+            long off[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dz = bn_dz(dv[k], yv[k], act, slope);
-                    o[k] = wr * (dz - db - (xv[k] - mean) * r * dw);
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    off[u] = c0 + bn_off4(wk, q0 + 256 * u, C, HW);
+                    dv[u] = *(const f32x4*)(dy + off[u]); xv[u] = *(const f32x4*)(x + off[u]); yv[u] = *(const f32x4*)(y + off[u]);
                 }
-                *(f32x4*)(dx + base + i) = o;
-            }
-        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = bn_dz(dv[u][k], yv[u][k], act, slope);
+                        o[k] = wr * (dz - db - (xv[u][k] - mean) * r * dw);
+                    }
+                    *(f32x4*)(dx + off[u]) = o;
+                }
+        }
+    } else {
+        for (int n = 0; n < N; ++n) {
+            const long base = ((long)n * C + c) * HW;
             for (int i = threadIdx.x; i < HW; i += 256) {
                 const float dz = bn_dz(dy[base + i], y[base + i], act, slope);
                 dx[base + i] = wr * (dz - db - (x[base + i] - mean) * r * dw);
@@ -961,23 +1039,34 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_parts_kernel(const float* d
     const long poff = (long)part * n * C * HW;
     const float mean = stats[(long)part * 2 * C + c], r = stats[(long)part * 2 * C + C + c];
     double sa = 0.0, sb = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const long base = poff + ((long)i * C + c) * HW;
-        if (V == 4) {
-            for (int e = tid * 4; e < HW; e += 1024) {
-                const f32x4 dv = *(const f32x4*)(dy + base + e), xv = *(const f32x4*)(x + base + e);
-                const f32x4 yv = *(const f32x4*)(y + base + e);
-                float pa = 0.f, pb = 0.f;
+    if (V == 4) {
+        const BnWalk wk = bn_walk(n, HW);
+        const long c0 = poff + (long)c * HW;
+        for (int q0 = tid; q0 < wk.tot4; q0 += 512) {
+            f32x4 dv[2], xv[2], yv[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dz = bn_dz(dv[k], yv[k], act, slope);
-                    pa += dz;
-                    pb += dz * ((xv[k] - mean) * r);
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    const long off = c0 + bn_off4(wk, q0 + 256 * u, C, HW);
+                    dv[u] = *(const f32x4*)(dy + off); xv[u] = *(const f32x4*)(x + off); yv[u] = *(const f32x4*)(y + off);
                 }
-                sa += (double)pa;
-                sb += (double)pb;
-            }
-        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    float pa = 0.f, pb = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = bn_dz(dv[u][k], yv[u][k], act, slope);
+                        pa += dz;
+                        pb += dz * ((xv[u][k] - mean) * r);
+                    }
+                    sa += (double)pa;
+                    sb += (double)pb;
+                }
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const long base = poff + ((long)i * C + c) * HW;
             for (int e = tid; e < HW; e += 256) {
                 const float dz = bn_dz(dy[base + e], y[base + e], act, slope);
                 sa += (double)dz;
@@ -1006,21 +1095,33 @@ __global__ __launch_bounds__(1024) void bn_bwd_small_parts_kernel(const float* d
     }
     __syncthreads();
     const float db = sh[part][0], dw = sh[part][1], wr = w[c] * r;
-    for (int i = 0; i < n; ++i) {
-        const long base = poff + ((long)i * C + c) * HW;
-        if (V == 4) {
-            for (int e = tid * 4; e < HW; e += 1024) {
-                const f32x4 dv = *(const f32x4*)(dy + base + e), xv = *(const f32x4*)(x + base + e);
-                const f32x4 yv = *(const f32x4*)(y + base + e);
-                f32x4 o;
+    if (V == 4) {
+        const BnWalk wk = bn_walk(n, HW);
+        const long c0 = poff + (long)c * HW;
+        for (int q0 = tid; q0 < wk.tot4; q0 += 512) {
+            f32x4 dv[2], xv[2], yv[2];
+            long off[2];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float dz = bn_dz(dv[k], yv[k], act, slope);
-                    o[k] = wr * (dz - db - (xv[k] - mean) * r * dw);
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    off[u] = c0 + bn_off4(wk, q0 + 256 * u, C, HW);
+                    dv[u] = *(const f32x4*)(dy + off[u]); xv[u] = *(const f32x4*)(x + off[u]); yv[u] = *(const f32x4*)(y + off[u]);
                 }
-                *(f32x4*)(dx + base + e) = o;
-            }
-        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (q0 + 256 * u < wk.tot4) {
+                    f32x4 o;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dz = bn_dz(dv[u][k], yv[u][k], act, slope);
+                        o[k] = wr * (dz - db - (xv[u][k] - mean) * r * dw);
+                    }
+                    *(f32x4*)(dx + off[u]) = o;
+                }
+        }
+    } else {
+        for (int i = 0; i < n; ++i) {
+            const long base = poff + ((long)i * C + c) * HW;
             for (int e = tid; e < HW; e += 256) {
                 const float dz = bn_dz(dy[base + e], y[base + e], act, slope);
                 dx[base + e] = wr * (dz - db - (x[base + e] - mean) * r * dw);
