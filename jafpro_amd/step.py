@@ -62,8 +62,13 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
-    def adam(self, lr: float):
-        ops.join_wgrad_stream()         # weight gradients may have been written on the side stream
+    def adam(self, lr: float, done=None):
+        # weight gradients may have been written on the side stream: wait for all of it, or -- `done`: an event recorded on that stream
+        # behind this module's last weight-gradient launch -- for this module's share only
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        else:
+            ops.join_wgrad_stream()
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params, refresh=True,
                       state=self.dev_state if _CAPTURE["on"] else None)
@@ -127,6 +132,8 @@ D_BATCHED = os.environ.get("JAF_D_BATCHED", "1") == "1"
 VGG_SIDE = os.environ.get("JAF_VGG_SIDE", "1") != "0"
 # the two BCE terms of a batched discriminator pass (and their sum) in one launch each way; 0: two bce_loss calls on slices
 BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
+# optimiser steps of the modules whose backward has finished, issued under the accumulate net's last weight gradients (train_step)
+EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -509,7 +516,39 @@ class Stage4Trainer:
             ov.finish([(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")])
             self.overlap_order = list(ov.fired)
         else:
+            # Per-module completion marks on the weight-gradient stream: a module is done when the backward pass has produced the
+            # gradient of its INPUT (the hook fires behind the module's last backward node, whose weight gradient is already enqueued).
+            # The modules finish in the order refine, inpaint, accumulate; only the accumulate net's last weight gradients (enc_0's
+            # 5 x 5 runs alone at the very end) are still in flight when the data-gradient chain ends, so the other optimiser steps
+            # and their weight re-packing run under that tail instead of behind it.
+            marks_ = {}
+            hooks = []
+            wst = ops.aux_stream(1) if (WGRAD_STREAM and EARLY_ADAM) else None
+            if wst is not None:
+                def _mark(name):
+                    def hook(_g):
+                        ev = torch.cuda.Event()
+                        ev.record(wst)
+                        marks_[name] = ev
+                        return None
+                    return hook
+                for t, name in ((g["fusion_output"], "flow"), (g["inpaint_warp"], "refine"), (g["masked"], "inpaint")):
+                    if t is not None and t.requires_grad:
+                        hooks.append(t.register_hook(_mark(name)))
             self._generator_backward(total, final, fl if split else None, g_vgg)
+            for h in hooks:
+                h.remove()
+            early = [n for n in ("refine", "inpaint", "flow") if n in marks_]
+            for n in early:
+                self.flat[n].adam(self.lrs[n], done=marks_[n])
+            mark("generator loss backward")
+            for n in ("accu", "inpaint", "refine", "flow"):
+                if n not in early:
+                    self.flat[n].adam(self.lrs[n])
+            mark("generator Adam x4")
+            return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),
+                    "errG": errG.detach(), "F_errD": (F_errD_real + F_errD_fake).detach(), "F_errG": F_errG.detach(),
+                    "final_output": final_d}
         mark("generator loss backward")
         for n in ("accu", "inpaint", "refine", "flow"):
             self.flat[n].adam(self.lrs[n])
