@@ -1,7 +1,4 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for V in "JAF_AUX_PRIO=1" "JAF_AUX_PRIO=" "JAF_CHAIN_PRIORITY=0" "JAF_AUX_PRIO=1" "JAF_AUX_PRIO=" "JAF_CHAIN_PRIORITY=0"; do
-  env $V python bench.py --steps 16 --warmup 4 --no-cpu-baseline --no-config2 --parity-mode-steps 0 --no-roofline > gpurun_out/pr.json 2> gpurun_out/pr.err
-  python -c "
-import json; j=json.load(open('gpurun_out/pr.json')); print('$V: %.2f ms/step (median %.2f)' % (j['ms_per_step'], j['median_ms_per_step']))"
-done
+python -m pytest tests/test_gpu_kernels.py -q -x -k "conv2d" -p no:cacheprovider 2>&1 | tail -2
+for V in "JAF_X=1" "JAFPRO_HIP_LIB=scratch/x/lib_head3.so" "JAF_X=1" "JAFPRO_HIP_LIB=scratch/x/lib_head3.so"; do bash profiles/experiments/ab_w.sh p5_${V%%=*} $V 2>&1 | grep "ms/step\|<1, 5"; done
