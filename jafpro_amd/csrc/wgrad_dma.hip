@@ -509,8 +509,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
         if (iy0 >= 0 && ix0 >= 0 && iy0 + PH <= d.H && ix0 + PW <= d.W) {     // (uniform) the whole patch is inside the image
 #pragma unroll
             for (int j = 0; j < XI; ++j) {
-                jaf_dma16_async(rxa, dstx + NW * j * 1024, x_goff[j] + tbase);
-                if constexpr (SPLIT) jaf_dma16_async(rxa, dstx + a.off_lo + NW * j * 1024, x_goff[j] + tbase + HW * 16);      // (the residual plane follows the hi plane)
+                // (unsigned: a dead slot's out-of-range offset plus the tile base passes 2^31; the buffer offset is a 32-bit unsigned quantity)
+                const unsigned src = (unsigned)x_goff[j] + (unsigned)tbase;
+                jaf_dma16_async(rxa, dstx + NW * j * 1024, (int)src);
+                if constexpr (SPLIT) jaf_dma16_async(rxa, dstx + a.off_lo + NW * j * 1024, (int)(src + (unsigned)(HW * 16)));      // (the residual plane follows the hi plane)
             }
         } else {
 #pragma unroll
