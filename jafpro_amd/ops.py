@@ -623,12 +623,27 @@ def set_wgrad_stream(stream):
     first (the trainer does before every Adam / all-reduce and before it returns).  Returns the previous value."""
     global _WGRAD_STREAM
     prev, _WGRAD_STREAM = _WGRAD_STREAM, stream
+    if stream is not prev:
+        _WGRAD_PENDING[1] = None      # join_wgrad_stream: nobody has joined THIS stream yet
     return prev
 
 
+_WGRAD_PENDING = [False, None]      # [enqueued on the weight-gradient stream since the last join, the stream that joined last]
+_LAZY_JOIN = os.environ.get("JAF_LAZY_JOIN", "1") != "0"
+
+
 def join_wgrad_stream():
-    if _WGRAD_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(_WGRAD_STREAM)
+    """The current stream waits for the weight-gradient stream -- only if anything went onto it since this stream's last join: a
+    wait on an idle side stream is NOT free here (its marker can sit behind another stream's kernels in a shared hardware queue:
+    the trainer's redundant join behind the last optimiser step stalled the main stream 0.85 ms per step)."""
+    if _WGRAD_STREAM is None:
+        return
+    cur = torch.cuda.current_stream()
+    if _LAZY_JOIN and not _WGRAD_PENDING[0] and _WGRAD_PENDING[1] == cur:
+        return
+    cur.wait_stream(_WGRAD_STREAM)
+    _WGRAD_PENDING[0] = False
+    _WGRAD_PENDING[1] = cur
 
 
 class LNStats:
@@ -971,6 +986,7 @@ class _ConvFn(Function):
         if ws is not None and ctx.needs_input_grad[0] and _grad_inplace(weight):
             # weight gradient first, on the side stream: it needs only dz (just made) and the saved input
             ws.wait_stream(torch.cuda.current_stream())
+            _WGRAD_PENDING[0] = True
             _conv_wgrad(ctx, m, weight, srcs, dz, dzp, True, stream=ws)
             for t in (ctx.xp, dzp, dz) + tuple(srcs):
                 if t is not None:
@@ -1301,6 +1317,7 @@ class _ConvLSTMFn(Function):
                 wst = _WGRAD_STREAM if w_inplace else None      # see set_wgrad_stream
                 if wst is not None:
                     wst.wait_stream(torch.cuda.current_stream())
+                    _WGRAD_PENDING[0] = True
                 with torch.cuda.stream(wst if wst is not None else torch.cuda.current_stream()):
                     ev = _PROF.begin() if _PROF is not None else None
                     # (the packed gate gradients are channel-major, 4 c + gate: the kernel permutes the rows of dW)
