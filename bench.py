@@ -162,6 +162,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if world > 1 or os.environ.get("JAF_BENCH_ONE_RANK_GROUP") == "1":
+        from jafpro_amd.dist import limit_hw_queues
+        limit_hw_queues()           # RCCL's own hardware queue on top of the step's five oversubscribes the GPU's (dist.limit_hw_queues)
     if args.cpu_baseline_only:
         # child process of the default run (below): the CPU oracle alone, one JSON line
         from jafpro_amd import synth as _synth
@@ -196,6 +199,16 @@ def main():
             dist.init_process_group(backend)
         from jafpro_amd.dist import GradReducer
         reducer = GradReducer()
+    elif os.environ.get("JAF_BENCH_ONE_RANK_GROUP") == "1":
+        # experiment hook (profiles/experiments): the N>1 step -- gradient exchange started from inside backward, the joins of the
+        # weight-gradient stream in front of every message, RCCL's own stream next to the step's side streams -- on the one GPU
+        # of a gpurun box, with a process group of ONE rank.  The messages move nothing; what shows is the cost of the control flow.
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port_ = s_.getsockname()[1]; s_.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(port_))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", dev_index))
+        from jafpro_amd.dist import GradReducer
+        reducer = GradReducer(skip_single=False)
 
     from jafpro_amd import ops, synth
     from jafpro_amd.step import Stage4Trainer, _to_dev
@@ -408,6 +421,8 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.barrier()              # ranks > 0 wait here while rank 0 takes its roofline step
+        dist.destroy_process_group()
+    elif dist.is_initialized():
         dist.destroy_process_group()
 
 

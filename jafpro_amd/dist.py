@@ -16,6 +16,20 @@ import torch
 import torch.distributed as dist
 
 
+def limit_hw_queues(n: int = 3) -> bool:
+    """Call BEFORE the process touches the GPU when it will also run RCCL.  HIP gives a process up to GPU_MAX_HW_QUEUES (default 4)
+    hardware queues per stream priority; the step's side streams use the 4 normal-priority ones plus 1 high-priority queue for the
+    dependent chain, and RCCL brings one more of its own.  Six queues oversubscribe the hardware queues of an MI355X and the step
+    runs 50 % slower (measured with a one-rank group, `profiles/experiments/round4_x4.log`: 54 -> 81 ms; the same 79-80 ms that
+    GPU_MAX_HW_QUEUES=5 alone produces); three normal-priority queues bring it back to 56.8 ms.  Returns False (and changes
+    nothing) when the variable is already set by the user or HIP is already initialised."""
+    import os
+    if "GPU_MAX_HW_QUEUES" in os.environ or torch.cuda.is_initialized():
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
+
+
 class GradReducer:
     def __init__(self, group=None, bucket_bytes: int = 64 << 20, skip_single: bool = True):
         if not dist.is_initialized():
@@ -86,14 +100,34 @@ class BackwardOverlap:
     node as its data gradient), so the module's flat gradient buffer is final and its messages can
     travel while the modules further upstream are still being differentiated.  `finish` starts whatever
     has not fired (modules whose input carries no gradient), waits for everything and takes the means.
-    Message order is the reverse graph order on every rank, so ranks issue identical collective sequences."""
+    Message order is the reverse graph order on every rank, so ranks issue identical collective sequences.
 
-    def __init__(self, reducer: GradReducer, before_begin=None):
+    Gradients written on a side stream (ops.set_wgrad_stream): either `before_begin` joins that stream into the
+    current one before a module's messages are issued (the dependent chain then stalls behind the weight-gradient
+    backlog at every module boundary), or -- `issue_stream`: a callable returning that side stream AFTER making it
+    wait for the current stream, or None -- the messages are issued FROM the side stream: RCCL's stream then waits
+    for the module's weight gradients and for the chain up to the hook, and the chain itself does not wait at all.
+    `finish(rest, each=f)` waits module by module in message order and calls f(name) as soon as that module's
+    means are final (the trainer's optimiser step: it runs beside the messages still travelling)."""
+
+    def __init__(self, reducer: GradReducer, before_begin=None, issue_stream=None):
         self.red = reducer
         self.before_begin = before_begin      # e.g. ops.join_wgrad_stream: gradients written on another stream
-        self.works = []
+        self.issue_stream = issue_stream      # e.g. ops.wgrad_stream_after_current
+        self.works = {}                       # name -> handles of its messages
         self.fired: List[str] = []
         self._hooks = []
+
+    def _begin(self, name: str, buffers) -> None:
+        self.fired.append(name)
+        st = self.issue_stream() if self.issue_stream is not None else None
+        if st is not None:
+            with torch.cuda.stream(st):
+                self.works[name] = self.red.begin(buffers)
+            return
+        if self.before_begin is not None:
+            self.before_begin()
+        self.works[name] = self.red.begin(buffers)
 
     def watch(self, x: torch.Tensor, name: str, buffers: Sequence[torch.Tensor]) -> None:
         if x is None or not x.requires_grad:
@@ -101,26 +135,23 @@ class BackwardOverlap:
 
         def hook(_grad, name=name, buffers=buffers):
             if name not in self.fired:
-                self.fired.append(name)
-                if self.before_begin is not None:
-                    self.before_begin()
-                self.works += self.red.begin(buffers)
+                self._begin(name, buffers)
             return None
 
         self._hooks.append(x.register_hook(hook))
 
-    def finish(self, rest: Sequence[Tuple[str, Sequence[torch.Tensor]]]) -> None:
+    def finish(self, rest: Sequence[Tuple[str, Sequence[torch.Tensor]]], each=None) -> None:
         for name, buffers in rest:
             if name not in self.fired:
-                self.fired.append(name)
-                if self.before_begin is not None:
-                    self.before_begin()
-                self.works += self.red.begin(buffers)
+                self._begin(name, buffers)
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        self.red.finish(self.works)
-        self.works = []
+        for name in self.fired:               # message order = completion order on RCCL's stream
+            self.red.finish(self.works.pop(name))
+            if each is not None:
+                each(name)
+        self.works = {}
 
 
 def shard_batch(batch: dict, rank: int, world: int) -> dict:

@@ -646,6 +646,18 @@ def join_wgrad_stream():
     _WGRAD_PENDING[1] = cur
 
 
+def wgrad_stream_after_current():
+    """The weight-gradient stream after it has been made to wait for everything enqueued on the current stream so far (None while
+    no such stream is set): work issued on it from here on sees both the weight gradients and the current stream's results up to
+    this point -- where dist.BackwardOverlap issues a module's gradient messages, so that the current stream itself never waits."""
+    ws = _WGRAD_STREAM
+    if ws is None:
+        return None
+    ws.wait_stream(torch.cuda.current_stream())
+    _WGRAD_PENDING[0] = True
+    return ws
+
+
 class LNStats:
     """Side channel between a convolution and the CRN LayerNorm that follows it (crn_model.ConvBlock): on the
     packed bf16 path the conv epilogue accumulates each image's (sum, sum of squares) into `sums`

@@ -65,7 +65,10 @@ class FlatParams:
     def adam(self, lr: float, done=None):
         # weight gradients may have been written on the side stream: wait for all of it, or -- `done`: an event recorded on that stream
         # behind this module's last weight-gradient launch -- for this module's share only
-        if done is not None:
+        # (done=True: the caller has already ordered the current stream behind this module's gradients)
+        if done is True:
+            pass
+        elif done is not None:
             torch.cuda.current_stream().wait_event(done)
         else:
             ops.join_wgrad_stream()
@@ -134,6 +137,7 @@ VGG_SIDE = os.environ.get("JAF_VGG_SIDE", "1") != "0"
 BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
 # optimiser steps of the modules whose backward has finished, issued under the accumulate net's last weight gradients (train_step)
 EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
+DIST_ISSUE_ON_WGRAD = os.environ.get("JAF_DIST_ISSUE_ON_WGRAD", "1") != "0"     # multi-rank: gradient messages issued from the weight-gradient stream
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -508,12 +512,29 @@ class Stage4Trainer:
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
             # input (reverse graph order), beside the differentiation of the modules upstream of it
-            ov = BackwardOverlap(self.reducer, before_begin=ops.join_wgrad_stream)
+            # The messages are issued FROM the weight-gradient stream (RCCL's stream waits for that module's weight gradients, the
+            # dependent chain does not wait), and every module takes its optimiser step as soon as its own means have arrived, beside
+            # the messages that still travel (JAF_DIST_ISSUE_ON_WGRAD=0: the chain joins the weight-gradient stream before every
+            # module's messages and all four optimiser steps follow the last message).
+            if DIST_ISSUE_ON_WGRAD:
+                ov = BackwardOverlap(self.reducer, issue_stream=ops.wgrad_stream_after_current, before_begin=ops.join_wgrad_stream)
+            else:
+                ov = BackwardOverlap(self.reducer, before_begin=ops.join_wgrad_stream)
             ov.watch(g["fusion_output"], "flow", [self.flat["flow"].grad])
             ov.watch(g["inpaint_warp"], "refine", [self.flat["refine"].grad])
             ov.watch(g["masked"], "inpaint", [self.flat["inpaint"].grad])
             self._generator_backward(total, final, fl if split else None, g_vgg)
-            ov.finish([(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")])
+            rest = [(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")]
+            if DIST_ISSUE_ON_WGRAD:
+                # a module's messages were issued behind its weight gradients, and the chain has waited for the messages: no join needed
+                ov.finish(rest, each=lambda n: self.flat[n].adam(self.lrs[n], done=True))
+                self.overlap_order = list(ov.fired)
+                mark("generator loss backward")
+                mark("generator Adam x4")
+                return {"total_loss": total.detach(), "vgg_l1": loss.detach(), "errD": (errD_real + errD_fake).detach(),
+                        "errG": errG.detach(), "F_errD": (F_errD_real + F_errD_fake).detach(), "F_errG": F_errG.detach(),
+                        "final_output": final_d}
+            ov.finish(rest)
             self.overlap_order = list(ov.fired)
         else:
             # Per-module completion marks on the weight-gradient stream: a module is done when the backward pass has produced the

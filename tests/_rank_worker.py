@@ -23,6 +23,9 @@ def main():
     import torch.distributed as dist
     backend = os.environ.get("JAF_RANK_BACKEND", "gloo")
     dev = rank if backend == "nccl" else 0            # RCCL: one device per rank; gloo: the ranks share device 0
+    if backend == "nccl":
+        from jafpro_amd.dist import limit_hw_queues
+        limit_hw_queues()                             # before the first HIP call, as a multi-rank launcher should (dist.limit_hw_queues)
     torch.cuda.set_device(dev)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev))
