@@ -81,14 +81,20 @@ def _overlap_worker(rank, world, port, out):
     a = m1(x)                       # the input of m1 carries no gradient: m1 is reduced by finish()
     b = m2(a)
     c = m3(b)
-    ov = BackwardOverlap(red)
+    ov = BackwardOverlap(red, issue_stream=lambda: None)      # (no side stream on the CPU: the messages leave from here)
     ov.watch(x, "m1", [flats["m1"]])
     ov.watch(a, "m2", [flats["m2"]])
     ov.watch(b, "m3", [flats["m3"]])
     c.square().mean().backward()
     fired_in_backward = list(ov.fired)
     local = {n: f.clone() for n, f in flats.items()}      # reads race with in-flight messages only for m2/m3 ...
-    ov.finish([("m3", [flats["m3"]]), ("m2", [flats["m2"]]), ("m1", [flats["m1"]])])
+    done_order, done_vals = [], {}
+
+    def each(name):                 # a module's means must be final when its callback runs (the trainer's optimiser step)
+        done_order.append(name)
+        done_vals[name] = flats[name].clone()
+    ov.finish([("m3", [flats["m3"]]), ("m2", [flats["m2"]]), ("m1", [flats["m1"]])], each=each)
+    assert done_order == ["m3", "m2", "m1"] and all(torch.equal(done_vals[n], flats[n]) for n in flats)
     # ... so the reference mean is recomputed from scratch without overlap
     for m in (m1, m2, m3):
         for p in m.parameters():

@@ -107,6 +107,21 @@ def test_shard_batch():
         shard_batch(b, 0, 3)
 
 
+def test_limit_hw_queues_respects_the_user_and_an_initialised_gpu(monkeypatch):
+    """dist.limit_hw_queues: sets GPU_MAX_HW_QUEUES only while it can still take effect (HIP not initialised) and never
+    overrides a value the user exported."""
+    import torch
+    from jafpro_amd.dist import limit_hw_queues
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "7")
+    assert limit_hw_queues() is False and os.environ["GPU_MAX_HW_QUEUES"] == "7"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
+    assert limit_hw_queues() is False and "GPU_MAX_HW_QUEUES" not in os.environ
+    monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
+    assert limit_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "3"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+
+
 def test_product_has_no_oracle_dependency():
     """The product package must never import the oracle (checked on source text)."""
     root = os.path.join(os.path.dirname(__file__), "..", "jafpro_amd")
