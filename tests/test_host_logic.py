@@ -118,7 +118,7 @@ def test_limit_hw_queues_respects_the_user_and_an_initialised_gpu(monkeypatch):
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
     assert limit_hw_queues() is False and "GPU_MAX_HW_QUEUES" not in os.environ
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
-    assert limit_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "3"
+    assert limit_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "2"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
 
 
