@@ -21,9 +21,9 @@ def limit_hw_queues(n: int = 2) -> bool:
     hardware queues per stream priority; the step's side streams use the 4 normal-priority ones plus 1 high-priority queue for the
     dependent chain, and RCCL brings one more of its own.  Six queues oversubscribe the hardware queues of an MI355X and the step
     runs 50 % slower (measured with a one-rank group, `profiles/experiments/round4_x4.log`: 54 -> 81 ms; the same 79-80 ms that
-    GPU_MAX_HW_QUEUES=5 alone produces); three or two normal-priority queues bring it back to 56.8 ms (no difference between the
-    two under the group; two is the default: it leaves room for a second queue of RCCL's at larger world sizes, which a 1-GPU box
-    cannot show).  Returns False (and changes nothing) when the variable is already set by the user or HIP is already initialised."""
+    GPU_MAX_HW_QUEUES=5 alone produces); three normal-priority queues bring it back to 55.9-56.2 ms, two to 57.1-57.4.  Two is the default:
+    it leaves room for a second queue of RCCL's at larger world sizes, which a 1-GPU box cannot show, and one queue too many costs
+    25 ms where one too few costs 1 (export GPU_MAX_HW_QUEUES=3 where the faster setting is known to hold).  Returns False (and changes nothing) when the variable is already set by the user or HIP is already initialised."""
     import os
     if "GPU_MAX_HW_QUEUES" in os.environ or torch.cuda.is_initialized():
         return False
