@@ -10,6 +10,7 @@ background input (:231, passed in as data) -- on grouped device tensors.
 """
 from __future__ import annotations
 
+import collections
 import os
 from typing import Dict, List, Optional, Sequence
 
@@ -138,6 +139,7 @@ BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
 # optimiser steps of the modules whose backward has finished, issued under the accumulate net's last weight gradients (train_step)
 EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
 DIST_ISSUE_ON_WGRAD = os.environ.get("JAF_DIST_ISSUE_ON_WGRAD", "1") != "0"     # multi-rank: gradient messages issued from the weight-gradient stream
+RUN_AHEAD = int(os.environ.get("JAF_RUN_AHEAD", "2"))     # steps the host may have in flight (0: unbounded)
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -291,6 +293,7 @@ class Stage4Trainer:
             "D": FlatParams(models.discriminator), "face": FlatParams(models.F_Discriminator),
         }
         self.reducer = reducer          # jafpro_amd.dist.GradReducer or None (single GPU)
+        self._inflight = collections.deque()      # end-of-step events of the steps the GPU may still be working on (RUN_AHEAD)
         self._prepared: Optional[PreparedClip] = None
         self.phase_mark = None          # optional callable(name): phase boundaries of train_step (profiling)
 
@@ -323,6 +326,16 @@ class Stage4Trainer:
         background CRN) is issued on the side HIP stream right before this clip's generator loss
         backward and is picked up by that next call (`next_prosrc`: that call's propagation source)."""
         # weight-gradient kernels run on their own stream beside the data gradients (ops.set_wgrad_stream)
+        # Bounded run-ahead: the host enqueues a step in about half the time the GPU needs for it, and every step it is ahead keeps
+        # that step's activations alive -- blocks that the side streams have touched cannot be handed out again before the GPU has
+        # passed them, so the caching allocator answers with fresh hipMalloc segments (0.5-6 GB each, ~27 us per MB of HOST time) step
+        # after step: 51 GB reserved after 25 steps at 256 x 256, 113 GB at 512 x 512, and 70-230 ms enqueue spikes that starve the
+        # GPU whenever they hit a step without slack (profiles/experiments/round4_x4.log).  Waiting here for the step before the
+        # previous one keeps at most RUN_AHEAD steps in flight: the reserve stops growing after the first steps and the host still has
+        # a whole step of slack.
+        if RUN_AHEAD > 0 and not _CAPTURE["on"] and not _CAPTURE["settling"]:
+            while len(self._inflight) >= RUN_AHEAD:
+                self._inflight.popleft().synchronize()
         prev_ws = ops.set_wgrad_stream(None if not WGRAD_STREAM else ops.aux_stream(1))
         if not _CAPTURE["on"] and not _CAPTURE["settling"]:
             self._last_graph = None      # an eager step in between: a graph's static hand-over slot no longer matches the sequence
@@ -332,6 +345,10 @@ class Stage4Trainer:
         finally:
             ops.join_wgrad_stream()
             ops.set_wgrad_stream(prev_ws)
+            if RUN_AHEAD > 0 and not _CAPTURE["on"] and not _CAPTURE["settling"]:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._inflight.append(ev)
             if not _CAPTURE["on"]:
                 flush_bn_counters(self.M)
 
