@@ -106,6 +106,12 @@ def test_next_clip_preparation_is_bit_identical():
     out2 = tr.train_step(dbatch)
     assert tr._prepared is None
     assert torch.isfinite(out2["final_output"]).all()
+    # bounded run-ahead (step.RUN_AHEAD): the host never has more than that many steps in flight, so the caching allocator's
+    # reserve stops growing once the first steps have populated it
+    from jafpro_amd import step as step_mod
+    for _ in range(4):
+        tr.train_step(dbatch, next_batch=dbatch)
+        assert 0 < len(tr._inflight) <= step_mod.RUN_AHEAD
 
 
 def test_train_step_with_gradient_overlap_on_one_rank_group():
