@@ -130,6 +130,12 @@ class BackwardOverlap:
             self.before_begin()
         self.works[name] = self.red.begin(buffers)
 
+    def begin_now(self, name: str, buffers: Sequence[torch.Tensor]) -> None:
+        """Issues `name`'s messages right away (a caller that knows by other means that these buffers are final, e.g. a parameter
+        range of a module whose weight gradients have all been enqueued: ops.watch_wgrads)."""
+        if name not in self.fired:
+            self._begin(name, buffers)
+
     def watch(self, x: torch.Tensor, name: str, buffers: Sequence[torch.Tensor]) -> None:
         if x is None or not x.requires_grad:
             return

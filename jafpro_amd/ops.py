@@ -632,6 +632,11 @@ _WGRAD_PENDING = [False, None]      # [enqueued on the weight-gradient stream si
 _LAZY_JOIN = os.environ.get("JAF_LAZY_JOIN", "1") != "0"
 
 
+def wgrad_stream():
+    """The stream set by set_wgrad_stream (None: weight gradients run on the current stream)."""
+    return _WGRAD_STREAM
+
+
 def join_wgrad_stream():
     """The current stream waits for the weight-gradient stream -- only if anything went onto it since this stream's last join: a
     wait on an idle side stream is NOT free here (its marker can sit behind another stream's kernels in a shared hardware queue:
@@ -644,6 +649,26 @@ def join_wgrad_stream():
     cur.wait_stream(_WGRAD_STREAM)
     _WGRAD_PENDING[0] = False
     _WGRAD_PENDING[1] = cur
+
+
+_WGRAD_WATCH = [None]       # (ids of the weights still to come, callback): see watch_wgrads
+
+
+def watch_wgrads(weights, callback=None) -> None:
+    """`callback()` runs on the host right after the LAST of `weights` has had its weight gradient enqueued in this backward pass
+    (each weight once: the convolution / ConvLSTM backward that owns it reports when its launches are out), whatever order the
+    backward pass visits them in.  An event recorded on the weight-gradient stream inside the callback therefore marks 'every
+    gradient of this parameter range is complete'.  watch_wgrads(None) clears a watch that has not fired."""
+    _WGRAD_WATCH[0] = None if not weights else ({id(w) for w in weights}, callback)
+
+
+def _wgrad_enqueued(weight) -> None:
+    w = _WGRAD_WATCH[0]
+    if w is not None and id(weight) in w[0]:
+        w[0].discard(id(weight))
+        if not w[0]:
+            _WGRAD_WATCH[0] = None
+            w[1]()
 
 
 def wgrad_stream_after_current():
@@ -1060,6 +1085,7 @@ class _ConvFn(Function):
                                     1 if inplace else 0), "jaf_channel_sum")
             if inplace:
                 db = None
+        _wgrad_enqueued(weight)
         return (dw, db, None) + tuple(dsrcs)
 
 
@@ -1393,6 +1419,7 @@ class _ConvLSTMFn(Function):
         elif dx is not None and slot is not None:
             slot.buf = dx
             SLOT_STATS["first"] += 1
+        _wgrad_enqueued(weight)
         return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0, None, None, None
 
 

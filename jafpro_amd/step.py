@@ -56,6 +56,7 @@ class FlatParams:
             p.grad = self.grad[off:off + n].view(p.shape)
             off += sz
         self.params = ps
+        self._offs = None
         self.step_count = 0
         self.dev_state = None           # fp32 [4]: the step count on the device (graph-captured steps, see GraphedTrainStep)
         ops.invalidate_packed_weights()
@@ -76,6 +77,28 @@ class FlatParams:
         self.step_count += 1
         ops.adam_step(self.flat, self.grad, self.m, self.v, lr, self.step_count, params=self.params, refresh=True,
                       state=self.dev_state if _CAPTURE["on"] else None)
+
+    def offset(self, i: int) -> int:
+        """Element offset of parameter i in the flat buffers."""
+        if self._offs is None:
+            self._offs = [0]
+            for p in self.params:
+                self._offs.append(self._offs[-1] + (p.numel() + 3) // 4 * 4)
+        return self._offs[i]
+
+    def adam_range(self, lr: float, i0: int, i1: int, done=None, bump: bool = False):
+        """Adam over parameters i0 .. i1-1 only (Adam is element-wise: any partition of the buffer takes the same step).  `bump`:
+        this call opens the module's optimiser step (the other ranges of the same step pass False).  Not for captured steps."""
+        if done is True:
+            pass
+        elif done is not None:
+            torch.cuda.current_stream().wait_event(done)
+        else:
+            ops.join_wgrad_stream()
+        if bump:
+            self.step_count += 1
+        a, b = self.offset(i0), self.offset(i1)
+        ops.adam_step(self.flat[a:b], self.grad[a:b], self.m[a:b], self.v[a:b], lr, self.step_count, params=self.params[i0:i1], refresh=True)
 
     def sync_dev_state(self):
         """Puts the host's step count on the device (before a capture; the captured launches advance it from there)."""
@@ -140,6 +163,7 @@ BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
 EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
 DIST_ISSUE_ON_WGRAD = os.environ.get("JAF_DIST_ISSUE_ON_WGRAD", "1") != "0"     # multi-rank: gradient messages issued from the weight-gradient stream
 RUN_AHEAD = int(os.environ.get("JAF_RUN_AHEAD", "2"))     # steps the host may have in flight (0: unbounded)
+ACCU_SPLIT = os.environ.get("JAF_ACCU_SPLIT", "1") != "0"     # multi-rank: the accumulate net's gradient message and optimiser step in two parameter ranges
 
 
 def _side_stream(device=None, which: int = 0) -> "torch.cuda.Stream":
@@ -294,6 +318,9 @@ class Stage4Trainer:
         }
         self.reducer = reducer          # jafpro_amd.dist.GradReducer or None (single GPU)
         self._inflight = collections.deque()      # end-of-step events of the steps the GPU may still be working on (RUN_AHEAD)
+        # first parameter of the accumulate net's "complete early" range (see _train_step): the fourth ConvLSTM level's weight
+        w4 = getattr(models.Accu_model, "lstm4_w", None)
+        self._accu_split = next((i for i, p in enumerate(self.flat["accu"].params) if p is w4), None) if w4 is not None else None
         self._prepared: Optional[PreparedClip] = None
         self.phase_mark = None          # optional callable(name): phase boundaries of train_step (profiling)
 
@@ -540,11 +567,31 @@ class Stage4Trainer:
             ov.watch(g["fusion_output"], "flow", [self.flat["flow"].grad])
             ov.watch(g["inpaint_warp"], "refine", [self.flat["refine"].grad])
             ov.watch(g["masked"], "inpaint", [self.flat["inpaint"].grad])
+            # The accumulate net's message in two parameter ranges: everything from the fourth ConvLSTM level on in parameter order
+            # (levels 4-5 and the decoder: 77 % of its 28 M parameters = 88 of 114 MB) is complete when the backward pass leaves the
+            # fourth level -- ops.watch_wgrads reports the moment -- and travels under the rest of the backward pass (the 200 x 200 and
+            # 100 x 100 levels, enc1..9); only the remaining 26 MB leave behind the end of the backward pass, where nothing hides them.
+            fa = self.flat["accu"]
+            k = self._accu_split if (DIST_ISSUE_ON_WGRAD and ACCU_SPLIT and ops.wgrad_stream() is not None) else None
+            if k is not None:
+                o = fa.offset(k)
+                ops.watch_wgrads([p for p in fa.params[k:] if p.dim() == 4], lambda: ov.begin_now("accu_hi", [fa.grad[o:]]))
             self._generator_backward(total, final, fl if split else None, g_vgg)
-            rest = [(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")]
+            ops.watch_wgrads(None)
+            if "accu_hi" in ov.fired:
+                rest = [(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint")] + [("accu_lo", [fa.grad[:o]])]
+            else:
+                rest = [(n, [self.flat[n].grad]) for n in ("flow", "refine", "inpaint", "accu")]
             if DIST_ISSUE_ON_WGRAD:
                 # a module's messages were issued behind its weight gradients, and the chain has waited for the messages: no join needed
-                ov.finish(rest, each=lambda n: self.flat[n].adam(self.lrs[n], done=True))
+                def _step(n):
+                    if n == "accu_hi":
+                        fa.adam_range(self.lrs["accu"], k, len(fa.params), done=True, bump=True)
+                    elif n == "accu_lo":
+                        fa.adam_range(self.lrs["accu"], 0, k, done=True)
+                    else:
+                        self.flat[n].adam(self.lrs[n], done=True)
+                ov.finish(rest, each=_step)
                 self.overlap_order = list(ov.fired)
                 mark("generator loss backward")
                 mark("generator Adam x4")

@@ -87,6 +87,8 @@ def _overlap_worker(rank, world, port, out):
     ov.watch(b, "m3", [flats["m3"]])
     c.square().mean().backward()
     fired_in_backward = list(ov.fired)
+    ov.begin_now("m1", [flats["m1"]])                    # a caller that knows the buffer is final starts it itself; finish() skips it
+    ov.begin_now("m2", [flats["m2"]])                    # (already on its way: ignored)
     local = {n: f.clone() for n, f in flats.items()}      # reads race with in-flight messages only for m2/m3 ...
     done_order, done_vals = [], {}
 

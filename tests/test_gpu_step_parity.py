@@ -230,7 +230,8 @@ def test_two_rank_trainer_rccl(tmp_path):
 def _check_two_ranks(res, gold, drop_face_rank):
     ix = step_index()
     for r in range(2):
-        assert res[r]["overlap_order"] == ["flow", "refine", "inpaint", "accu"]
+        # (the accumulate net leaves in two parameter ranges: levels 4-5 + decoder from inside its backward pass, the rest behind it)
+        assert res[r]["overlap_order"] == ["flow", "refine", "inpaint", "accu_hi", "accu_lo"]
         err = (res[r]["final_output"] - torch.from_numpy(gold["r%d.final_output" % r])).abs().max().item()
         print("rank %d frame max|diff| %.3e" % (r, err))
         assert err <= 1e-3
