@@ -25,6 +25,7 @@ NPARTS = 24
 ENC_NC = [12, 24, 24, 24, 24, 48, 48, 96, 96]          # src/networks.py:1602
 ENC_K = [5, 3, 3, 3, 3, 3, 3, 3, 3]                     # enc1 is 5x5 pad 2 (:1294)
 ENC_S = [1, 2, 1, 2, 1, 2, 1, 2, 1]
+_DEC_PACKED_OUT = os.environ.get("JAF_DEC_PACKED_OUT", "1") != "0"      # dec4 writes the output convolution's packed image
 _ENC_KEEP_S2 = os.environ.get("JAF_ENC_KEEP_S2", "0") == "1"      # A/B: the (unread) fp32 copies in front of the wide stride-2 layers
 SIZES = [200, 100, 50, 25, 13]
 
@@ -78,6 +79,15 @@ class _GroupedStateDict(nn.Module):
 def _lrelu_conv(x_srcs, w, b, stride=1, pad=1, shared=None, prepacked=None, dst=None, keep_f32=True):
     return ops.conv2d(x_srcs, w, b, stride=stride, pad=pad, act=ACT_LRELU, slope=0.2, groups=NPARTS, shared=shared,
                       prepacked=prepacked, dst=dst, keep_f32=keep_f32)
+
+
+def _dec_out_image(i: int, skip: torch.Tensor, c: int):
+    """The LAST decoder layer (dec4) feeds only the 3-channel output convolution: on the packed bf16 path it writes that
+    convolution's packed input image itself and no fp32 tensor (no packing pass in front of the output convolution, and its data
+    gradient comes back as a packed dz: ops.mark_single_consumer).  None for the other layers (their consumer is a resize)."""
+    if i != 3 or not _DEC_PACKED_OUT or not ops.packed_active():
+        return None
+    return ops.PackedImage(skip.shape[0], NPARTS, c, skip.shape[2], skip.shape[3], skip.device)
 
 
 class _PartEncoderMixin:
@@ -195,11 +205,16 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
         lstm.T = T
         hs = self._encode(x, tap=lstm)
         x = hs[4]
+        img = None
         for i in range(4):            # Upsampler_SE: bilinear(AC=True) to a fixed size, cat skip, conv+lrelu
             skip = hs[3 - i]
             up = ops.resize(x, (skip.shape[2], skip.shape[3]), align_corners=True, lazy=True)    # sampled while dec packs its input
-            x = _lrelu_conv([up, skip], getattr(self, "dec%d_w" % (i + 1)), getattr(self, "dec%d_b" % (i + 1)))
-        return ops.conv2d(x, self.out_w, self.out_b, stride=1, pad=1, act=ACT_NONE, groups=NPARTS)
+            img = _dec_out_image(i, skip, self.DEC_NC[i])
+            x = _lrelu_conv([up, skip], getattr(self, "dec%d_w" % (i + 1)), getattr(self, "dec%d_b" % (i + 1)),
+                            dst=img.slot(0, 0, pad_tail=True) if img is not None else None, keep_f32=img is None)
+        if img is not None:
+            ops.mark_single_consumer(x)
+        return ops.conv2d(x, self.out_w, self.out_b, stride=1, pad=1, act=ACT_NONE, groups=NPARTS, prepacked=img)
 
     def forward(self, x_in):
         """x_in: list[24][T] of (B,3,200,200) -> list[24] of (B,3,200,200)."""
@@ -282,11 +297,16 @@ class UNet_inpainter(_GroupedStateDict, _PartEncoderMixin):
         up9 = ops.resize(feats[4], size, align_corners=True, lazy=True)
         upe = ops.resize(embed, size, align_corners=True, lazy=True)
         x = _lrelu_conv([up9, upe, skip], self.dec1_w, self.dec1_b, shared=[False, True, False])
+        img = None
         for i in range(1, 4):
             skip = feats[3 - i]
             up = ops.resize(x, (skip.shape[2], skip.shape[3]), align_corners=True, lazy=True)
-            x = _lrelu_conv([up, skip], getattr(self, "dec%d_w" % (i + 1)), getattr(self, "dec%d_b" % (i + 1)))
-        return ops.conv2d(x, self.out_w, self.out_b, stride=1, pad=1, act=ACT_NONE, groups=NPARTS)
+            img = _dec_out_image(i, skip, self.DEC_NC[i])
+            x = _lrelu_conv([up, skip], getattr(self, "dec%d_w" % (i + 1)), getattr(self, "dec%d_b" % (i + 1)),
+                            dst=img.slot(0, 0, pad_tail=True) if img is not None else None, keep_f32=img is None)
+        if img is not None:
+            ops.mark_single_consumer(x)
+        return ops.conv2d(x, self.out_w, self.out_b, stride=1, pad=1, act=ACT_NONE, groups=NPARTS, prepacked=img)
 
     def forward(self, texture_list):
         return _as_list(self.forward_grouped(_as_grouped(texture_list).contiguous()))
