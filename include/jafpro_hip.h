@@ -456,6 +456,12 @@ int jaf_part_mask_mul(jaf_stream_t s, const float* tex, const float* masks, cons
 /* list[24] of (B,3,200,200) parts <-> atlas [B,T,3,800,1200] (train/4...py:269-276). */
 int jaf_atlas_to_parts(jaf_stream_t s, const float* atlas, float* parts, int32_t B, int32_t T,
                        int32_t AH, int32_t AW, int32_t PSZ);
+/* The same slicing (train/4...py:269-276) written as the packed input image of the first part-encoder convolution
+ * (src/networks.py:1294 enc1): bf16 [T*B][24][1][PSZ*PSZ][8], channels 3..7 zero; JAF_PREC_BF16X3: hi plane + residual plane.
+ * JAF_EUNSUPPORTED when PSZ or AW is not a multiple of 4 or a pointer is not 16-byte aligned (use jaf_atlas_to_parts +
+ * jaf_conv2d_pack_input then).                                                                                            */
+int jaf_atlas_to_parts_packed(jaf_stream_t s, const float* atlas, void* image, int32_t B, int32_t T, int32_t AH, int32_t AW,
+                              int32_t PSZ, int32_t precision);
 
 /* ------------------------------------------------------------------------------------------
  * Renderer path (src/cal_flow.py:28-35, src/nmr.py:263-278,617-659; NMR kernels

@@ -225,6 +225,59 @@ extern "C" int jaf_atlas_to_parts(jaf_stream_t s, const float* atlas, float* par
     return jaf_launch_status();
 }
 
+// The same slicing straight into the packed bf16 image the first part-encoder convolution reads (csrc/conv_dma.hip layout
+// [image t*B+b][part][1 channel group][y*PSZ+x][8 channels], channels 3..7 zero; split: the residual plane behind the hi plane):
+// the fp32 parts tensor (369 MB at B=8, T=4) is neither written nor read back by a packing pass.
+// grid (x blocks of 4 pixels, rows, B*P) per reference frame.
+__global__ void atlas_to_parts_packed_kernel(const float* __restrict__ atlas, unsigned char* __restrict__ img, int B, int T, int t, int AH,
+                                             int AW, int PSZ, int split) {
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x >= PSZ || y >= PSZ) return;
+    const int pcols = AW / PSZ;
+    const int P = (AH / PSZ) * pcols;
+    const int p = blockIdx.z % P;
+    const int b = blockIdx.z / P;
+    const int ay = (p / pcols) * PSZ + y;
+    const int ax = (p % pcols) * PSZ + x;
+    const float* src = atlas + ((((long)b * T + t) * 3) * AH + ay) * AW + ax;
+    const long plane = (long)AH * AW;
+    const f32x4 c0 = *(const f32x4*)src, c1 = *(const f32x4*)(src + plane), c2 = *(const f32x4*)(src + 2 * plane);
+    const long HW = (long)PSZ * PSZ;
+    unsigned char* dst = img + ((((long)t * B + b) * P + p) * (split ? 2 : 1)) * HW * 16 + ((long)y * PSZ + x) * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const __bf16 h0 = (__bf16)c0[k], h1 = (__bf16)c1[k], h2 = (__bf16)c2[k];
+        const unsigned int w0 = (unsigned int)__builtin_bit_cast(unsigned short, h0) | ((unsigned int)__builtin_bit_cast(unsigned short, h1) << 16);
+        const unsigned int w1 = (unsigned int)__builtin_bit_cast(unsigned short, h2);
+        *(jaf_u32x4*)(dst + k * 16) = (jaf_u32x4){w0, w1, 0u, 0u};
+        if (split) {
+            const __bf16 l0 = (__bf16)(c0[k] - (float)h0), l1 = (__bf16)(c1[k] - (float)h1), l2 = (__bf16)(c2[k] - (float)h2);
+            const unsigned int v0 = (unsigned int)__builtin_bit_cast(unsigned short, l0) | ((unsigned int)__builtin_bit_cast(unsigned short, l1) << 16);
+            const unsigned int v1 = (unsigned int)__builtin_bit_cast(unsigned short, l2);
+            *(jaf_u32x4*)(dst + HW * 16 + k * 16) = (jaf_u32x4){v0, v1, 0u, 0u};
+        }
+    }
+}
+
+extern "C" int jaf_atlas_to_parts_packed(jaf_stream_t s, const float* atlas, void* image, int32_t B, int32_t T, int32_t AH, int32_t AW,
+                                         int32_t PSZ, int32_t precision) {
+    JAF_REQUIRE(atlas && image && B >= 1 && T >= 1 && PSZ >= 1 && AH % PSZ == 0 && AW % PSZ == 0);
+    JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    const long bp = (long)B * (AH / PSZ) * (AW / PSZ);
+    if (bp > 65535) return JAF_EUNSUPPORTED;
+    if (PSZ % 4 || AW % 4 || (((uintptr_t)atlas) & 15) || (((uintptr_t)image) & 15)) return JAF_EUNSUPPORTED;
+    const int wx = PSZ / 4;
+    int tx = 64;
+    while (tx > 8 && (tx >> 1) >= wx) tx >>= 1;
+    const int ty = 256 / tx;
+    const dim3 grid(jaf_cdiv(wx, tx), jaf_cdiv(PSZ, ty), (unsigned)bp);
+    for (int t = 0; t < T; ++t)
+        hipLaunchKernelGGL(atlas_to_parts_packed_kernel, grid, dim3(tx, ty), 0, (hipStream_t)s, atlas, (unsigned char*)image, B, T, t, AH, AW,
+                           PSZ, precision == JAF_PREC_BF16X3 ? 1 : 0);
+    return jaf_launch_status();
+}
+
 // out[b, 3p+c, y, x] = tex[...] * (OR_t used[t] && masks[b,t,ay,ax] != 0)
 // grid (x blocks, row blocks, B*P), block (tx, ty): no per-element index decoding
 __global__ void part_mask_mul_kernel(const float* __restrict__ tex, const float* __restrict__ masks, const int* __restrict__ used,

@@ -103,15 +103,15 @@ class _PartEncoderMixin:
             self._add("enc%d_b" % (i + 1), "Downsampler_list.{p}.enc%d.enconv.0.bias" % (i + 1), b)
             cin = c
 
-    def _encode(self, x, tap=None, skips_feed_one_conv=False):
+    def _encode(self, x, tap=None, skips_feed_one_conv=False, x_image=None):
         """enc1..enc9 -> [x1, x3, x5, x7, x9].  On the packed bf16 path every layer writes its output straight into the
         next layer's packed input image (ops.PackedImage): no separate packing pass between the convolutions.
         `tap(level, x_level, image)` (accumulate: the ConvLSTM of that level) is called as soon as a skip feature exists;
         it receives the image the feature was written into -- for the accumulate network that image is the ConvLSTM's
         [x, h] sequence image, whose x half enc_{i+1} then reads in place -- and returns what to collect for the level."""
         feats = []
-        img_in = None
         packed = ops.packed_active()
+        img_in = x_image if packed else None       # enc1's packed input, when the caller made it (ops.atlas_to_parts_packed)
         for i in range(9):
             k, s = ENC_K[i], ENC_S[i]
             c = ENC_NC[i]
@@ -190,8 +190,9 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
         self._add("out_w", "Upsampler_list.{p}.conv.weight", w)
         self._add("out_b", "Upsampler_list.{p}.conv.bias", b)
 
-    def forward_grouped(self, x: torch.Tensor, T: int) -> torch.Tensor:
-        """x: [T*B, 72, 200, 200] with image index t*B + b  ->  [B, 72, 200, 200]."""
+    def forward_grouped(self, x: torch.Tensor, T: int, x_image=None) -> torch.Tensor:
+        """x: [T*B, 72, 200, 200] with image index t*B + b  ->  [B, 72, 200, 200].  `x_image`: the packed image of x
+        (ops.atlas_to_parts_packed; x is then only its shape)."""
         TB = x.shape[0]
         B = TB // T
 
@@ -203,7 +204,7 @@ class Accumulate_LSTM_no_loss(_GroupedStateDict, _PartEncoderMixin):
                                 groups=NPARTS, return_all=False, seq_image=image, return_state=False)
             return h
         lstm.T = T
-        hs = self._encode(x, tap=lstm)
+        hs = self._encode(x, tap=lstm, x_image=x_image)
         x = hs[4]
         img = None
         for i in range(4):            # Upsampler_SE: bilinear(AC=True) to a fixed size, cat skip, conv+lrelu

@@ -21,7 +21,7 @@ from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, PACK_DG
 
 __all__ = ["set_precision", "get_precision", "conv2d", "convlstm", "layernorm_lrelu", "batchnorm_act", "avg_pool", "resize",
            "reflect_pad", "texture_warp", "grid_sample", "blend", "mul_bcast", "part_mask_mul",
-           "atlas_to_parts", "vgg_preprocess", "l1_loss", "bce_loss", "linear", "adam_step",
+           "atlas_to_parts", "atlas_to_parts_packed", "vgg_preprocess", "l1_loss", "bce_loss", "linear", "adam_step",
            "project_faces", "rasterize_fim_wim", "bc_transform", "axpby", "conv_transpose2d", "ACT_NONE", "ACT_LRELU",
            "ACT_RELU", "ACT_SIGMOID", "ACT_TANH"]
 
@@ -1923,6 +1923,25 @@ def atlas_to_parts(atlas: torch.Tensor, psz: int = 200) -> torch.Tensor:
     out = torch.empty((T * B, P * 3, psz, psz), device=atlas.device, dtype=torch.float32)
     check(lib().jaf_atlas_to_parts(_s(), _p(atlas), _p(out), B, T, AH, AW, psz), "jaf_atlas_to_parts")
     return out
+
+
+def atlas_to_parts_packed(atlas: torch.Tensor, psz: int = 200):
+    """The same slicing as the packed bf16 input image of the first part-encoder convolution: returns (x, image) where `image` is
+    the PackedImage [T*B][24][3 -> 8 channels] and `x` a storage-less [T*B, 72, psz, psz] tensor that only carries the shape
+    (conv2d(..., prepacked=image) reads nothing else).  None while the packed path is off or the geometry is not 16-byte
+    friendly: the caller then takes atlas_to_parts + the packing pass."""
+    _chk(atlas, "atlas")
+    if not packed_active():
+        return None
+    B, T, _, AH, AW = atlas.shape
+    P = (AH // psz) * (AW // psz)
+    img = PackedImage(T * B, P, 3, psz, psz, atlas.device)
+    rc = lib().jaf_atlas_to_parts_packed(_s(), _p(atlas), _p(img.buf), B, T, AH, AW, psz, _PRECISION)
+    if rc == -2:            # JAF_EUNSUPPORTED
+        return None
+    check(rc, "jaf_atlas_to_parts_packed")
+    x = torch.empty_strided((T * B, P * 3, psz, psz), (0, 0, 0, 0), device=atlas.device, dtype=torch.float32)
+    return x, img
 
 
 # --------------------------------------------------------------------------------------------

@@ -162,6 +162,7 @@ BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
 # optimiser steps of the modules whose backward has finished, issued under the accumulate net's last weight gradients (train_step)
 EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
 DIST_ISSUE_ON_WGRAD = os.environ.get("JAF_DIST_ISSUE_ON_WGRAD", "1") != "0"     # multi-rank: gradient messages issued from the weight-gradient stream
+ATLAS_PACKED = os.environ.get("JAF_ATLAS_PACKED", "1") != "0"     # atlas slicing straight into enc1's packed input image
 RUN_AHEAD = int(os.environ.get("JAF_RUN_AHEAD", "2"))     # steps the host may have in flight (0: unbounded)
 ACCU_SPLIT = os.environ.get("JAF_ACCU_SPLIT", "1") != "0"     # multi-rank: the accumulate net's gradient message and optimiser step in two parameter ranges
 
@@ -267,8 +268,10 @@ def generator_forward(M: Stage4Models, b: Dict[str, torch.Tensor], used: Sequenc
         prepared = prepare_clip(M, b, prosrc, with_loss_target, part="renderer" if prepared.tsf is None else "networks", into=prepared)
     bg_output, tsf = prepared.bg_output, prepared.tsf
     tex = b["src_texture_im"] if len(used) == T_all else b["src_texture_im"][:, used].contiguous()
-    x = ops.atlas_to_parts(tex.contiguous())                                    # :269-276
-    accu = M.Accu_model.forward_grouped(x, len(used))                           # :278
+    # :269-276 -- the 24-part slicing writes the first encoder layer's packed input image itself (no fp32 parts tensor, no packing pass)
+    xi = ops.atlas_to_parts_packed(tex.contiguous()) if ATLAS_PACKED else None
+    x, ximg = xi if xi is not None else (ops.atlas_to_parts(tex.contiguous()), None)
+    accu = M.Accu_model.forward_grouped(x, len(used), x_image=ximg)             # :278
     masked = ops.part_mask_mul(accu, b["src_mask_im"].contiguous(), _used_flags(T_all, used, accu.device))   # :283-298
     inpaint = M.inpaint_model.forward_grouped(masked)                           # :300
     inpaint_warp = ops.texture_warp(inpaint, b["tgt_IUV255"], align_corners)    # :309-312

@@ -847,3 +847,26 @@ def test_bce_pair_and_fused_linear_backward_equal_the_separate_launches():
             ops._LINEAR_FUSED_BWD = prev
     for a, r, name in zip(res[0], res[1], ("real", "fake", "sum", "dx", "dw0", "db0", "dw1", "db1")):
         assert torch.equal(a, r), (name, (a - r).abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_atlas_slicing_into_the_packed_image_is_bit_identical(mode):
+    """ops.atlas_to_parts_packed writes enc1's packed input image itself (train/4...py:269-276 + the packing pass of the first
+    part-encoder convolution in one kernel): the accumulate net's output must not change by a bit against
+    atlas_to_parts + jaf_conv2d_pack_input, in both packed arithmetics; off the packed path it declines (None)."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.networks import Accumulate_LSTM_no_loss
+    m = synth.load_synth(Accumulate_LSTM_no_loss(), 21).cuda()
+    atlas = torch.from_numpy(synth.uniform(23, "atlas", (1, 2, 3, 800, 1200))).cuda()
+    prev = ops.set_precision("f32")
+    try:
+        assert ops.atlas_to_parts_packed(atlas) is None
+        ops.set_precision(mode)
+        with torch.no_grad():
+            ref = m.forward_grouped(ops.atlas_to_parts(atlas), 2)
+            x, img = ops.atlas_to_parts_packed(atlas)
+            assert tuple(x.shape) == (2, 72, 200, 200) and img.split == (mode == "bf16x3")
+            out = m.forward_grouped(x, 2, x_image=img)
+        assert torch.equal(out, ref)
+    finally:
+        ops.set_precision(prev)
