@@ -152,7 +152,7 @@ WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradi
 # rasteriser, barycentric flow, flow warp) right before the VGG + GAN loss backward, which it overlaps (north star).
 # "bwd": everything right before the loss backward, where the CRN competes with the backward's own kernels.
 # Measured at B=8: 68.6 vs 70.4 ms/step.
-PREP_AT = os.environ.get("JAF_PREP_AT", "d")
+PREP_AT = os.environ.get("JAF_PREP_AT", "")        # "d" / "b": see Stage4Trainer._prep_at (default: "d" on one GPU, "b" with an active reducer)
 # the discriminators' real and generated passes as one batch with per-half BatchNorm statistics (train_step); 0: two passes
 D_BATCHED = os.environ.get("JAF_D_BATCHED", "1") == "1"
 # the VGG + L1 loss and its gradient w.r.t. the generated frame on side stream 3, beside the discriminator phase
@@ -320,6 +320,10 @@ class Stage4Trainer:
             "D": FlatParams(models.discriminator), "face": FlatParams(models.F_Discriminator),
         }
         self.reducer = reducer          # jafpro_amd.dist.GradReducer or None (single GPU)
+        # where the next clip's preparation is issued: "d" = its networks part (frozen background CRN) beside the discriminator phase and
+        # the renderer part beside the generator backward (best on one GPU); "b" = all of it beside the generator backward -- best when
+        # RCCL shares the process (two hardware queues, dist.limit_hw_queues): 56.8 -> 55.5 ms with a one-rank group (round4_x4.log)
+        self._prep_at = PREP_AT or ("b" if (reducer is not None and reducer.active) else "d")
         self._inflight = collections.deque()      # end-of-step events of the steps the GPU may still be working on (RUN_AHEAD)
         # first parameter of the accumulate net's "complete early" range (see _train_step): the fourth ConvLSTM level's weight
         w4 = getattr(models.Accu_model, "lstm4_w", None)
@@ -483,7 +487,7 @@ class Stage4Trainer:
         else:
             raise RuntimeError("train_step supports image_size 256 (reference) and 512 (config 5), got %d" % M.image_size)
         target_d, src0_d = dview(target), dview(src0)
-        if next_batch is not None and PREP_AT == "d":
+        if next_batch is not None and self._prep_at == "d":
             self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True, part="networks")
         # ---- face discriminator, one update (:362-374)
         if face_pred is not None and D_BATCHED:
@@ -555,7 +559,7 @@ class Stage4Trainer:
         total = loss + 2 * errG.squeeze(0) + 2 * F_errG.squeeze(0)
         if next_batch is not None:      # overlaps with the VGG + GAN loss backward below
             self._prepared = prepare_clip(M, next_batch, next_prosrc, with_loss_target=True,
-                                          part="renderer" if PREP_AT == "d" else "all", into=self._prepared if PREP_AT == "d" else None)
+                                          part="renderer" if self._prep_at == "d" else "all", into=self._prepared if self._prep_at == "d" else None)
         if self.reducer is not None and self.reducer.active:
             # each module's gradient messages leave as soon as the backward pass has passed the module's
             # input (reverse graph order), beside the differentiation of the modules upstream of it
