@@ -26,6 +26,7 @@ ENC_NC = [12, 24, 24, 24, 24, 48, 48, 96, 96]          # src/networks.py:1602
 ENC_K = [5, 3, 3, 3, 3, 3, 3, 3, 3]                     # enc1 is 5x5 pad 2 (:1294)
 ENC_S = [1, 2, 1, 2, 1, 2, 1, 2, 1]
 _DEC_PACKED_OUT = os.environ.get("JAF_DEC_PACKED_OUT", "1") != "0"      # dec4 writes the output convolution's packed image
+_VGG_SKIP_F32 = os.environ.get("JAF_VGG_SKIP_F32", "1") != "0"      # untapped VGG conv -> conv layers write no fp32 output
 _ENC_KEEP_S2 = os.environ.get("JAF_ENC_KEEP_S2", "0") == "1"      # A/B: the (unread) fp32 copies in front of the wide stride-2 layers
 SIZES = [200, 100, 50, 25, 13]
 
@@ -508,8 +509,11 @@ class VGG19_CRN(nn.Module):
                 img_out = None
                 if nxt_is_conv and ops.packed_active():
                     img_out = ops.PackedImage(x.shape[0], 1, conv.weight.shape[0], x.shape[2], x.shape[3], x.device)
+                # ... and an untapped layer's fp32 output has no reader at all (the next convolution reads the image, the backward pass
+                # takes the ReLU's sign from it): 7 layers, 307 MB per pass over 8 frames, not written
                 x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=1, act=ACT_RELU, prepacked=img_in,
-                               dst=img_out.slot(0, 0, pad_tail=True) if img_out is not None else None)
+                               dst=img_out.slot(0, 0, pad_tail=True) if img_out is not None else None,
+                               keep_f32=img_out is None or idx in self.TAPS or not _VGG_SKIP_F32)
                 img_in = img_out
                 if idx in self.TAPS:
                     feats.append(x)
