@@ -122,6 +122,41 @@ def test_limit_hw_queues_respects_the_user_and_an_initialised_gpu(monkeypatch):
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
 
 
+def test_wgrad_watch_fires_once_after_the_last_weight():
+    """ops.watch_wgrads: the callback runs when the LAST watched weight has reported its weight-gradient launches, in whatever
+    order they come, exactly once; unwatched weights and a cleared watch do nothing."""
+    from jafpro_amd import ops
+    a, b, c = (torch.zeros(1) for _ in range(3))
+    fired = []
+    ops.watch_wgrads([a, b], lambda: fired.append("ab"))
+    ops._wgrad_enqueued(c); ops._wgrad_enqueued(b)
+    assert fired == []
+    ops._wgrad_enqueued(b)                       # (a weight reporting twice does not count twice)
+    assert fired == []
+    ops._wgrad_enqueued(a)
+    assert fired == ["ab"]
+    ops._wgrad_enqueued(a); ops._wgrad_enqueued(b)
+    assert fired == ["ab"]
+    ops.watch_wgrads([a], lambda: fired.append("a"))
+    ops.watch_wgrads(None)
+    ops._wgrad_enqueued(a)
+    assert fired == ["ab"]
+
+
+def test_flat_params_offsets_match_the_parameter_views():
+    """FlatParams.offset(i): element offset of parameter i in the flat buffers (16-byte aligned views) -- what adam_range and the
+    multi-rank message split slice by."""
+    from jafpro_amd.step import FlatParams
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Conv2d(5, 2, 1))
+    f = FlatParams(m)
+    esz = f.flat.element_size()
+    for i, p in enumerate(f.params):
+        assert f.offset(i) % 4 == 0
+        assert p.data_ptr() == f.flat.data_ptr() + f.offset(i) * esz
+        assert p.grad.data_ptr() == f.grad.data_ptr() + f.offset(i) * esz
+    assert f.offset(len(f.params)) == f.flat.numel()
+
+
 def test_product_has_no_oracle_dependency():
     """The product package must never import the oracle (checked on source text)."""
     root = os.path.join(os.path.dirname(__file__), "..", "jafpro_amd")
