@@ -17,7 +17,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libjafpro_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["conv.hip", "conv_bf16.hip", "conv_dma.hip", "conv_dma_split.hip", "wgrad.hip", "wgrad_bf16.hip", "wgrad_dma.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
+SOURCES = ["conv.hip", "conv_pack_weights.hip", "conv_dma.hip", "conv_dma_split.hip", "wgrad.hip", "wgrad_dma.hip", "elementwise.hip", "norm.hip", "resample.hip", "gather.hip",
            "raster.hip", "raster_bwd.hip", "raster_texture.hip", "linear.hip", "ubench.hip", "input_pipeline.hip", "metrics.hip"]
 # raster.hip must keep the reference's fp32 expression trees (no FMA contraction): see its header.
 EXTRA = {"raster.hip": ["-ffp-contract=off"], "raster_bwd.hip": ["-ffp-contract=off"], "raster_texture.hip": ["-ffp-contract=off"]}

@@ -247,7 +247,9 @@ static bool desc_ok(const jaf_conv_desc* d) {
 extern "C" int jaf_conv2d_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan) {
     JAF_REQUIRE(desc_ok(d) && plan);
     if (lstm) JAF_REQUIRE((d->Cout & 3) == 0 && d->KH == 3 && d->KW == 3 && d->stride == 1);
-    if (d->precision != JAF_PREC_F32) return jafb_plan(d, lstm, plan);
+    // the bf16 modes run on the packed-input kernels only (jaf_conv2d_plan_packed / jaf_conv2d_fwd_packed_io): the fp32-input
+    // staging kernel of rounds 1-2 is gone
+    if (d->precision != JAF_PREC_F32) return JAF_EUNSUPPORTED;
     plan->precision = JAF_PREC_F32;
     plan->NG = plan->ng_last = plan->nsteps = plan->nsteps_last = plan->npos = plan->plane = 0;
     const int M = d->Cout;
@@ -478,8 +480,7 @@ extern "C" int jaf_conv2d_fwd(jaf_stream_t s, const jaf_conv_desc* d, const jaf_
     JAF_REQUIRE(desc_ok(d) && plan && src0 && packed_w && out);
     JAF_REQUIRE(d->nsrc < 2 || src1);
     JAF_REQUIRE(d->nsrc < 3 || src2);
-    if (d->precision != JAF_PREC_F32)
-        return jafb_fwd((hipStream_t)s, d, plan, src0, src1, src2, packed_w, bias, out);
+    if (d->precision != JAF_PREC_F32) return JAF_EUNSUPPORTED;          // bf16 modes: jaf_conv2d_fwd_packed_io
     JAF_REQUIRE(plan_ok(d, plan));
     ConvArgs a;
     fill_args(a, d, plan);
@@ -502,8 +503,7 @@ extern "C" int jaf_convlstm_cell_fwd(jaf_stream_t s, const jaf_conv_desc* d, con
     JAF_REQUIRE(d->Cout % (16 * plan->MT) == 0);
     JAF_REQUIRE((d->nsrc == 2) == (h_prev != nullptr));
     JAF_REQUIRE(d->H == d->OH && d->W == d->OW);
-    if (d->precision != JAF_PREC_F32)
-        return jafb_lstm((hipStream_t)s, d, plan, x, h_prev, packed_w, bias, c_prev, h_out, c_out, gates_out);
+    if (d->precision != JAF_PREC_F32) return JAF_EUNSUPPORTED;          // bf16 modes: jaf_convlstm_cell_fwd_packed_io
     JAF_REQUIRE(plan_ok(d, plan));
     ConvArgs a;
     fill_args(a, d, plan);

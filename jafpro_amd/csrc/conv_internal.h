@@ -69,15 +69,6 @@ static inline int jaf_kernel_slots(const void* kernel, int lds, JafOcc (*cache)[
 }
 
 
-int jafb_plan(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
+// conv_pack_weights.hip: the bf16 / split-bf16 weight image of the packed-input kernels
 int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, int mode, const float* w,
               int32_t w_rows_tot, void* packed);
-int jafb_fwd(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, const float* src0,
-             const float* src1, const float* src2, const void* packed_w, const float* bias, float* out);
-int jafb_lstm(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, const float* x,
-              const float* h_prev, const void* packed_w, const float* bias, const float* c_prev,
-              float* h_out, float* c_out, float* gates_out);
-int jafb_wgrad(hipStream_t s, const jaf_conv_desc* d, const float* src0, const float* src1,
-               const float* src2, const float* dz, float* dw, int accumulate, void* workspace,
-               int64_t workspace_bytes);
-int64_t jafb_wgrad_workspace(const jaf_conv_desc* d);

@@ -200,11 +200,8 @@ extern "C" int jaf_conv2d_wgrad(jaf_stream_t s_, const jaf_conv_desc* d,
     hipStream_t s = (hipStream_t)s_;
     const int KHW = d->KH * d->KW;
     JAF_REQUIRE(d->precision >= JAF_PREC_F32 && d->precision <= JAF_PREC_BF16X3);
-    // bf16 matrix cores for the 3x3 layers (all but a handful of first/last layers): JAF_PREC_BF16 rounds the operands to
-    // bf16, JAF_PREC_BF16X3 splits each into a bf16 head and residual and issues three MFMAs per product (fp32-grade
-    // gradients; the exact fp32 MFMA kernel below ran at 33 TFLOP/s and was 55 % of that mode's step).
-    if ((d->precision == JAF_PREC_BF16 || d->precision == JAF_PREC_BF16X3) && d->KH == 3 && d->KW == 3)
-        return jafb_wgrad(s, d, src0, src1, src2, dz, dw, accumulate, nullptr, 0);
+    // This fp32-input kernel computes in exact fp32 whatever d->precision says: in the bf16 modes it only serves the layers the
+    // packed weight-gradient kernels do not cover (7 x 7 and 4 x 4 taps: the propagater's first / last layers, FlowNetSD).
     if (!accumulate) {
         hipError_t e = hipMemsetAsync(dw, 0, sizeof(float) * (size_t)d->G * d->Cout * d->w_cin_tot * KHW, s);
         if (e != hipSuccess) return (int)e;

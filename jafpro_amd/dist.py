@@ -25,10 +25,42 @@ def limit_hw_queues(n: int = 2) -> bool:
     it leaves room for a second queue of RCCL's at larger world sizes, which a 1-GPU box cannot show, and one queue too many costs
     25 ms where one too few costs 1 (export GPU_MAX_HW_QUEUES=3 where the faster setting is known to hold).  Returns False (and changes nothing) when the variable is already set by the user or HIP is already initialised."""
     import os
-    if "GPU_MAX_HW_QUEUES" in os.environ or torch.cuda.is_initialized():
+    import warnings
+    if "GPU_MAX_HW_QUEUES" in os.environ:
         return False
-    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    if torch.cuda.is_initialized():
+        warnings.warn("jafpro_amd.dist.limit_hw_queues() called after HIP was initialised: GPU_MAX_HW_QUEUES can no longer be set "
+                      "for this process and a multi-rank step will run ~50 %% slower; call it before the first GPU call "
+                      "(or export GPU_MAX_HW_QUEUES=%d in the launcher)" % hw_queues_default(n), RuntimeWarning, stacklevel=2)
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(hw_queues_default(n))
     return True
+
+
+def hw_queues_default(n: int = 2) -> int:
+    """JAF_HW_QUEUES overrides the size of the normal-priority queue pool `limit_hw_queues` asks for (2 is the safe default; 3 was 1 ms
+    faster with a one-rank group, whether it holds at N = 8 can only be measured on an 8-GPU node)."""
+    import os
+    try:
+        return max(1, int(os.environ.get("JAF_HW_QUEUES", n)))
+    except ValueError:
+        return int(n)
+
+
+def warn_if_hw_queues_unset(reducer) -> None:
+    """A trainer with an active RCCL reducer in a process whose launcher never called `limit_hw_queues`: say so once (the step is
+    correct either way, but six hardware queues cost 50 % of it: profiles/experiments/round4_x4.log)."""
+    import os
+    import warnings
+    if reducer is None or not getattr(reducer, "active", False) or "GPU_MAX_HW_QUEUES" in os.environ:
+        return
+    try:
+        if dist.get_backend(reducer.group) != "nccl":
+            return
+    except Exception:
+        return
+    warnings.warn("multi-rank trainer over RCCL without GPU_MAX_HW_QUEUES: call jafpro_amd.dist.limit_hw_queues() before the first "
+                  "GPU call of every rank (or export GPU_MAX_HW_QUEUES=2)", RuntimeWarning, stacklevel=3)
 
 
 class GradReducer:
@@ -89,6 +121,29 @@ class GradReducer:
         if any(b.is_cuda for b in buffers):
             from . import ops
             ops.invalidate_packed_weights()
+
+    def host_broadcast_ints(self, values: Sequence[int], src: int = 0) -> List[int]:
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        dist.broadcast(t, src=src, group=self._host_group)
+        return [int(v) for v in t]
+
+    @staticmethod
+    def checksum(buffers: Sequence[torch.Tensor]) -> torch.Tensor:
+        """int64 [len(buffers)]: the wrapping sum of every buffer's 32-bit patterns.  Integer addition is exact and order-free, so
+        two ranks holding bit-identical buffers get the same number whatever their reduction order; a single differing bit in
+        one element changes it."""
+        return torch.stack([b.reshape(-1).view(torch.int32).sum(dtype=torch.int64) for b in buffers])
+
+    def consistent(self, buffers: Sequence[torch.Tensor]) -> List[bool]:
+        """Per buffer: do all ranks hold the same bits?  One small all-gather + ONE device read-back: not for every step
+        (Stage4Trainer calls it every `check_every` steps)."""
+        if not self.active:
+            return [True] * len(buffers)
+        mine = self.checksum(buffers)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine, group=self.group)
+        allv = torch.stack(out).cpu()
+        return [bool((allv[:, i] == allv[0, i]).all()) for i in range(len(buffers))]
 
 
 class BackwardOverlap:

@@ -105,8 +105,8 @@ class VideoEvaluator(torch.nn.Module):
     """perceptual_criterion = VGGLoss_CRN(weights=[1/2.6, 1/4.8, 1/3.7, 1/5.6, 10/1.5]) (video_evaluation.py:66) plus the
     closed-form metrics.  VGG weights come from load_state_dict (the ImageNet weights are not available offline).
     `with_flow=True` adds the script's FlowNetSD temporal term (:66-67): its weights are the external FlowNet2-SD checkpoint --
-    until they have been loaded (`load_flow_weights`, or a load_state_dict that carries `flow_criterion.*` keys) the evaluator
-    reports NaN for "flow" instead of a number computed from the random initialisation."""
+    until they have been loaded (`load_flow_weights`, or a load_state_dict that carries EVERY `flow_criterion.*` key) the evaluator
+    leaves "flow" out of its result instead of a number computed from the random initialisation."""
 
     def __init__(self, with_flow: bool = True):
         super().__init__()
@@ -120,13 +120,17 @@ class VideoEvaluator(torch.nn.Module):
         if self.flow_criterion is None:
             raise RuntimeError("VideoEvaluator(with_flow=False) has no flow criterion")
         r = self.flow_criterion.load_state_dict(state_dict, strict=strict)
-        self.flow_weights_loaded = True
+        self.flow_weights_loaded = not r.missing_keys
         return r
 
-    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
-        if any(k.startswith(prefix + "flow_criterion.") for k in state_dict):
-            self.flow_weights_loaded = True
-        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        """The flow term counts as loaded only when EVERY `flow_criterion.*` key was present (a partial / non-strict load that
+        carries a few of them leaves the rest at their random initialisation: ADVICE r4)."""
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self.flow_criterion is not None:
+            want = ["flow_criterion." + k for k in self.flow_criterion.state_dict()]
+            self.flow_weights_loaded = all(k in state_dict for k in want) and not any(k.startswith("flow_criterion.") for k in r.missing_keys)
+        return r
 
     @torch.no_grad()
     def flow_error(self, pred_rgb: torch.Tensor, gt_rgb: torch.Tensor) -> float:
@@ -168,6 +172,15 @@ class VideoEvaluator(torch.nn.Module):
         for i in range(F):                                         # the script scores frame by frame (:191)
             vgg += float(self.perceptual_criterion(self.vgg_preprocess_rgb(p[i:i + 1]), self.vgg_preprocess_rgb(g[i:i + 1])))
         out["vgg"] = vgg / F
-        # the script divides the F-1 terms by F (:220); NaN while the FlowNet2-SD weights have not been loaded
-        out["flow"] = self.flow_error(p, g) / F if (self.flow_criterion is not None and self.flow_weights_loaded) else float("nan")
+        # the script divides the F-1 terms by F (:220).  The key is OMITTED while the FlowNet2-SD weights have not been loaded (it
+        # was NaN in round 4: a caller that averages over videos or over keys then propagated the NaN; `aggregate` below skips
+        # videos without the key)
+        if self.flow_criterion is not None and self.flow_weights_loaded:
+            out["flow"] = self.flow_error(p, g) / F
         return out
+
+    @staticmethod
+    def aggregate(per_video) -> Dict[str, float]:
+        """Mean of every metric over the videos that report it (video_evaluation.py:216-222 prints these means)."""
+        keys = sorted({k for d in per_video for k in d})
+        return {k: float(sum(d[k] for d in per_video if k in d) / max(1, sum(1 for d in per_video if k in d))) for k in keys}

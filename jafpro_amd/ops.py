@@ -78,9 +78,9 @@ _PACK_CACHE_MAX = 4096
 _PACK_KEYS_BY_ID = {}
 _PROF = None
 _PRECISION = PREC_F32
-# JAF_PREC_BF16 runs on the packed-input (DMA-staged) kernels of csrc/conv_dma.hip; JAF_NO_PACKED=1 keeps
-# the fp32-input bf16 kernel (conv_bf16.hip) for A/B measurements.
-_USE_PACKED = os.environ.get("JAF_NO_PACKED") is None
+# The bf16 modes run on the packed-input (DMA-staged) kernels of csrc/conv_dma.hip / conv_dma_split.hip -- the only bf16 kernels
+# there are since round 5 (the fp32-input staging kernels of rounds 1-2 were deleted); f32 runs on csrc/conv.hip.
+_USE_PACKED = True
 _PREC_NAMES = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
 
 
@@ -220,13 +220,10 @@ def _fill_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil,
     return d
 
 
-# JAF_PREC_BF16X3 on the packed / DMA-staged kernels too (csrc/conv_dma_split.hip: hi + lo operand images, three matrix-core
-# instructions per product); JAF_NO_SPLIT_PACKED=1 keeps the fp32-input split kernels of conv_bf16.hip for A/B measurements
-_SPLIT_PACKED = os.environ.get("JAF_NO_SPLIT_PACKED") is None
-
-
 def _packed_prec(prec) -> bool:
-    return _USE_PACKED and (prec == PREC_BF16 or (prec == PREC_BF16X3 and _SPLIT_PACKED))
+    """JAF_PREC_BF16 and JAF_PREC_BF16X3 (csrc/conv_dma_split.hip: hi + lo operand images, three matrix-core instructions per
+    product) run on the packed-input kernels."""
+    return prec == PREC_BF16 or prec == PREC_BF16X3
 
 
 def _packed_path_now() -> bool:
@@ -525,7 +522,7 @@ def _wgrad_workspace(d, hidden: int, stream_handle: int, device):
     """(pointer or None, bytes) for jaf_conv2d_wgrad_packed_ws."""
     if not _WGRAD_PARTIALS:
         return None, 0
-    key = (id(d), hidden)
+    key = (bytes(d), hidden)          # the descriptor's contents (an id() can be reused by another layer's descriptor: ADVICE r4)
     need = _WGRAD_WS_NEED.get(key)
     if need is None:
         need = int(lib().jaf_conv2d_wgrad_packed_ws_bytes(ctypes.byref(d), hidden))
@@ -538,7 +535,12 @@ def _wgrad_workspace(d, hidden: int, stream_handle: int, device):
     buf = _WGRAD_WS.get(stream_handle)
     if buf is None or buf.numel() < need or buf.device != device:
         if buf is not None:
-            _WGRAD_WS_OLD.append(buf)
+            # an outgrown buffer may still be read by a launch enqueued earlier on that stream: the caching allocator keeps the block
+            # out of circulation until the stream has passed this point (record_stream), then it is released -- nothing piles up
+            for st in ([torch.cuda.current_stream()] + list(_AUX_STREAMS.values())):
+                if st.cuda_stream == stream_handle:
+                    buf.record_stream(st)
+            _WGRAD_WS_OLD[:] = [buf]
         buf = torch.empty(max(need, 64 << 20), dtype=torch.uint8, device=device)
         _WGRAD_WS[stream_handle] = buf
     return _p(buf), buf.numel()

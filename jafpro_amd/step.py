@@ -164,6 +164,7 @@ EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
 DIST_ISSUE_ON_WGRAD = os.environ.get("JAF_DIST_ISSUE_ON_WGRAD", "1") != "0"     # multi-rank: gradient messages issued from the weight-gradient stream
 ATLAS_PACKED = os.environ.get("JAF_ATLAS_PACKED", "1") != "0"     # atlas slicing straight into enc1's packed input image
 RUN_AHEAD = int(os.environ.get("JAF_RUN_AHEAD", "2"))     # steps the host may have in flight (0: unbounded)
+RANK_CHECK_EVERY = int(os.environ.get("JAF_RANK_CHECK_EVERY", "200"))     # multi-rank: steps between cross-rank checksum comparisons (0: never)
 ACCU_SPLIT = os.environ.get("JAF_ACCU_SPLIT", "1") != "0"     # multi-rank: the accumulate net's gradient message and optimiser step in two parameter ranges
 
 
@@ -330,6 +331,64 @@ class Stage4Trainer:
         self._accu_split = next((i for i, p in enumerate(self.flat["accu"].params) if p is w4), None) if w4 is not None else None
         self._prepared: Optional[PreparedClip] = None
         self.phase_mark = None          # optional callable(name): phase boundaries of train_step (profiling)
+        # Rank consistency (the reference's nn.DataParallel re-replicates every module from device 0 in every forward,
+        # train/4...py:123-162; here each rank owns a replica for the whole run): parameters, Adam moments, step counts and
+        # BatchNorm buffers are taken from rank 0 once, now, and every `check_every` steps the ranks compare an exact checksum of
+        # their parameter and moment buffers (BatchNorm running statistics stay rank-local by design: SURVEY 8(e)).
+        self.check_every = RANK_CHECK_EVERY
+        self._steps_done = 0
+        if reducer is not None and reducer.active:
+            from .dist import warn_if_hw_queues_unset
+            warn_if_hw_queues_unset(reducer)
+            self.sync_from_rank0()
+
+    def sync_from_rank0(self) -> None:
+        """Every rank takes rank 0's trainable state: flat parameters, Adam moments and step counts of the six modules, and all
+        buffers of the model set (BatchNorm running statistics / counters, the frozen networks' weights included)."""
+        red = self.reducer
+        flush_bn_counters(self.M)
+        names = sorted(self.flat)
+        red.broadcast([t for n in names for t in (self.flat[n].flat, self.flat[n].m, self.flat[n].v)])
+        counts = red.host_broadcast_ints([self.flat[n].step_count for n in names])
+        for n, c in zip(names, counts):
+            self.flat[n].step_count = c
+        frozen = [p.data for p in self.M.parameters() if not p.requires_grad]
+        bufs = [b for b in self.M.buffers() if b.is_floating_point() or b.dtype in (torch.int64, torch.int32)]
+        red.broadcast(frozen + bufs)
+        ops.invalidate_packed_weights()
+
+    def snapshot(self):
+        """The training state a step changes -- parameters, Adam moments and step counts of the six modules, every buffer of the
+        model set (BatchNorm statistics and counters) -- as device copies; `restore` puts it back."""
+        return ({n: (f.flat.clone(), f.m.clone(), f.v.clone(), f.step_count) for n, f in self.flat.items()},
+                [(bf, bf.clone()) for bf in self.M.buffers()],
+                [(m, m._nbt_pending) for m in self.M.modules() if hasattr(m, "_nbt_pending")])
+
+    def restore(self, snap) -> None:
+        ops.join_wgrad_stream()
+        for n, (p, m, v, c) in snap[0].items():
+            f = self.flat[n]
+            f.flat.copy_(p); f.m.copy_(m); f.v.copy_(v)
+            f.step_count = c
+        for bf, val in snap[1]:
+            bf.copy_(val)
+        for m, c in snap[2]:
+            m._nbt_pending = c
+        for f in self.flat.values():                 # the images follow the weights back (per module: the re-pack tables of Adam)
+            ops.refresh_packed_weights(f.params)
+
+    def check_rank_consistency(self) -> None:
+        """Raises on every rank if any rank's parameters or Adam moments differ in a single bit from rank 0's."""
+        red = self.reducer
+        if red is None or not red.active:
+            return
+        ops.join_wgrad_stream()
+        names = sorted(self.flat)
+        bufs = [t for n in names for t in (self.flat[n].flat, self.flat[n].m, self.flat[n].v)]
+        ok = red.consistent(bufs)
+        bad = [names[i // 3] + "." + ("param", "adam_m", "adam_v")[i % 3] for i, o in enumerate(ok) if not o]
+        if bad:
+            raise RuntimeError("data-parallel ranks have diverged after %d steps: %s differ across ranks" % (self._steps_done, ", ".join(bad)))
 
     def _reduce(self, names: Sequence[str]):
         if self.reducer is not None:
@@ -374,8 +433,8 @@ class Stage4Trainer:
         if not _CAPTURE["on"] and not _CAPTURE["settling"]:
             self._last_graph = None      # an eager step in between: a graph's static hand-over slot no longer matches the sequence
         try:
-            return self._train_step(batch, used, prosrc, align_corners, next_batch,
-                                    prosrc if next_prosrc is None else next_prosrc)
+            out = self._train_step(batch, used, prosrc, align_corners, next_batch,
+                                   prosrc if next_prosrc is None else next_prosrc)
         finally:
             ops.join_wgrad_stream()
             ops.set_wgrad_stream(prev_ws)
@@ -385,6 +444,11 @@ class Stage4Trainer:
                 self._inflight.append(ev)
             if not _CAPTURE["on"]:
                 flush_bn_counters(self.M)
+        if not _CAPTURE["on"] and not _CAPTURE["settling"]:
+            self._steps_done += 1
+            if self.check_every > 0 and self.reducer is not None and self.reducer.active and self._steps_done % self.check_every == 0:
+                self.check_rank_consistency()
+        return out
 
     def train_step_graphed(self, batch, used: Sequence[int] = (0, 1, 2, 3), prosrc: int = 0, align_corners: bool = False,
                            next_batch=None, next_prosrc: Optional[int] = None):
@@ -665,12 +729,32 @@ def flush_bn_counters(module: nn.Module) -> None:
         m._nbt_pending = 0
 
 
+class _ClipToken:
+    """Identity of a clip as the caller holds it.  The token keeps STRONG references to the clip's tensors: while it lives, the
+    caching allocator cannot hand their storage to another clip, so "same tensor objects at the same versions" means "same data"
+    (a token of addresses alone matched a NEW clip allocated into the freed blocks of a dropped one, both at version 0, and the
+    replay then trained on the previously staged clip: ADVICE r4).  Host arrays are compared by value."""
+    __slots__ = ("items",)
+
+    def __init__(self, b):
+        self.items = tuple((k, v, v._version) if isinstance(v, torch.Tensor) else (k, np.asarray(v).tobytes(), None)
+                           for k, v in sorted(b.items()))
+
+    def matches(self, b) -> bool:
+        if b is None or len(b) != len(self.items):
+            return False
+        for k, ref, ver in self.items:
+            v = b.get(k)
+            if isinstance(ref, torch.Tensor):
+                if v is not ref or v._version != ver:
+                    return False
+            elif isinstance(v, torch.Tensor) or np.asarray(v).tobytes() != ref:
+                return False
+        return True
+
+
 def _clip_token(b):
-    """Identity of a clip as the caller holds it: tensors by storage and version, host arrays by value."""
-    if b is None:
-        return None
-    return tuple((k, v.data_ptr(), v._version) if isinstance(v, torch.Tensor) else (k, np.asarray(v).tobytes())
-                 for k, v in sorted(b.items()))
+    return None if b is None else _ClipToken(b)
 
 
 class GraphedTrainStep:
@@ -775,24 +859,10 @@ class GraphedTrainStep:
         self.resyncs = 0
 
     def _snapshot(self):
-        tr = self.trainer
-        return ({n: (f.flat.clone(), f.m.clone(), f.v.clone(), f.step_count) for n, f in tr.flat.items()},
-                [(bf, bf.clone()) for bf in tr.M.buffers()],
-                [(m, m._nbt_pending) for m in tr.M.modules() if hasattr(m, "_nbt_pending")])
+        return self.trainer.snapshot()
 
     def _restore(self, snap):
-        tr = self.trainer
-        ops.join_wgrad_stream()
-        for n, (p, m, v, c) in snap[0].items():
-            f = tr.flat[n]
-            f.flat.copy_(p); f.m.copy_(m); f.v.copy_(v)
-            f.step_count = c
-        for bf, val in snap[1]:
-            bf.copy_(val)
-        for m, c in snap[2]:
-            m._nbt_pending = c
-        for f in tr.flat.values():                   # the images follow the weights back (per module: the re-pack tables of Adam)
-            ops.refresh_packed_weights(f.params)
+        self.trainer.restore(snap)
 
     @staticmethod
     def _prep_pairs(dst: PreparedClip, src: PreparedClip):
@@ -834,7 +904,7 @@ class GraphedTrainStep:
         else:
             if next_batch is None:
                 raise ValueError("this graph was captured with a next clip: pass next_batch")
-            if not in_sequence or _clip_token(batch) != self.staged_token:
+            if not in_sequence or self.staged_token is None or not self.staged_token.matches(batch):
                 self._resync(batch)
             self._put(self.stage, next_batch)
             self.staged_token = _clip_token(next_batch)

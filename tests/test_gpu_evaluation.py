@@ -47,7 +47,16 @@ def test_video_evaluator_end_to_end():
     from oracle import torch_oracle as O
     pred, gt = _video(1, F=2, S=192)
     ev = E.VideoEvaluator()
-    assert not ev.flow_weights_loaded          # "flow" is NaN until FlowNet2-SD weights arrive (random weights mean nothing)
+    assert not ev.flow_weights_loaded          # "flow" is left out until FlowNet2-SD weights arrive (random weights mean nothing)
+    # a partial, non-strict load that carries only SOME flow keys must not count as loaded
+    part = {k: v for i, (k, v) in enumerate(ev.state_dict().items()) if not (k.startswith("flow_criterion.") and i % 2)}
+    ev.load_state_dict(part, strict=False)
+    assert not ev.flow_weights_loaded
+    o0 = ev.cuda()(torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda())
+    assert "flow" not in o0 and all(np.isfinite(v) for v in o0.values())
+    assert set(E.VideoEvaluator.aggregate([o0, dict(o0, flow=2.0), dict(o0, flow=4.0)])) == set(o0) | {"flow"}
+    assert E.VideoEvaluator.aggregate([o0, dict(o0, flow=2.0), dict(o0, flow=4.0)])["flow"] == 3.0
+    ev = ev.cpu()
     synth.load_synth(ev, 808)
     assert ev.flow_weights_loaded
     assert E.VideoEvaluator(with_flow=False).flow_criterion is None

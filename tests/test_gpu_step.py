@@ -481,3 +481,18 @@ def test_graphed_step_trains_on_the_clip_it_is_given():
     for k in ("total_loss", "vgg_l1"):
         a, b = float(o_e[k].reshape(-1)[0]), float(o[k].reshape(-1)[0])
         assert abs(a - b) <= 5e-3 * max(1.0, abs(a)), (k, a, b)
+    # the caller drops the staged clip and starts another sequence whose clip lands in the freed blocks (same addresses,
+    # fresh tensors at version 0).  The token holds the staged tensors themselves, so the new clip can never match it.
+    staged = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in clips[1].items()}
+    tr2.train_step_graphed(clips[2], next_batch=staged)          # (out of sequence again: resync 2) stages `staged`
+    addrs = {k: v.data_ptr() for k, v in staged.items() if isinstance(v, torch.Tensor)}
+    del staged
+    fresh = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in clips[0].items()}
+    n_before = g.resyncs
+    tr2.train_step_graphed(fresh, next_batch=clips[1])
+    torch.cuda.synchronize()
+    assert g.resyncs == n_before + 1, "a new clip was taken for the staged one (reused addresses: %s)" % (
+        [k for k, v in fresh.items() if isinstance(v, torch.Tensor) and addrs.get(k) == v.data_ptr()],)
+    for k, v in g.cur.items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(v, clips[0][k]), k

@@ -116,9 +116,14 @@ def test_limit_hw_queues_respects_the_user_and_an_initialised_gpu(monkeypatch):
     assert limit_hw_queues() is False and os.environ["GPU_MAX_HW_QUEUES"] == "7"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: True)
-    assert limit_hw_queues() is False and "GPU_MAX_HW_QUEUES" not in os.environ
+    import pytest
+    with pytest.warns(RuntimeWarning, match="after HIP was initialised"):       # too late: said aloud, nothing changed
+        assert limit_hw_queues() is False and "GPU_MAX_HW_QUEUES" not in os.environ
     monkeypatch.setattr(torch.cuda, "is_initialized", lambda: False)
     assert limit_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "2"
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    monkeypatch.setenv("JAF_HW_QUEUES", "3")                                    # the pool size is the launcher's to choose
+    assert limit_hw_queues() is True and os.environ["GPU_MAX_HW_QUEUES"] == "3"
     monkeypatch.delenv("GPU_MAX_HW_QUEUES")
 
 
@@ -221,3 +226,80 @@ def test_uv_map_asset_builders_equal_the_reference(tmp_path, golden_dir):
     assert np.array_equal(mesh.create_mapping("ids", a["obj"], contain_bg=False), gold["map.ids.nobg"])
     with pytest.raises(ValueError):
         mesh.create_mapping("nope", a["obj"], **kw)
+
+
+def test_draw_subset_reproduces_the_script_stream():
+    """jafpro_amd.train.draw_subset(RandomState(seed)) == the reference script's own draws under np.random.seed(seed)
+    (train/4.convLSTM_flowpro_interval.py:249-261: one random(), one choice(4, k, replace=False), and for k > 1 one
+    choice(k, 1)), restated here against NumPy's GLOBAL stream, 200 iterations of 10 seeds; all four subset sizes and
+    unsorted orders occur; the propagation source is always a drawn reference."""
+    import numpy as np
+    from jafpro_amd.train import draw_subset
+
+    def script_draw():
+        r = np.random.random()
+        k = 1 if r < 0.25 else 2 if r < 0.5 else 3 if r < 0.75 else 4
+        idx = np.random.choice(4, k, replace=False)
+        p = idx[0] if k == 1 else idx[np.random.choice(k, 1)]
+        return tuple(int(i) for i in idx), int(np.asarray(p).reshape(-1)[0])
+
+    sizes, unsorted = set(), 0
+    for seed in range(10):
+        np.random.seed(seed)
+        want = [script_draw() for _ in range(200)]
+        rng = np.random.RandomState(seed)
+        got = [draw_subset(rng) for _ in range(200)]
+        assert got == want
+        for u, p in got:
+            assert p in u and len(set(u)) == len(u)
+            sizes.add(len(u))
+            unsorted += list(u) != sorted(u)
+    assert sizes == {1, 2, 3, 4} and unsorted > 100
+
+
+def test_run_stage4_loop_bookkeeping_without_a_gpu(tmp_path):
+    """The loop's own logic on a stand-in trainer (no kernels): count starts at 12000 (:197) and advances per iteration, iteration
+    k is handed iteration k+1's clip and propagation source, the last one none, the checkpoint cadence fires on
+    count % interval == 0 and puts every module back to .train() (:515-542), `iters` bounds the run, `epochs=None` cycles."""
+    import numpy as np
+    import torch
+    from jafpro_amd import train
+
+    class _Mods(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for n in ("Accu_model", "inpaint_model", "bg_model", "refine_model", "discriminator", "F_Discriminator", "propagater"):
+                setattr(self, n, torch.nn.Linear(2, 2))
+
+    class _Trainer:
+        reducer = None
+
+        def __init__(self):
+            self.M, self.calls = _Mods(), []
+            self.M.bg_model.eval()
+
+        def train_step(self, batch, used, prosrc, next_batch=None, next_prosrc=None):
+            self.calls.append((batch["id"], used, prosrc, None if next_batch is None else next_batch["id"], next_prosrc))
+            return {"total_loss": torch.zeros(1), "final_output": torch.zeros(1)}
+
+    items = [{"id": i, "src_img": torch.zeros(1, 4, 3, 8, 8), "bg_noise": torch.zeros(1, 3, 8, 8)} for i in range(3)]
+    tr = _Trainer()
+    hist = train.run_stage4(tr, items, seed=16, ckpt_dir=str(tmp_path), save_interval=2, device="cpu")
+    rng = np.random.RandomState(16)
+    want = [train.draw_subset(rng) for _ in range(3)]
+    assert [(c[1], c[2]) for c in tr.calls] == want
+    assert [c[0] for c in tr.calls] == [0, 1, 2] and [c[3] for c in tr.calls] == [1, 2, None]
+    assert [c[4] for c in tr.calls] == [want[1][1], want[2][1], None]
+    assert [h["count"] for h in hist] == [12001, 12002, 12003]
+    import os
+    assert sorted(os.listdir(tmp_path)) == sorted("%s_iter_12002.pth" % p for p in ("Accu", "inpaint", "bg", "refine", "D", "FD", "pro"))
+    assert tr.M.bg_model.training          # :538, the script's quirk: bg_model.train() after a save
+    tr2 = _Trainer()
+    hist = train.run_stage4(tr2, items, iters=7, epochs=None, draws=[((0,), 0)] * 100, device="cpu")
+    assert [c[0] for c in tr2.calls] == [0, 1, 2, 0, 1, 2, 0] and tr2.calls[-1][3] is None and len(hist) == 7
+    tr3 = _Trainer()
+    train.run_stage4(tr3, items, draws=[((1, 0), 1), ((2,), 2)], device="cpu")          # the draws run out first
+    assert len(tr3.calls) == 2 and tr3.calls[-1][3] is None
+    import pytest
+    with pytest.raises(ValueError):
+        train.run_stage4(_Trainer(), items, draws=[((1, 0), 3)], device="cpu")
