@@ -27,15 +27,50 @@ MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "bf16x3": 2500.0 / 3.0}
 SEEDS = {"accu": 1301, "inpaint": 1302, "bg": 1303, "refine": 1304, "flow": 1305, "D": 1306, "face": 1307, "vgg": 1308}
 
 
-def build_models(fidx, image_size=256):
+def build_models(fidx, image_size=256, seeds=None):
     from jafpro_amd import synth
     from jafpro_amd.step import Stage4Models
     M = Stage4Models(fidx, image_size=image_size)
     mods = {"accu": M.Accu_model, "inpaint": M.inpaint_model, "bg": M.bg_model, "refine": M.refine_model,
             "flow": M.propagater, "D": M.discriminator, "face": M.F_Discriminator, "vgg": M.loss_criterion}
     for k, m in mods.items():
-        synth.load_synth(m, SEEDS[k])
+        synth.load_synth(m, (seeds or SEEDS)[k])
     return M, mods
+
+
+# the weights / batch of the oracle's B=8 fixture tests/golden/step_s328_b8.npz (oracle/make_step_golden.py case s328_b8;
+# tests/_step_util.SEEDS): the frame the fp32 CPU oracle generates for them is what `frame_linf_*` is measured against
+FIXTURE_SEEDS = {"accu": 201, "inpaint": 202, "bg": 203, "refine": 204, "flow": 205, "D": 206, "face": 207, "vgg": 208}
+FIXTURE_CASE, FIXTURE_BATCH_SEED, FIXTURE_B = "step_s328_b8.npz", 328, 8
+
+
+def measure_frame_parity(fidx, modes):
+    """L-inf distance of the generated frame from the fp32 CPU oracle's, per arithmetic mode, measured IN THIS RUN: the
+    generator forward of the fixture's weights and B=8 batch on this GPU against the fixture's stored frame (north star: <= 1e-3
+    for the parity-grade modes; bf16 rounds every operand to 8 bits and is held to 1e-1)."""
+    from jafpro_amd import ops, synth
+    from jafpro_amd.step import _to_dev, generator_forward
+    path = os.path.join(ROOT, "tests", "golden", FIXTURE_CASE)
+    if not os.path.exists(path):
+        return None
+    ref = torch.from_numpy(np.load(path)["final_output"]).cuda()
+    M, _ = build_models(fidx, 256, FIXTURE_SEEDS)
+    M = M.cuda()
+    M.set_train_modes()
+    b = _to_dev(synth.stage4_batch(FIXTURE_BATCH_SEED, FIXTURE_B), "cuda")
+    out = {}
+    prev = ops.get_precision()
+    try:
+        for mode in modes:
+            ops.set_precision(mode)
+            with torch.no_grad():
+                g = generator_forward(M, b, (0, 1, 2, 3), 0)
+            out[mode] = float((g["final_output"] - ref).abs().max())
+    finally:
+        ops.set_precision(prev)
+    del M
+    torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(mods, fidx, size=256):
@@ -145,6 +180,8 @@ def main():
                     help="report this kernel instantiation in `roofline` instead of the one with the largest total time")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-config2", action="store_true", help="skip the forward-only BASELINE configs[1] figure (N=1 only)")
+    ap.add_argument("--no-frame-parity", action="store_true",
+                    help="skip the in-run frame L-inf of each arithmetic mode against the oracle's B=8 fixture (N=1, 256 only)")
     ap.add_argument("--preheat", type=float, default=float(os.environ.get("JAF_BENCH_PREHEAT", "0")),
                     help="seconds of synthetic matrix-multiply load before the warm-up steps (not steps; reported as preheat_s)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each clip inside its own step instead of one step ahead")
@@ -317,6 +354,14 @@ def main():
                    "host_enqueue_ms": host_enqueue_ms,
                    "loss": float(out["total_loss"].reshape(-1)[0])},
     }
+    # what the gradient exchange ran on (scalars: proof for an N > 1 line that RCCL saw N ranks)
+    rccl = {"world": world, "backend": dist.get_backend() if dist.is_initialized() else None,
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (dist.is_initialized() and backend == "nccl") else None,
+            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "bucket_mb": (reducer.bucket_elems * 4) >> 20 if reducer is not None else None,
+            "overlap_order": list(getattr(trainer, "overlap_order", [])) or None}
+    result["config"]["rccl"] = rccl
+    result["config"].update({"rccl_world": rccl["world"], "rccl_backend": rccl["backend"], "rccl_version": rccl["rccl_version"],
+                             "hw_queues": rccl["hw_queues"]})
 
     if rank == 0 and not args.no_roofline:
         # one extra step with every kernel on ONE stream: a kernel that shares the chip with side-stream work
@@ -352,7 +397,17 @@ def main():
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pj)) as f:
                 pt = json.load(f)
             if pt.get("kernel") == name and args.precision == "bf16" and pt.get("batch", 8) == B:
-                traffic, traffic_src = pt["hbm_bytes_per_launch"], pt["source"]
+                traffic = pt["hbm_bytes_per_launch"]
+                # where the committed figure comes from: the PMC table, the commit the library was at when it was taken, and
+                # the git blob hashes of the kernel sources at that commit (a stale figure shows as a hash that no longer matches
+                # `git hash-object` of the file: tests/test_host_logic.py checks it)
+                traffic_src = {"file": pt["source"], "commit": pt.get("commit"), "kernel_source_blobs": pt.get("kernel_source_blobs")}
+                sys.path.insert(0, os.path.join(ROOT, "profiles"))
+                from pmc_summarize import git_blob_hash
+                blobs = pt.get("kernel_source_blobs") or {}
+                changed = sorted(p_ for p_, h_ in blobs.items() if git_blob_hash(os.path.join(ROOT, p_)) != h_)
+                traffic_src["stale"] = (not blobs) or bool(changed)        # True: a listed source changed since the counters were read
+                traffic_src["changed_since"] = changed
         except (OSError, ValueError, KeyError):
             pass
         ceil = measure_ceilings() if args.precision != "f32" else None
@@ -395,6 +450,18 @@ def main():
                                      "frames_per_s": B / dt, "steps": nsteps,
                                      "note": "each step synchronised (no run-ahead of the host): an upper bound of the back-to-back time"}
         ops.set_precision(args.precision)
+        # the same figures as scalar keys (a record that keeps only scalars of `config` still carries them)
+        for mode in ("bf16x3", "f32"):
+            r_ = result["config"].get(mode + "_parity_mode")
+            if r_:
+                result["config"][mode + "_ms_per_step"] = r_["ms_per_step"]
+                result["config"][mode + "_frames_per_s"] = r_["frames_per_s"]
+    if rank == 0 and world == 1 and args.size == 256 and not args.no_frame_parity:
+        fp = measure_frame_parity(fidx, ("f32", "bf16x3", "bf16"))
+        if fp is not None:
+            for mode, v in fp.items():
+                result["config"]["frame_linf_" + mode] = v
+            result["config"]["frame_linf_fixture"] = "tests/golden/" + FIXTURE_CASE
     if rank == 0 and world == 1 and args.size == 256 and not args.no_config2:
         # BASELINE configs[1]: forward-only clip loop (test/conv_pro_test.py:219-279), B=2 clips x 30 target frames, fp32
         from jafpro_amd.step import forward_clip

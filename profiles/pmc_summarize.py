@@ -31,6 +31,21 @@ def load(counter):
     return tot, n
 
 
+TRAFFIC_SOURCES = ("jafpro_amd/csrc/conv_dma.hip", "jafpro_amd/csrc/conv_dma_kernel.h", "jafpro_amd/ops.py", "jafpro_amd/crn_model.py",
+                   "jafpro_amd/networks.py")
+
+
+def git_blob_hash(path):
+    """`git hash-object <path>` without git (sha1 of "blob <size>\0" + contents)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_blobs():
+    return {p: git_blob_hash(os.path.join(ROOT, p)) for p in TRAFFIC_SOURCES}
+
+
 def main():
     tag = sys.argv[1]
     fetch, nf = load("FETCH_SIZE")
@@ -60,6 +75,10 @@ def main():
         if k == dom:
             json.dump({"kernel": dom, "launches": n, "fetch_kib_per_launch": f, "write_kib_per_launch": w,
                        "hbm_bytes_per_launch": (2 * f + w) * 1024,
+                       # provenance: the commit the tree was at (JAF_PROFILE_COMMIT, passed by the caller of the
+                       # profiling script: the GPU box has no .git) and the git blob hashes of the sources that shape the
+                       # dominant kernel's traffic; bench.py recomputes the hashes and flags a stale figure
+                       "commit": os.environ.get("JAF_PROFILE_COMMIT"), "kernel_source_blobs": source_blobs(),
                        "source": "profiles/%s_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                                  "2*FETCH+WRITE per MI355X_MICROARCH.md)" % tag},
                       open(os.path.join(ROOT, "profiles", jname), "w"), indent=1)
