@@ -182,6 +182,14 @@ int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t G, int32_t 
 int jaf_convlstm_gates_bwd_packed_prec(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
                                        const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                        const float* c_cur, float* dc_prev, void* packed, float* dbias, int precision);
+/* Same with the element types of the tensors given (bf16 STORAGE of BASELINE configs[2], JAF_PREC_BF16 with bf16 gates only):
+ * dh_bf16: dh holds bf16 (the d h_{t-1} a data-gradient launch wrote with jaf_packed_io.out2_bf16); state_bf16: c_prev, c_cur,
+ * dc_next and dc_prev hold bf16 (jaf_packed_io.state_bf16 of the forward cell).  26 instead of 36 bytes per hidden-channel pixel.
+ * Reference: the adjoint of src/convLSTM.py:48-54 (fp32 there). */
+int jaf_convlstm_gates_bwd_packed_dt(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const void* dh,
+                                     int dh_bf16, const void* dc_next, const void* gates, int gates_bf16,
+                                     const void* c_prev, const void* c_cur, void* dc_prev, int state_bf16, void* packed,
+                                     float* dbias, int precision);
 int jaf_conv2d_plan_packed(const jaf_conv_desc* d, int lstm, jaf_conv_plan* plan);
 /* flags: JAF_PLAN_NO_INTERLEAVE keeps a lane's pixel tiles 16 pixels apart (no pixel interleave): the layout that makes
  * the 16-byte items of a packed bf16 OUTPUT image (jaf_packed_io) contiguous across the lanes of a store -- for launches
@@ -239,6 +247,12 @@ typedef struct jaf_packed_io {
     int32_t dz_mask_ng8, dz_mask_coff;
     float dz_slope;
     float* dz_dbias;
+    /* bf16 STORAGE (JAF_PREC_BF16 launches only; BASELINE configs[2] names bf16): the NCHW tensors a launch writes hold bf16
+     * instead of fp32 -- `out` (also what accumulate_f32 / the dz mode's first gradient read), `out2`, and for the ConvLSTM cell
+     * the state tensors c_prev (read) and c_out (written).  Same shapes and strides in elements; the pointers are passed through
+     * the float* / void* parameters.  The statistics of jaf_conv2d_fwd_packed_stats are taken from the unrounded values.
+     * Reference: src/convLSTM.py:41-56 (c), src/crn_model.py:78-106 (pre-LayerNorm conv output), all fp32 there.          */
+    int32_t out_bf16, out2_bf16, state_bf16;
 } jaf_packed_io;
 int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                              const void* packed_in, const void* packed_w, const float* bias, float* out,
@@ -352,6 +366,24 @@ int jaf_layernorm_lrelu_bwd_packed_prec(jaf_stream_t s, const float* dy, const f
                                         float* dbeta, double* workspace, float* scratch, float* conv_dbias,
                                         int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps,
                                         int precision);
+/* The LayerNorm entry points with the element types of their NCHW tensors given (bf16 STORAGE of BASELINE configs[2]; JAF_PREC_BF16
+ * only): x_bf16 -- x, the pre-LayerNorm convolution output (jaf_packed_io.out_bf16), holds bf16; dy_bf16 -- the incoming gradient
+ * holds bf16 (the consumer convolution's data gradient written with out_bf16); jaf_layernorm_lrelu_bwd_dt writes dx in x's type.
+ * Statistics, gamma / beta and their gradients stay fp32 / fp64.  Reference: src/crn_model.py:67-87 (fp32 there). */
+int jaf_layernorm_lrelu_fwd_dt(jaf_stream_t s, const void* x, int x_bf16, const float* stats, const float* gamma,
+                               const float* beta, float* y, int32_t N, int32_t C, int32_t HW, float slope);
+int jaf_layernorm_lrelu_fwd_packed_dt(jaf_stream_t s, const void* x, int x_bf16, const float* stats, const float* gamma,
+                                      const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
+                                      int32_t N, int32_t C, int32_t HW, float slope, int precision);
+int jaf_layernorm_lrelu_bwd_dt(jaf_stream_t s, const void* dy, int dy_bf16, const void* x, int x_bf16, const float* stats,
+                               const float* gamma, const float* beta, void* dx, float* dgamma,
+                               float* dbeta, double* workspace, int32_t N, int32_t C, int32_t HW,
+                               float slope, float eps);
+int jaf_layernorm_lrelu_bwd_packed_dt(jaf_stream_t s, const void* dy, int dy_bf16, const void* x, int x_bf16,
+                                      const float* stats, const float* gamma, const float* beta, void* packed_dx,
+                                      float* dgamma, float* dbeta, double* workspace, float* scratch, float* conv_dbias,
+                                      int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps,
+                                      int precision);
 
 /* BatchNorm2d in training mode (src/flow_net.py:13-51, src/networks.py:369-390; eps 1e-5,
  * momentum 0.1, biased var for normalisation, unbiased for running_var) + activation

@@ -47,7 +47,7 @@ class LayerNorm(nn.Module):
         its convolution's epilogue already accumulated (ops.LNStats) and, on the packed bf16 path, the packed image of
         the convolution that consumes the result (ops.PackedDst); sole: x is a convolution's output that nothing else reads
         (its gradient may then go back to that convolution as a packed bf16 image)."""
-        return ops.layernorm_lrelu(x.contiguous(), self.gamma, self.beta, self.eps, slope, pre, dst, keep_f32, sole)
+        return ops.layernorm_lrelu(x if x.is_contiguous() else x.contiguous(), self.gamma, self.beta, self.eps, slope, pre, dst, keep_f32, sole)
 
 
 class ConvBlock(nn.Module):
@@ -69,7 +69,10 @@ class ConvBlock(nn.Module):
         for r in range(self.n_repeats):
             conv, ln = self.conv_block[3 * r], self.conv_block[3 * r + 1]
             st = ln.pre_stats          # this LayerNorm's own side channel (zeroed once, kept clean by the finalize kernel)
-            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE, ln_stats=st, prepacked=img_in)
+            # bf16 storage (bf16 arithmetic mode): the pre-LayerNorm output is read by this block's LayerNorm alone, which takes
+            # its statistics from the convolution's epilogue (unrounded) and reads the tensor in bf16
+            x = ops.conv2d(x, conv.weight, conv.bias, stride=1, pad=self.pad, act=ACT_NONE, ln_stats=st, prepacked=img_in,
+                           out_dtype=torch.bfloat16)
             img_out = out_image
             if r + 1 < self.n_repeats and ops.packed_active():
                 img_out = ops.PackedImage(x.shape[0], 1, x.shape[1], x.shape[2], x.shape[3], x.device)

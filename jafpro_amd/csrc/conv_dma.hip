@@ -807,11 +807,39 @@ extern "C" int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const fl
 // jaf_conv2d_wgrad_packed_lstm the rows of dW.
 // grid (pixel blocks, C/2, N*G), block 256.
 // ---------------------------------------------------------------------------------------------
-template <int V, typename GT>
-__global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C, int HW, const float* __restrict__ dh,
-                                                                    const float* __restrict__ dc_next, const GT* __restrict__ gates,
-                                                                    const float* __restrict__ c_prev, const float* __restrict__ c_cur,
-                                                                    float* __restrict__ dc_prev, unsigned char* __restrict__ packed,
+// DT: element type of dh (fp32: the gradient autograd hands in for the last step; bf16: the d h_{t-1} the data-gradient launch of
+// step t+1 wrote, jaf_packed_io.out2_bf16); ST: element type of the cell-state tensors c_prev, c_cur, dc_next, dc_prev (bf16
+// storage of BASELINE configs[2]: 26 instead of 36 bytes per hidden-channel pixel).
+template <int V, typename T>
+__device__ __forceinline__ void lg_load(const T* __restrict__ p, float (&o)[V]) {
+    if constexpr (V > 1) {
+        typedef T tv __attribute__((ext_vector_type(V)));
+        const tv t = *(const tv*)p;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = (float)t[k];
+    } else {
+        o[0] = (float)p[0];
+    }
+}
+template <int V, typename T>
+__device__ __forceinline__ void lg_store(T* __restrict__ p, const float (&o)[V]) {
+    if constexpr (V > 1) {
+        typedef T tv __attribute__((ext_vector_type(V)));
+        typedef float fv __attribute__((ext_vector_type(V)));
+        fv f;
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = o[k];
+        *(tv*)p = __builtin_convertvector(f, tv);
+    } else {
+        p[0] = (T)o[0];
+    }
+}
+
+template <int V, typename GT, typename DT = float, typename ST = float>
+__global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C, int HW, const DT* __restrict__ dh,
+                                                                    const ST* __restrict__ dc_next, const GT* __restrict__ gates,
+                                                                    const ST* __restrict__ c_prev, const ST* __restrict__ c_cur,
+                                                                    ST* __restrict__ dc_prev, unsigned char* __restrict__ packed,
                                                                     float* __restrict__ dbias, int iters, int split) {
     const int kp = blockIdx.y;                     // hidden-channel pair 2 kp, 2 kp + 1 = item kp of every pixel
     const long ng = blockIdx.z;
@@ -845,17 +873,10 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C
 #pragma unroll
                 for (int k = 0; k < V; ++k) { gi[k] = (float)gp[k]; gf[k] = (float)gp[cs + k]; go[k] = (float)gp[2 * cs + k]; gg[k] = (float)gp[3 * cs + k]; }
             }
-            if constexpr (V > 1) {
-                typedef float fv __attribute__((ext_vector_type(V)));
-                *(fv*)cc = *(const fv*)(c_cur + e);
-                *(fv*)dhv = *(const fv*)(dh + e);
-                if (dc_next) *(fv*)dcn = *(const fv*)(dc_next + e);
-                if (c_prev) *(fv*)cp = *(const fv*)(c_prev + e);
-            } else {
-                cc[0] = c_cur[e]; dhv[0] = dh[e];
-                if (dc_next) dcn[0] = dc_next[e];
-                if (c_prev) cp[0] = c_prev[e];
-            }
+            lg_load<V, ST>(c_cur + e, cc);
+            lg_load<V, DT>(dh + e, dhv);
+            if (dc_next) lg_load<V, ST>(dc_next + e, dcn);
+            if (c_prev) lg_load<V, ST>(c_prev + e, cp);
             float dcp[V];
 #pragma unroll
             for (int k = 0; k < V; ++k) {
@@ -869,12 +890,7 @@ __global__ __launch_bounds__(256) void lstm_gates_bwd_cmajor_kernel(int G, int C
                 o[3][h][k] = dc * gi[k] * (1.f - gg[k] * gg[k]);
                 dcp[k] = dc * gf[k];
             }
-            if constexpr (V > 1) {
-                typedef float fv __attribute__((ext_vector_type(V)));
-                *(fv*)(dc_prev + e) = *(fv*)dcp;
-            } else {
-                dc_prev[e] = dcp[0];
-            }
+            lg_store<V, ST>(dc_prev + e, dcp);
         }
         unsigned char* op = packed + cd_item_off(ng, ng8, kp, HW, pix, split);        // (split-bf16: hi plane, lo plane behind it)
 #pragma unroll
@@ -910,13 +926,23 @@ extern "C" int jaf_convlstm_gates_bwd_packed(jaf_stream_t s, int32_t N, int32_t 
 extern "C" int jaf_convlstm_gates_bwd_packed_prec(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const float* dh,
                                                   const float* dc_next, const void* gates, int gates_bf16, const float* c_prev,
                                                   const float* c_cur, float* dc_prev, void* packed, float* dbias, int precision) {
+    return jaf_convlstm_gates_bwd_packed_dt(s, N, G, C, HW, dh, 0, dc_next, gates, gates_bf16, c_prev, c_cur, dc_prev, 0, packed, dbias,
+                                            precision);
+}
+
+extern "C" int jaf_convlstm_gates_bwd_packed_dt(jaf_stream_t s, int32_t N, int32_t G, int32_t C, int32_t HW, const void* dh,
+                                                int dh_bf16, const void* dc_next, const void* gates, int gates_bf16,
+                                                const void* c_prev, const void* c_cur, void* dc_prev, int state_bf16, void* packed,
+                                                float* dbias, int precision) {
     JAF_REQUIRE(dh && gates && c_cur && dc_prev && packed && dbias && N >= 1 && G >= 1 && C >= 4 && HW >= 1);
     JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    JAF_REQUIRE(!(dh_bf16 || state_bf16) || (precision == JAF_PREC_BF16 && gates_bf16));
     const int split = precision == JAF_PREC_BF16X3 ? 1 : 0;
     if (C % 4) return JAF_EUNSUPPORTED;
     JAF_REQUIRE(C / 2 <= 65535 && (long)N * G <= 65535);
     const uintptr_t al = ((uintptr_t)dh) | ((uintptr_t)gates) | ((uintptr_t)c_cur) | ((uintptr_t)dc_prev) |
                          ((uintptr_t)dc_next) | ((uintptr_t)c_prev);
+    // (bf16 tensors: V elements are 2 V bytes, so the fp32 alignment conditions more than cover them)
     const bool v4 = (HW % 4 == 0) && (al & 15) == 0;
     const bool v2 = (HW % 2 == 0) && (al & 7) == 0;
     const int V = v4 ? 4 : (v2 ? 2 : 1);
@@ -926,11 +952,16 @@ extern "C" int jaf_convlstm_gates_bwd_packed_prec(jaf_stream_t s, int32_t N, int
     static const int it_env = getenv("JAF_LSTM_GATES_ITERS") ? atoi(getenv("JAF_LSTM_GATES_ITERS")) : 0;
     const int iters = it_env > 0 ? it_env : 1;
     const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 2, N * G);
-#define JAF_LGC(V_, T_)                                                                                          \
-    hipLaunchKernelGGL((lstm_gates_bwd_cmajor_kernel<V_, T_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, dh, dc_next, \
-                       (const T_*)gates, c_prev, c_cur, dc_prev, (unsigned char*)packed, dbias, iters, split)
-    if (gates_bf16) { if (v4) JAF_LGC(4, __bf16); else if (v2) JAF_LGC(2, __bf16); else JAF_LGC(1, __bf16); }
-    else { if (v4) JAF_LGC(4, float); else if (v2) JAF_LGC(2, float); else JAF_LGC(1, float); }
+#define JAF_LGC(V_, T_, D_, S_)                                                                                  \
+    hipLaunchKernelGGL((lstm_gates_bwd_cmajor_kernel<V_, T_, D_, S_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, (const D_*)dh, \
+                       (const S_*)dc_next, (const T_*)gates, (const S_*)c_prev, (const S_*)c_cur, (S_*)dc_prev, (unsigned char*)packed, \
+                       dbias, iters, split)
+#define JAF_LGV(T_, D_, S_) do { if (v4) JAF_LGC(4, T_, D_, S_); else if (v2) JAF_LGC(2, T_, D_, S_); else JAF_LGC(1, T_, D_, S_); } while (0)
+    if (state_bf16) { if (dh_bf16) JAF_LGV(__bf16, __bf16, __bf16); else JAF_LGV(__bf16, float, __bf16); }
+    else if (dh_bf16) return JAF_EUNSUPPORTED;          // (a bf16 dh only arises beside a bf16 state)
+    else if (gates_bf16) JAF_LGV(__bf16, float, float);
+    else JAF_LGV(float, float, float);
+#undef JAF_LGV
 #undef JAF_LGC
     return jaf_launch_status();
 }
@@ -1074,7 +1105,15 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int ch = ((mb * MR + mt * 16) >> 2) + q;
-            if (ch < C) cpre[mt] = *(const f32x4*)(a.c_prev + (((long)n * d.G + g) * C + ch) * OHW + opix[0]);
+            if (ch < C) {
+                const long co_ = (((long)n * d.G + g) * C + ch) * OHW + opix[0];
+                if (a.state_bf16) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    cpre[mt] = __builtin_convertvector(*(const bf16x4*)((const __bf16*)a.c_prev + co_), f32x4);
+                } else {
+                    cpre[mt] = *(const f32x4*)(a.c_prev + co_);
+                }
+            }
         }
     }
 
@@ -1420,6 +1459,7 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.dz_mask_ng8 = a.dz_mask_coff = 0;
     a.dz_slope = 0.f;
     a.dz_dbias = nullptr;
+    a.out_bf16 = a.out2_bf16 = a.state_bf16 = 0;
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1446,6 +1486,10 @@ static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm)
     }
     if (io->accumulate_f32 && (lstm || (io->skip_f32 && !io->dz_mask))) return false;
     if (io->out2 && (lstm || io->skip_f32 || (io->dst && !io->dz_mask) || io->split_rows < 1 || io->split_rows >= d->Cout)) return false;
+    // bf16 storage of the NCHW outputs / the cell state: bf16 arithmetic only (the parity-grade modes keep fp32 tensors)
+    if ((io->out_bf16 || io->out2_bf16 || io->state_bf16) && d->precision != JAF_PREC_BF16) return false;
+    if (io->state_bf16 && !lstm) return false;
+    if ((io->out_bf16 || io->out2_bf16) && lstm) return false;
     return true;
 }
 
@@ -1466,6 +1510,9 @@ static void cd_apply_io(ConvDArgs& a, const jaf_packed_io* io) {
     a.dz_dbias = io->dz_dbias;
     a.out2 = io->out2;
     a.split = io->out2 ? io->split_rows : 0;
+    a.out_bf16 = io->out_bf16 ? 1 : 0;
+    a.out2_bf16 = (io->out2 && io->out2_bf16) ? 1 : 0;
+    a.state_bf16 = io->state_bf16 ? 1 : 0;
 }
 
 extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,

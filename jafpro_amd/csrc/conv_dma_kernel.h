@@ -45,6 +45,9 @@ struct ConvDArgs {
     int dz_mask_ng8, dz_mask_coff;
     float dz_slope;
     float* dz_dbias;
+    // bf16 STORAGE of the NCHW tensors this launch writes (jaf_packed_io.out_bf16 / out2_bf16 / state_bf16; bf16 arithmetic only):
+    // `out` (and what acc_out reads), `out2`, and the ConvLSTM's cell state (c_prev read, c_out written) hold bf16 instead of fp32
+    int out_bf16, out2_bf16, state_bf16;
 };
 
 // Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
@@ -87,24 +90,32 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
         // the launch writes ONE fp32 tensor and nothing else (no packed image, statistics, accumulation or second output):
         // its own instantiation, so that the registers of those features are not carried through the matrix-core loop
         typedef float pvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
+        typedef __bf16 phvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
         const bool pv = a.vec && (NT > 1);
+        const bool hb = a.out_bf16 != 0;
 #define CD_EPILOGUE_PLAIN(ACT_)                                                                       \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
                 if (co < d.Cout) {                                                                    \
                     const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
-                    float* op = a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;  \
+                    const long ooff = ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;    \
+                    float* op = a.out + ooff;                                                         \
+                    __bf16* hp = (__bf16*)a.out + ooff;      /* out_bf16: the same tensor in bf16 */   \
                     if (pv) {                                                                         \
                         if (opix[0] >= 0) {                                                           \
                             pvec o;                                                                   \
                             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
                                 o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
-                            *(pvec*)(op + opix[0]) = o;                                               \
+                            if (hb) *(phvec*)(hp + opix[0]) = __builtin_convertvector(o, phvec);      \
+                            else *(pvec*)(op + opix[0]) = o;                                          \
                         }                                                                             \
                     } else {                                                                          \
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
-                            if (opix[nt] >= 0) op[opix[nt]] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope); \
+                            if (opix[nt] >= 0) {                                                      \
+                                const float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);           \
+                                if (hb) hp[opix[nt]] = (__bf16)v; else op[opix[nt]] = v;             \
+                            }                                                                         \
                     }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
@@ -176,18 +187,26 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) part[j][nt] = 0.f;
                         if (co0 + j < dC) {
-                            const float* pp = a.out2 ? a.out + (((long)n * d.G + g) * a.split + co0 + j) * OHW
-                                                     : a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co0 + j) * OHW;
+                            const long poff = a.out2 ? (((long)n * d.G + g) * a.split + co0 + j) * OHW
+                                                     : ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co0 + j) * OHW;
+                            const float* pp = a.out + poff;
+                            const __bf16* ph = (const __bf16*)a.out + poff;
                             if (vec) {
                                 if (opix[0] >= 0) {
-                                    const fvec pv = *(const fvec*)(pp + opix[0]);
+                                    if (a.out_bf16) {
+                                        const hvec pv = *(const hvec*)(ph + opix[0]);
 #pragma unroll
-                                    for (int nt = 0; nt < NT; ++nt) part[j][nt] = pv[nt];
+                                        for (int nt = 0; nt < NT; ++nt) part[j][nt] = (float)pv[nt];
+                                    } else {
+                                        const fvec pv = *(const fvec*)(pp + opix[0]);
+#pragma unroll
+                                        for (int nt = 0; nt < NT; ++nt) part[j][nt] = pv[nt];
+                                    }
                                 }
                             } else {
 #pragma unroll
                                 for (int nt = 0; nt < NT; ++nt)
-                                    if (opix[nt] >= 0) part[j][nt] = pp[opix[nt]];
+                                    if (opix[nt] >= 0) part[j][nt] = a.out_bf16 ? (float)ph[opix[nt]] : pp[opix[nt]];
                             }
                         }
                     }
@@ -294,24 +313,22 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             }
         }
         if (a.skip_f32 || (DZ && !a.out2)) return;
-#define CD_EPILOGUE(ACT_, ST_)                                                                        \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-                const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
-                if (co < d.Cout && !(DZ && co < a.split)) {      /* (dz rows went to `dst`) */  \
-                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
-                    const bool second = a.out2 && co >= a.split;                                      \
-                    float* op = second ? a.out2 + (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW \
-                                       : (a.out2 ? a.out + (((long)n * d.G + g) * a.split + co) * OHW        \
-                                                 : a.out + ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW);  \
-                    const bool accp = a.acc_out && !second;                                           \
+// one output row (channel `co`) of the lane's NT pixels: OP_ / HP_ = the row's base as fp32 / bf16 elements, HB_: bf16 storage,
+// ACCP_: add what is there (GradSlot).  A macro, not a pointer select: selecting between the kernel's two output pointers at run
+// time made the compiler park them in scratch memory.
+#define CD_STORE_ROW(ACT_, ST_, OP_, HP_, HB_, ACCP_)                                                 \
                     if (vec) {                                                                        \
                         if (opix[0] >= 0) {                                                           \
                             fvec o;                                                                   \
                             _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                         \
                                 o[nt] = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                   \
-                            if (accp) o += *(const fvec*)(op + opix[0]);                              \
-                            *(fvec*)(op + opix[0]) = o;                                               \
+                            if (HB_) {                                                                \
+                                if (ACCP_) o += __builtin_convertvector(*(const hvec*)((HP_) + opix[0]), fvec); \
+                                *(hvec*)((HP_) + opix[0]) = __builtin_convertvector(o, hvec);         \
+                            } else {                                                                  \
+                                if (ACCP_) o += *(const fvec*)((OP_) + opix[0]);                      \
+                                *(fvec*)((OP_) + opix[0]) = o;                                        \
+                            }                                                                         \
                             if (ST_) {                                                                \
                                 _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { st1 += o[nt]; st2 += o[nt] * o[nt]; } \
                             }                                                                         \
@@ -320,10 +337,29 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                             \
                             if (opix[nt] >= 0) {                                                      \
                                 float v = jaf_act(acc[mt][nt][j] + b, ACT_, d.slope);                 \
-                                if (accp) v += op[opix[nt]];                                          \
-                                op[opix[nt]] = v;                                                     \
+                                if (HB_) {                                                            \
+                                    if (ACCP_) v += (float)(HP_)[opix[nt]];                           \
+                                    (HP_)[opix[nt]] = (__bf16)v;                                      \
+                                } else {                                                              \
+                                    if (ACCP_) v += (OP_)[opix[nt]];                                  \
+                                    (OP_)[opix[nt]] = v;                                              \
+                                }                                                                     \
                                 if (ST_) { st1 += v; st2 += v * v; }                                  \
                             }                                                                         \
+                    }
+#define CD_EPILOGUE(ACT_, ST_)                                                                        \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+                const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
+                if (co < d.Cout && !(DZ && co < a.split)) {      /* (dz rows went to `dst`) */  \
+                    const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
+                    if (a.out2 && co >= a.split) {                                                    \
+                        const long ooff = (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW; \
+                        CD_STORE_ROW(ACT_, ST_, a.out2 + ooff, (__bf16*)a.out2 + ooff, a.out2_bf16, false)   \
+                    } else {                                                                          \
+                        const long ooff = a.out2 ? (((long)n * d.G + g) * a.split + co) * OHW         \
+                                                 : ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW; \
+                        CD_STORE_ROW(ACT_, ST_, a.out + ooff, (__bf16*)a.out + ooff, a.out_bf16, a.acc_out)  \
                     }                                                                                 \
                 }                                                                                     \
             }                                                                                         \
@@ -338,6 +374,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 break;
         }
 #undef CD_EPILOGUE
+#undef CD_STORE_ROW
         if (a.stats) {      // uniform: wave sums -> LDS -> one pair of fp64 atomics per workgroup, spread over slots
             st1 = jaf_wave_sum(st1);
             st2 = jaf_wave_sum(st2);
@@ -374,6 +411,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     if (NT == 4) {                      // fetched before the matrix-core loop (conv_dma_kernel): no exposed latency here
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) cp[nt] = cpre[mt][nt & 3];
+                    } else if (a.state_bf16) {
+                        cp = __builtin_convertvector(*(const hvec*)((const __bf16*)a.c_prev + hc + opix[0]), fvec);
                     } else {
                         cp = *(const fvec*)(a.c_prev + hc + opix[0]);
                     }
@@ -390,7 +429,8 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     hs4[nt & 3] = vh[nt];
                 }
                 if (live) {
-                    *(fvec*)(a.c_out + hc + opix[0]) = vc;
+                    if (a.state_bf16) *(hvec*)((__bf16*)a.c_out + hc + opix[0]) = __builtin_convertvector(vc, hvec);
+                    else *(fvec*)(a.c_out + hc + opix[0]) = vc;
                     if (!a.skip_f32) *(fvec*)(a.h_out + hc + opix[0]) = vh;
                 }
                 if (a.dst) {     // h_t straight into the consumer's packed image (next step's [x, h] / the decoder's skip)
@@ -455,9 +495,10 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     const float gf = jaf_sigmoid(acc[mt][nt][1] + bf);
                     const float go = jaf_sigmoid(acc[mt][nt][2] + bo);
                     const float gg = jaf_tanh(acc[mt][nt][3] + bg);
-                    const float cp = a.c_prev ? a.c_prev[hc + opix[nt]] : 0.f;
+                    const float cp = a.c_prev ? (a.state_bf16 ? (float)((const __bf16*)a.c_prev)[hc + opix[nt]] : a.c_prev[hc + opix[nt]]) : 0.f;
                     const float cc = gf * cp + gi * gg;
-                    a.c_out[hc + opix[nt]] = cc;
+                    if (a.state_bf16) ((__bf16*)a.c_out)[hc + opix[nt]] = (__bf16)cc;
+                    else a.c_out[hc + opix[nt]] = cc;
                     const float hv = go * jaf_tanh(cc);
                     if (!a.skip_f32) a.h_out[hc + opix[nt]] = hv;
                     if (a.dst) {

@@ -107,3 +107,30 @@ __device__ __forceinline__ float jaf_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+
+// V consecutive elements of an fp32 or bf16 tensor as floats (one 4V- or 2V-byte access) and back (RNE): the I/O of the HBM-bound
+// kernels that serve both storage formats of the bf16 mode (fp32 tensors, and the bf16 ones of BASELINE configs[2]'s storage).
+template <int V, typename T>
+__device__ __forceinline__ void jaf_ldv(const T* __restrict__ p, float (&o)[V]) {
+    if constexpr (V > 1) {
+        typedef T tv __attribute__((ext_vector_type(V)));
+        const tv t = *(const tv*)p;
+#pragma unroll
+        for (int k = 0; k < V; ++k) o[k] = (float)t[k];
+    } else {
+        o[0] = (float)p[0];
+    }
+}
+template <int V, typename T>
+__device__ __forceinline__ void jaf_stv(T* __restrict__ p, const float (&o)[V]) {
+    if constexpr (V > 1) {
+        typedef T tv __attribute__((ext_vector_type(V)));
+        typedef float fv __attribute__((ext_vector_type(V)));
+        fv f;
+#pragma unroll
+        for (int k = 0; k < V; ++k) f[k] = o[k];
+        *(tv*)p = __builtin_convertvector(f, tv);
+    } else {
+        p[0] = (T)o[0];
+    }
+}

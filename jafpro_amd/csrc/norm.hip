@@ -108,46 +108,46 @@ extern "C" int jaf_layernorm_stats(jaf_stream_t s_, const float* x, int32_t N, i
     return jaf_launch_status();
 }
 
-// grid (pixel blocks, C, N)
-template <int V>
-__global__ void ln_lrelu_fwd_kernel(const float* x, const float* stats, const float* gamma, const float* beta,
+// grid (pixel blocks, C, N).  XT: element type of x (fp32, or bf16: the pre-LayerNorm convolution output under bf16 storage).
+template <int V, typename XT>
+__global__ void ln_lrelu_fwd_kernel(const XT* x, const float* stats, const float* gamma, const float* beta,
                                     float* y, int C, int HW, float slope) {
     const int c = blockIdx.y, n = blockIdx.z;
     const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
     if (pix >= HW) return;
     const long e = ((long)n * C + c) * HW + pix;
     const float mean = stats[2 * n], r = stats[2 * n + 1], g = gamma[c], b = beta[c];
-    if (V == 4) {
-        const f32x4 xv = *(const f32x4*)(x + e);
-        f32x4 o;
+    float xv[V], o[V];
+    jaf_ldv<V, XT>(x + e, xv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float z = (xv[k] - mean) * r * g + b;
-            o[k] = z > 0.f ? z : z * slope;
-        }
-        *(f32x4*)(y + e) = o;
-    } else {
-        const float z = (x[e] - mean) * r * g + b;
-        y[e] = z > 0.f ? z : z * slope;
+    for (int k = 0; k < V; ++k) {
+        const float z = (xv[k] - mean) * r * g + b;
+        o[k] = z > 0.f ? z : z * slope;
     }
+    jaf_stv<V, float>(y + e, o);
 }
 
 extern "C" int jaf_layernorm_lrelu_fwd(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                                        const float* beta, float* y, int32_t N, int32_t C, int32_t HW, float slope) {
+    return jaf_layernorm_lrelu_fwd_dt(s, x, 0, stats, gamma, beta, y, N, C, HW, slope);
+}
+
+extern "C" int jaf_layernorm_lrelu_fwd_dt(jaf_stream_t s, const void* x, int x_bf16, const float* stats, const float* gamma,
+                                          const float* beta, float* y, int32_t N, int32_t C, int32_t HW, float slope) {
     JAF_REQUIRE(x && stats && gamma && beta && y && N >= 1 && C >= 1 && HW >= 1 && C <= 65535 && N <= 65535);
-    if ((HW % 4 == 0) && al16(x, y))
-        hipLaunchKernelGGL(ln_lrelu_fwd_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, (hipStream_t)s, x, stats,
-                           gamma, beta, y, C, HW, slope);
-    else
-        hipLaunchKernelGGL(ln_lrelu_fwd_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, (hipStream_t)s, x, stats,
-                           gamma, beta, y, C, HW, slope);
+    const bool v4 = (HW % 4 == 0) && al16(x, y);
+#define JAF_LNF(V_, T_) hipLaunchKernelGGL((ln_lrelu_fwd_kernel<V_, T_>), dim3(jaf_cdiv(HW / V_, 256), C, N), dim3(256), 0, (hipStream_t)s, \
+                                           (const T_*)x, stats, gamma, beta, y, C, HW, slope)
+    if (x_bf16) { if (v4) JAF_LNF(4, __bf16); else JAF_LNF(1, __bf16); }
+    else { if (v4) JAF_LNF(4, float); else JAF_LNF(1, float); }
+#undef JAF_LNF
     return jaf_launch_status();
 }
 
 // Same, and ALSO written as the consumer convolution's packed bf16 image [n][ng8][HW][8] (jaf_packed_io): a lane
 // owns 8 channels x V pixels so that every 16-byte item it stores is complete.  grid (pixel blocks, ceil(C/8), N).
-template <int V>
-__global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+template <int V, typename XT>
+__global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const XT* __restrict__ x, const float* __restrict__ stats,
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   float* __restrict__ y, unsigned char* __restrict__ dst, int dst_ng8,
                                                                   int dst_cg0, int C, int HW, float slope, int split) {
@@ -167,21 +167,14 @@ __global__ __launch_bounds__(256) void ln_lrelu_fwd_packed_kernel(const float* _
         if (c < C) {
             const long e = ((long)n * C + c) * HW + pix;
             const float g = gamma[c], b = beta[c];
-            if (V == 4) {
-                const f32x4 xv = *(const f32x4*)(x + e);
-                f32x4 ov;
+            float xv[V];
+            jaf_ldv<V, XT>(x + e, xv);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float z = (xv[k] - mean) * r * g + b;
-                    ov[k] = z > 0.f ? z : z * slope;
-                    o[j][k] = ov[k];
-                }
-                if (y) *(f32x4*)(y + e) = ov;
-            } else {
-                const float z = (x[e] - mean) * r * g + b;
-                o[j][0] = z > 0.f ? z : z * slope;
-                if (y) y[e] = o[j][0];
+            for (int k = 0; k < V; ++k) {
+                const float z = (xv[k] - mean) * r * g + b;
+                o[j][k] = z > 0.f ? z : z * slope;
             }
+            if (y) jaf_stv<V, float>(y + e, o[j]);
         }
     }
     // split-bf16 destination: group cg's hi plane at 2 cg, the residual plane (v - bf16(v)) right behind it
@@ -216,17 +209,25 @@ extern "C" int jaf_layernorm_lrelu_fwd_packed(jaf_stream_t s, const float* x, co
 extern "C" int jaf_layernorm_lrelu_fwd_packed_prec(jaf_stream_t s, const float* x, const float* stats, const float* gamma,
                                               const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
                                               int32_t N, int32_t C, int32_t HW, float slope, int precision) {
+    return jaf_layernorm_lrelu_fwd_packed_dt(s, x, 0, stats, gamma, beta, y, dst, dst_ng8_tot, dst_coff, N, C, HW, slope, precision);
+}
+
+extern "C" int jaf_layernorm_lrelu_fwd_packed_dt(jaf_stream_t s, const void* x, int x_bf16, const float* stats, const float* gamma,
+                                                 const float* beta, float* y, void* dst, int32_t dst_ng8_tot, int32_t dst_coff,
+                                                 int32_t N, int32_t C, int32_t HW, float slope, int precision) {
     JAF_REQUIRE(x && stats && gamma && beta && dst && N >= 1 && C >= 1 && HW >= 1 && N <= 65535);
     JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    JAF_REQUIRE(!x_bf16 || precision == JAF_PREC_BF16);
     const int split = precision == JAF_PREC_BF16X3 ? 1 : 0;
     JAF_REQUIRE(dst_coff >= 0 && (dst_coff & 7) == 0 && dst_coff / 8 + jaf_cdiv(C, 8) <= dst_ng8_tot && jaf_cdiv(C, 8) <= 65535);
     const dim3 block(256);
-    if ((HW % 4 == 0) && al16(x, y))
-        hipLaunchKernelGGL(ln_lrelu_fwd_packed_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), jaf_cdiv(C, 8), N), block, 0, (hipStream_t)s, x,
-                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope, split);
-    else
-        hipLaunchKernelGGL(ln_lrelu_fwd_packed_kernel<1>, dim3(jaf_cdiv(HW, 256), jaf_cdiv(C, 8), N), block, 0, (hipStream_t)s, x,
-                           stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot, dst_coff / 8, C, HW, slope, split);
+    const bool v4 = (HW % 4 == 0) && al16(x, y);
+#define JAF_LNP(V_, T_) hipLaunchKernelGGL((ln_lrelu_fwd_packed_kernel<V_, T_>), dim3(jaf_cdiv(HW / V_, 256), jaf_cdiv(C, 8), N), block, 0, \
+                                           (hipStream_t)s, (const T_*)x, stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot,          \
+                                           dst_coff / 8, C, HW, slope, split)
+    if (x_bf16) { if (v4) JAF_LNP(4, __bf16); else JAF_LNP(1, __bf16); }
+    else { if (v4) JAF_LNP(4, float); else JAF_LNP(1, float); }
+#undef JAF_LNP
     return jaf_launch_status();
 }
 
@@ -234,8 +235,8 @@ extern "C" int jaf_layernorm_lrelu_fwd_packed_prec(jaf_stream_t s, const float* 
 // ws[n][c % 16][0] += gamma_c*a (S1), ws[n][c % 16][1] += gamma_c*b (S2): the C workgroups of one image spread their
 // fp64 atomics over 16 slots (one address per image cost a ~21 us floor per launch), folded by ln_bwd_fold_kernel.
 #define LN_BWD_SLOTS 16
-template <int V>
-__global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const float* stats, const float* gamma,
+template <int V, typename DT, typename XT>
+__global__ void ln_bwd_reduce_kernel(const DT* dy, const XT* x, const float* stats, const float* gamma,
                                      const float* beta, float* dgamma, float* dbeta, double* ws, int C, int HW,
                                      float slope, float* cn /* nullable: [N][C][2] = (gamma_c * sum dz, sum xhat) */) {
     const int c = blockIdx.x;
@@ -245,10 +246,10 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
     const float g = gamma[c], b = beta[c];
     double sa = 0.0, sb = 0.0, sx = 0.0;
     if (V == 4) {
-        const f32x4* x4 = (const f32x4*)(x + base);
-        const f32x4* d4 = (const f32x4*)(dy + base);
         for (int i = threadIdx.x; i < (HW >> 2); i += blockDim.x) {
-            const f32x4 xv = x4[i], dv = d4[i];
+            float xv[4], dv[4];
+            jaf_ldv<4, XT>(x + base + 4 * i, xv);
+            jaf_ldv<4, DT>(dy + base + 4 * i, dv);
             float pa = 0.f, pb = 0.f, px = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -265,9 +266,9 @@ __global__ void ln_bwd_reduce_kernel(const float* dy, const float* x, const floa
         }
     } else {
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-            const float xh = (x[base + i] - mean) * r;
+            const float xh = ((float)x[base + i] - mean) * r;
             const float z = xh * g + b;
-            const float dz = dy[base + i] * (z > 0.f ? 1.f : slope);
+            const float dz = (float)dy[base + i] * (z > 0.f ? 1.f : slope);
             sa += (double)dz;
             sb += (double)dz * (double)xh;
             sx += (double)xh;
@@ -305,10 +306,10 @@ __global__ void ln_bwd_fold_kernel(double* ws, int N) {
     w[1] = s2;
 }
 
-// grid (pixel blocks, C, N)
-template <int V>
-__global__ void ln_bwd_apply_kernel(const float* dy, const float* x, const float* stats, const float* gamma,
-                                    const float* beta, const double* ws, float* dx, int C, int HW, float slope,
+// grid (pixel blocks, C, N).  dx takes x's element type.
+template <int V, typename DT, typename XT>
+__global__ void ln_bwd_apply_kernel(const DT* dy, const XT* x, const float* stats, const float* gamma,
+                                    const float* beta, const double* ws, XT* dx, int C, int HW, float slope,
                                     float eps) {
     const int c = blockIdx.y, n = blockIdx.z;
     const int pix = (blockIdx.x * blockDim.x + threadIdx.x) * V;
@@ -322,47 +323,52 @@ __global__ void ln_bwd_apply_kernel(const float* dy, const float* x, const float
     // S2 / ((M-1) * sigma * r)
     const float kk = (sigma > 0.f) ? (float)(w[1] / ((M - 1.0) * (double)sigma * (double)r)) : 0.f;
     const float g = gamma[c], b = beta[c];
-    if (V == 4) {
-        const f32x4 xv = *(const f32x4*)(x + e), dv = *(const f32x4*)(dy + e);
-        f32x4 o;
+    float xv[V], dv[V], o[V];
+    jaf_ldv<V, XT>(x + e, xv);
+    jaf_ldv<V, DT>(dy + e, dv);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float xh = (xv[k] - mean) * r;
-            const float z = xh * g + b;
-            const float dxh = dv[k] * (z > 0.f ? 1.f : slope) * g;
-            o[k] = r * (dxh - m1 - xh * kk);
-        }
-        *(f32x4*)(dx + e) = o;
-    } else {
-        const float xh = (x[e] - mean) * r;
+    for (int k = 0; k < V; ++k) {
+        const float xh = (xv[k] - mean) * r;
         const float z = xh * g + b;
-        const float dxh = dy[e] * (z > 0.f ? 1.f : slope) * g;
-        dx[e] = r * (dxh - m1 - xh * kk);
+        const float dxh = dv[k] * (z > 0.f ? 1.f : slope) * g;
+        o[k] = r * (dxh - m1 - xh * kk);
     }
+    jaf_stv<V, XT>(dx + e, o);
 }
 
 extern "C" int jaf_layernorm_lrelu_bwd(jaf_stream_t s_, const float* dy, const float* x, const float* stats,
                                        const float* gamma, const float* beta, float* dx, float* dgamma,
                                        float* dbeta, double* workspace, int32_t N, int32_t C, int32_t HW,
                                        float slope, float eps) {
+    return jaf_layernorm_lrelu_bwd_dt(s_, dy, 0, x, 0, stats, gamma, beta, dx, dgamma, dbeta, workspace, N, C, HW, slope, eps);
+}
+
+// LN_DISPATCH(F): F(V, DT, XT) for the element types of dy and x given at run time
+#define LN_DISPATCH(F, V_)                                                       \
+    do {                                                                         \
+        if (dy_bf16) { if (x_bf16) F(V_, __bf16, __bf16); else F(V_, __bf16, float); } \
+        else { if (x_bf16) F(V_, float, __bf16); else F(V_, float, float); }     \
+    } while (0)
+
+extern "C" int jaf_layernorm_lrelu_bwd_dt(jaf_stream_t s_, const void* dy, int dy_bf16, const void* x, int x_bf16, const float* stats,
+                                          const float* gamma, const float* beta, void* dx, float* dgamma,
+                                          float* dbeta, double* workspace, int32_t N, int32_t C, int32_t HW,
+                                          float slope, float eps) {
     JAF_REQUIRE(dy && x && stats && gamma && beta && dx && dgamma && dbeta && workspace);
     JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535 && C <= 65535);
     hipStream_t s = (hipStream_t)s_;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * LN_BWD_SLOTS * N, s);
     if (e != hipSuccess) return (int)e;
-    if ((HW % 4 == 0) && al16(dy, x, dx)) {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel<4>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                           workspace, C, HW, slope, (float*)nullptr);
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
-        hipLaunchKernelGGL(ln_bwd_apply_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
-                           beta, workspace, dx, C, HW, slope, eps);
-    } else {
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel<1>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                           workspace, C, HW, slope, (float*)nullptr);
-        hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
-        hipLaunchKernelGGL(ln_bwd_apply_kernel<1>, dim3(jaf_cdiv(HW, 256), C, N), dim3(256), 0, s, dy, x, stats, gamma,
-                           beta, workspace, dx, C, HW, slope, eps);
-    }
+    const bool v4 = (HW % 4 == 0) && al16(dy, x, dx);
+#define LN_RED(V_, D_, X_) hipLaunchKernelGGL((ln_bwd_reduce_kernel<V_, D_, X_>), dim3(C, N), dim3(256), 0, s, (const D_*)dy, (const X_*)x, stats, \
+                                              gamma, beta, dgamma, dbeta, workspace, C, HW, slope, (float*)nullptr)
+#define LN_APP(V_, D_, X_) hipLaunchKernelGGL((ln_bwd_apply_kernel<V_, D_, X_>), dim3(jaf_cdiv(HW / V_, 256), C, N), dim3(256), 0, s,           \
+                                              (const D_*)dy, (const X_*)x, stats, gamma, beta, workspace, (X_*)dx, C, HW, slope, eps)
+    if (v4) LN_DISPATCH(LN_RED, 4); else LN_DISPATCH(LN_RED, 1);
+    hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
+    if (v4) LN_DISPATCH(LN_APP, 4); else LN_DISPATCH(LN_APP, 1);
+#undef LN_RED
+#undef LN_APP
     return jaf_launch_status();
 }
 
@@ -370,8 +376,8 @@ extern "C" int jaf_layernorm_lrelu_bwd(jaf_stream_t s_, const float* dy, const f
 // -> LeakyReLU blocks, src/crn_model.py:90-106) in the form its data / weight gradient kernels read: dx as a packed bf16
 // image [n][ceil(C/8)][HW][8] -- a lane owns 8 channels x V pixels, as in ln_lrelu_fwd_packed_kernel -- instead of an fp32
 // tensor that jaf_conv2d_pack_dz would read back (4 + 4 + 2 bytes per element become 2).  grid (pixel blocks, ceil(C/8), N).
-template <int V>
-__global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int V, typename DT, typename XT>
+__global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const DT* __restrict__ dy, const XT* __restrict__ x,
                                                                   const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, const double* __restrict__ ws,
                                                                   unsigned char* __restrict__ dst, int C, int HW, float slope, float eps, int split) {
@@ -396,20 +402,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_packed_kernel(const float* _
         if (c < C) {
             const long e = ((long)n * C + c) * HW + pix;
             const float g = gamma[c], b = beta[c];
-            if (V == 4) {
-                const f32x4 xv = *(const f32x4*)(x + e), dv = *(const f32x4*)(dy + e);
+            float xv[V], dv[V];
+            jaf_ldv<V, XT>(x + e, xv);
+            jaf_ldv<V, DT>(dy + e, dv);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float xh = (xv[k] - mean) * r;
-                    const float z = xh * g + b;
-                    const float dxh = dv[k] * (z > 0.f ? 1.f : slope) * g;
-                    o[j][k] = r * (dxh - m1 - xh * kk);
-                }
-            } else {
-                const float xh = (x[e] - mean) * r;
+            for (int k = 0; k < V; ++k) {
+                const float xh = (xv[k] - mean) * r;
                 const float z = xh * g + b;
-                const float dxh = dy[e] * (z > 0.f ? 1.f : slope) * g;
-                o[j][0] = r * (dxh - m1 - xh * kk);
+                const float dxh = dv[k] * (z > 0.f ? 1.f : slope) * g;
+                o[j][k] = r * (dxh - m1 - xh * kk);
             }
         }
     }
@@ -468,27 +469,34 @@ extern "C" int jaf_layernorm_lrelu_bwd_packed_prec(jaf_stream_t s_, const float*
                                                    float* dbeta, double* workspace, float* scratch, float* conv_dbias,
                                                    int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps,
                                                    int precision) {
+    return jaf_layernorm_lrelu_bwd_packed_dt(s_, dy, 0, x, 0, stats, gamma, beta, packed_dx, dgamma, dbeta, workspace, scratch, conv_dbias,
+                                             accumulate_dbias, N, C, HW, slope, eps, precision);
+}
+
+extern "C" int jaf_layernorm_lrelu_bwd_packed_dt(jaf_stream_t s_, const void* dy, int dy_bf16, const void* x, int x_bf16,
+                                                 const float* stats, const float* gamma, const float* beta, void* packed_dx,
+                                                 float* dgamma, float* dbeta, double* workspace, float* scratch, float* conv_dbias,
+                                                 int accumulate_dbias, int32_t N, int32_t C, int32_t HW, float slope, float eps,
+                                                 int precision) {
     JAF_REQUIRE(dy && x && stats && gamma && beta && packed_dx && dgamma && dbeta && workspace && scratch);
     JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    JAF_REQUIRE(!(dy_bf16 || x_bf16) || precision == JAF_PREC_BF16);
     const int split = precision == JAF_PREC_BF16X3 ? 1 : 0;
     JAF_REQUIRE(N >= 1 && C >= 1 && HW >= 1 && N <= 65535 && C <= 65535);
     hipStream_t s = (hipStream_t)s_;
     hipError_t e = hipMemsetAsync(workspace, 0, sizeof(double) * 2 * LN_BWD_SLOTS * N, s);
     if (e != hipSuccess) return (int)e;
     const bool v4 = (HW % 4 == 0) && al16(dy, x);
-    if (v4)
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel<4>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                           workspace, C, HW, slope, scratch);
-    else
-        hipLaunchKernelGGL(ln_bwd_reduce_kernel<1>, dim3(C, N), dim3(256), 0, s, dy, x, stats, gamma, beta, dgamma, dbeta,
-                           workspace, C, HW, slope, scratch);
+#define LN_RED(V_, D_, X_) hipLaunchKernelGGL((ln_bwd_reduce_kernel<V_, D_, X_>), dim3(C, N), dim3(256), 0, s, (const D_*)dy, (const X_*)x, stats, \
+                                              gamma, beta, dgamma, dbeta, workspace, C, HW, slope, scratch)
+#define LN_APP(V_, D_, X_) hipLaunchKernelGGL((ln_bwd_apply_packed_kernel<V_, D_, X_>), dim3(jaf_cdiv(HW / V_, 256), jaf_cdiv(C, 8), N), dim3(256), \
+                                              0, s, (const D_*)dy, (const X_*)x, stats, gamma, beta, workspace, (unsigned char*)packed_dx, C, HW,  \
+                                              slope, eps, split)
+    if (v4) LN_DISPATCH(LN_RED, 4); else LN_DISPATCH(LN_RED, 1);
     hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
-    if (v4)
-        hipLaunchKernelGGL(ln_bwd_apply_packed_kernel<4>, dim3(jaf_cdiv(HW / 4, 256), jaf_cdiv(C, 8), N), dim3(256), 0, s, dy, x, stats,
-                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps, split);
-    else
-        hipLaunchKernelGGL(ln_bwd_apply_packed_kernel<1>, dim3(jaf_cdiv(HW, 256), jaf_cdiv(C, 8), N), dim3(256), 0, s, dy, x, stats,
-                           gamma, beta, workspace, (unsigned char*)packed_dx, C, HW, slope, eps, split);
+    if (v4) LN_DISPATCH(LN_APP, 4); else LN_DISPATCH(LN_APP, 1);
+#undef LN_RED
+#undef LN_APP
     if (conv_dbias)
         hipLaunchKernelGGL(ln_bwd_conv_bias_kernel, dim3(jaf_cdiv(C, 64)), dim3(64), 0, s, scratch, stats, workspace, conv_dbias, N, C,
                            HW, eps, accumulate_dbias ? 1 : 0);

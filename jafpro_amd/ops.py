@@ -101,6 +101,24 @@ def get_precision() -> str:
     return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
 
 
+# bf16 STORAGE in the "bf16" arithmetic mode (BASELINE configs[2] names bf16; SURVEY 8(d) "bf16 storage / fp32 accumulate"): tensors
+# that only kernels of this library read between two convolutions -- the ConvLSTM's cell state and its time-loop gradients, the
+# pre-LayerNorm convolution outputs of the CRN and the gradients flowing back into them -- are kept in bf16 instead of fp32.  Every
+# operand of every convolution is rounded to bf16 in that mode anyway; "f32" and "bf16x3" (the parity-grade modes) never use it.
+_BF16_STORAGE = True
+
+
+def set_bf16_storage(flag: bool) -> bool:
+    """False: the "bf16" mode keeps every NCHW tensor in fp32 as in rounds 1-4 (A/B and tests).  Returns the previous setting."""
+    global _BF16_STORAGE
+    prev, _BF16_STORAGE = _BF16_STORAGE, bool(flag)
+    return prev
+
+
+def bf16_storage_active() -> bool:
+    return _BF16_STORAGE and _PRECISION == PREC_BF16 and _PACKED_IMAGES
+
+
 class _arith:
     """`with _arith(ctx.mode):` -- a backward pass runs in the arithmetic its forward ran in, whatever
     set_precision says by then (its saved packed images / bf16 gates belong to that mode)."""
@@ -372,10 +390,13 @@ def packed_active() -> bool:
 
 
 def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_f32: bool = False,
-               accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0, dz_fuse=None) -> Optional[PackedIO]:
-    if prepacked is None and dst is None and not accumulate and out2 is None:
+               accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0, dz_fuse=None,
+               out_bf16: bool = False, state_bf16: bool = False) -> Optional[PackedIO]:
+    out2_bf16 = out2 is not None and out2.dtype == torch.bfloat16
+    if prepacked is None and dst is None and not accumulate and out2 is None and not (out_bf16 or state_bf16):
         return None
     io = PackedIO()
+    io.out_bf16, io.out2_bf16, io.state_bf16 = int(out_bf16), int(out2_bf16), int(state_bf16)
     if dz_fuse is not None:       # (mask image buffer, its planes per (image, group), channel offset, act' below zero, dbias or None)
         mbuf, mng8, mcoff, mslope, dbias = dz_fuse
         io.dz_mask, io.dz_mask_ng8, io.dz_mask_coff, io.dz_slope = mbuf.data_ptr(), int(mng8), int(mcoff), float(mslope)
@@ -713,8 +734,11 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
               w_cin_tot, w_cin_off, act, slope, out: Optional[torch.Tensor] = None, out_ctot=None, out_coff=0,
               xp: Optional[torch.Tensor] = None, want_xp: bool = False, ln_stats: Optional["LNStats"] = None,
               prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None, skip_f32: bool = False, lazy=None,
-              accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0, dz_fuse=None):
+              accumulate: bool = False, out2: Optional[torch.Tensor] = None, split: int = 0, dz_fuse=None,
+              out_dtype: Optional[torch.dtype] = None):
     """`accumulate`: out += result (packed bf16 path only; `out` must be given): see GradSlot.
+    `out_dtype` = torch.bfloat16 (bf16 arithmetic only, see bf16_storage_active): the NCHW result is stored in bf16; a given `out` /
+    `out2` says so by its own dtype.
     `dz_fuse`: the launch is a data gradient whose only output is the PRODUCER layer's packed dz in `dst` (jaf_packed_io.dz_mask).
     `out2`, `split`: rows >= split of every group go to out2 [N, G*(Cout-split), OH, OW], the others to `out` taken as
     [N, G*split, OH, OW] (pass out_ctot = G*Cout): jaf_packed_io.out2."""
@@ -728,7 +752,10 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             # element is never written.  Any op that is not packed-aware rejects it (not contiguous).
             out = torch.empty_strided((N, out_ctot, OH, OW), (0, 0, 0, 0), device=srcs[0].device, dtype=torch.float32)
         else:
-            out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=torch.float32)
+            out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=out_dtype or torch.float32)
+    out_bf16 = out.dtype == torch.bfloat16 and not skip_f32
+    if (out_bf16 or (out2 is not None and out2.dtype == torch.bfloat16)) and _PRECISION != PREC_BF16:
+        raise RuntimeError("conv: bf16 output tensors belong to the bf16 arithmetic mode")
     key = (N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, tuple(specs), w_cin_tot, w_cin_off,
            out_ctot, out_coff, act, float(slope))
     d = _make_desc(N, G, Cin, Cout, H, W, OH, OW, KH, KW, stride, pad_t, pad_l, dil, specs, w_cin_tot, w_cin_off,
@@ -745,7 +772,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             _check_image(dst.image, dst.image.N, G, 0, OH, OW, "conv2d destination")
             if dst.img_off + N > dst.image.N:
                 raise RuntimeError("conv2d destination: images %d..%d outside the packed image (%d)" % (dst.img_off, dst.img_off + N, dst.image.N))
-        io = _io_struct(prepacked, dst, skip_f32, accumulate, out2, split, dz_fuse)
+        io = _io_struct(prepacked, dst, skip_f32, accumulate, out2, split, dz_fuse, out_bf16=out_bf16)
         sums = None
         if ln_stats is not None:
             ln_stats.filled = False
@@ -881,7 +908,7 @@ def _fusable_producer(t: torch.Tensor, spec):
 
 class _ConvMeta:
     __slots__ = ("G", "stride", "pad", "act", "slope", "shared", "specs", "N", "Cin", "Cout", "H", "W", "OH", "OW",
-                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst", "keep_f32", "lazy")
+                 "KH", "KW", "cin_tot", "ln_stats", "prepacked", "dst", "keep_f32", "lazy", "out_dtype")
 
 
 def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool, stream=None):
@@ -927,7 +954,8 @@ class _ConvFn(Function):
                           m.KH, m.KW, m.stride, m.pad, m.pad, 1, m.cin_tot, 0, m.act, m.slope, want_xp=True,
                           ln_stats=m.ln_stats, prepacked=m.prepacked if use_img else None, dst=m.dst if use_img else None,
                           skip_f32=use_img and not m.keep_f32 and m.dst is not None and m.dst.coff % 8 == 0
-                          and m.act in (ACT_LRELU, ACT_RELU), lazy=m.lazy)
+                          and m.act in (ACT_LRELU, ACT_RELU), lazy=m.lazy,
+                          out_dtype=m.out_dtype if (m.out_dtype is not None and bf16_storage_active()) else None)
         if m.lazy is not None and xp is None:
             raise RuntimeError("conv2d: a lazily resized source reached a convolution outside the packed bf16 path")
         # the activation backward needs only the SIGN of y (ReLU / LeakyReLU), which the consumer's packed bf16 image holds
@@ -972,6 +1000,8 @@ class _ConvFn(Function):
         srcs = ctx.saved_tensors[2:]
         if getattr(ctx, "fused", None) is None:       # (a handed-over dz comes with a storage-less placeholder for dy)
             dy = _c(dy)
+            if dy.dtype != torch.float32:             # a bf16-stored output whose gradient did not come back as a packed dz (rare)
+                dy = dy.float()
         L = lib()
         bias = ctx.bias_ref
         want_db = ctx.has_bias and ctx.needs_input_grad[1]
@@ -1053,6 +1083,8 @@ class _ConvFn(Function):
                                        xp=dzp, want_xp=True, out=first, out_ctot=(m.G * c) if first is not None else None,
                                        accumulate=first is not None, dst=dzimg.slot(0, 0, pad_tail=True), skip_f32=first is None,
                                        dz_fuse=(mbuf, mng8, coff, pm.slope if pm.act == ACT_LRELU else 0.0, pdb))
+                    if first is None and g.dtype != t.dtype:
+                        g = torch.empty_strided(tuple(g.shape), (0, 0, 0, 0), device=g.device, dtype=t.dtype)     # (placeholder in the edge's type)
                     prod.fused = (dzimg.buf, _dz_bias_finish(prod, pdb, m.G * c))
                     FUSED_STATS["dz"] += 1
                     if first is not None:
@@ -1061,10 +1093,14 @@ class _ConvFn(Function):
                     dsrcs.append(g)      # (single consumer: the storage-less placeholder _conv_raw made)
                     coff += c
                     continue
+                # (the gradient takes the source's storage type: bf16 for the bf16-stored tensors of the bf16 mode, see bf16_storage_active)
                 g, dzp = _conv_raw([dz] if dz is not None else [dy], spec, weight, m.Cout, PACK_DGRAD, None, m.N, m.G, m.Cout, c, m.OH, m.OW, m.H, m.W,
                                    m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0, xp=dzp,
                                    want_xp=True, out=first, out_ctot=(m.G * c) if first is not None else None,
-                                   accumulate=first is not None)
+                                   accumulate=first is not None,
+                                   out_dtype=torch.bfloat16 if (t.dtype == torch.bfloat16 and first is None and _packed_path_now() and _PRECISION == PREC_BF16) else None)
+                if g.dtype != t.dtype and first is None:
+                    g = g.to(t.dtype)
                 if gs == 0:      # source shared by all groups: sum the per-group gradients
                     g = g.view(m.N, m.G, c, m.H, m.W).sum(1)
                 if first is not None:
@@ -1094,14 +1130,15 @@ class _ConvFn(Function):
 def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 0,
            act: int = ACT_NONE, slope: float = 0.0, groups: int = 1, shared: Optional[Sequence[bool]] = None,
            ln_stats: Optional[LNStats] = None, prepacked: Optional[PackedImage] = None, dst: Optional[PackedDst] = None,
-           keep_f32: bool = True):
+           keep_f32: bool = True, out_dtype: Optional[torch.dtype] = None):
     """Grouped convolution over the channel concatenation of `srcs` with fused bias + activation.
     `ln_stats`: see LNStats (filled only on the packed bf16 path with act NONE and groups 1).
     `prepacked`: the packed bf16 image of exactly this concatenation, already written by the producers of `srcs`
     (then `srcs` are only the autograd edges); `dst`: the consumer's image slot the outputs are also written to.
     keep_f32=False with a `dst` (ReLU / LeakyReLU layers): every consumer reads the packed image, so the fp32 result
     is not written at all and the returned tensor is a storage-less autograd handle.  All three are honoured on the packed
-    bf16 path only (see PackedImage).
+    bf16 path only (see PackedImage).  out_dtype=torch.bfloat16: the caller's consumers of the result all read bf16 (today: the
+    CRN LayerNorm) -- honoured while bf16_storage_active(), fp32 otherwise.
 
     srcs[i]: [N, groups*c_i, H, W] (or [N, c_i, H, W] when shared[i]: every group reads the same
     channels).  weight: [groups*Cout, sum(c_i), KH, KW] or [groups, Cout, sum(c_i), KH, KW].
@@ -1110,6 +1147,8 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
         srcs = [srcs]
     if not (prepacked is not None and packed_active()):       # with their packed image given, the sources are only autograd edges
         srcs = [t if getattr(t, "_jaf_lazy", None) is not None and _packed_path_now() else _chk(t, "conv2d source") for t in srcs]
+    if out_dtype not in (None, torch.float32, torch.bfloat16):
+        raise ValueError("conv2d: out_dtype must be torch.float32 or torch.bfloat16")
     _chk(weight, "conv2d weight")
     if bias is not None:
         _chk(bias, "conv2d bias")
@@ -1140,6 +1179,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
     m.ln_stats = ln_stats
     m.prepacked, m.dst, m.keep_f32 = prepacked, dst, keep_f32
+    m.out_dtype = out_dtype if out_dtype == torch.bfloat16 else None
     m.lazy = [getattr(t, "_jaf_lazy", None) for t in srcs]
     if not any(l is not None for l in m.lazy):
         m.lazy = None
@@ -1215,6 +1255,11 @@ class _ConvLSTMFn(Function):
         # and of the gate backward, which reads them exactly once)
         g16 = _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
         gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.bfloat16 if g16 else torch.float32) if keep else None
+        # bf16 storage: the cell state (written once, read by the next step and twice by the gate backward) in bf16 too -- whenever
+        # it stays inside this node (zero initial state, c_T not handed out)
+        st16 = g16 and bf16_storage_active() and h0 is None and not want_c
+        if st16:
+            cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.bfloat16)
         xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
         use_img = seq_image is not None and packed_active() and h0 is None
         if use_img:
@@ -1240,13 +1285,15 @@ class _ConvLSTMFn(Function):
                     hdst = seq_image.slot(C, (t + 1) * N) if t + 1 < T else final_dst
                     if hdst is not None:
                         # n + img_off indexes the destination image from ITS base; the input block starts at t*N
-                        io = _io_struct(seq_image, hdst, skip_f32=(skip_h and t + 1 < T))
+                        io = _io_struct(seq_image, hdst, skip_f32=(skip_h and t + 1 < T), state_bf16=st16)
                     else:
-                        io = _io_struct(seq_image, None)
+                        io = _io_struct(seq_image, None, state_bf16=st16)
                 else:
                     xp = pack_input([x[t]] if first else [x[t], hprev], d)
                     if final_dst is not None and t + 1 == T and packed_active():
-                        io = _io_struct(None, final_dst)
+                        io = _io_struct(None, final_dst, state_bf16=st16)
+                    elif st16:
+                        io = _io_struct(None, None, state_bf16=True)
                 if keep:
                     xps.append(xp)
                 check(L.jaf_convlstm_cell_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
@@ -1270,6 +1317,7 @@ class _ConvLSTMFn(Function):
         ctx.has_state = h0 is not None
         ctx.xp_ng8 = seq_image.ng8 if use_img else 0
         ctx.h_skipped = skip_h
+        ctx.st16 = st16
         ctx.mode = (_PRECISION, _USE_PACKED)        # backward uses the arithmetic the forward ran in
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
@@ -1315,6 +1363,8 @@ class _ConvLSTMFn(Function):
         fused = ctx.xps is not None and _packed_path_now() and C % 4 == 0
         if (gates.dtype == torch.bfloat16 or ctx.h_skipped) and not fused:
             raise RuntimeError("convlstm: precision changed between forward and backward")
+        st16 = bool(getattr(ctx, "st16", False))       # bf16 storage of c (forward) -> dc and dh of the time loop in bf16 too
+        sdt = torch.bfloat16 if st16 else torch.float32
         if b_inplace:
             db = bias.grad
         elif fused:
@@ -1340,7 +1390,7 @@ class _ConvLSTMFn(Function):
             else:
                 dht = dh_out if t == T - 1 else dh
             dht = _c(dht)
-            dc_prev = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
+            dc_prev = torch.empty((N, GC, H, W), device=x.device, dtype=sdt)
             gt = gates[t]
             specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
             Cin = C if first else 2 * C
@@ -1350,10 +1400,13 @@ class _ConvLSTMFn(Function):
             gtp = None       # packed gate gradients: shared by the weight gradient and the two data gradients
             if fused:
                 gtp = torch.empty(N * G * ng8 * H * W * 16 * (2 if _PRECISION == PREC_BF16X3 else 1), device=x.device, dtype=torch.uint8)
-                with _hbm("lstm_gates_bwd_pack_kernel", N * G * C * H * W * (4.0 * (4 if first else 5) + 4.0 * gt.element_size()) + gtp.numel()):
-                    check(L.jaf_convlstm_gates_bwd_packed_prec(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),
-                                                               1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cprev), _p(cs[t]),
-                                                               _p(dc_prev), _p(gtp), _p(db), _PRECISION), "jaf_convlstm_gates_bwd_packed_prec")
+                if dc is not None and dc.dtype != sdt:
+                    dc = dc.to(sdt)
+                with _hbm("lstm_gates_bwd_pack_kernel", N * G * C * H * W * (dht.element_size() + (3.0 if first else 4.0) * dc_prev.element_size()
+                                                                             + 4.0 * gt.element_size()) + gtp.numel()):
+                    check(L.jaf_convlstm_gates_bwd_packed_dt(_s(), N, G, C, H * W, _p(dht), 1 if dht.dtype == torch.bfloat16 else 0, _p(dc), _p(gt),
+                                                             1 if gt.dtype == torch.bfloat16 else 0, None if first else _p(cprev), _p(cs[t]),
+                                                             _p(dc_prev), 1 if st16 else 0, _p(gtp), _p(db), _PRECISION), "jaf_convlstm_gates_bwd_packed_dt")
                 wst = _WGRAD_STREAM if w_inplace else None      # see set_wgrad_stream
                 if wst is not None:
                     wst.wait_stream(torch.cuda.current_stream())
@@ -1393,7 +1446,7 @@ class _ConvLSTMFn(Function):
             if dx is not None and not first and fused and 2 * C <= _LSTM_FUSED_DGRAD_MAX_ROWS:
                 # d[x_t, h_{t-1}] in one launch: 2C rows per group, the x rows into dx[t], the h rows into dh -- the packed gate
                 # gradients (4C channels) are read once instead of twice
-                dh = torch.empty((N, GC, H, W), device=x.device, dtype=torch.float32)
+                dh = torch.empty((N, GC, H, W), device=x.device, dtype=sdt)
                 fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
                                                     dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
                 _, gtp = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, 2 * C, H, W, H, W, 3, 3, 1, 1, 1,
@@ -1408,7 +1461,7 @@ class _ConvLSTMFn(Function):
                                        accumulate=dx_first is not None, **(fz or {}))
                 if not first:
                     dh = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
-                                   1, 2 * C, C, ACT_NONE, 0.0, xp=gtp)
+                                   1, 2 * C, C, ACT_NONE, 0.0, xp=gtp, out_dtype=sdt)
             dc = dc_prev
         dh0 = dh if (ctx.has_state and ctx.needs_input_grad[5]) else None
         dc0 = dc if (ctx.has_state and ctx.needs_input_grad[6]) else None
@@ -1470,10 +1523,13 @@ class _LayerNormLReLUFn(Function):
         # packed dz (+ bias gradient), no fp32 dx, no jaf_conv2d_pack_dz pass
         ctx.prod = _ln_producer(x) if (sole and ctx.needs_input_grad[0] and _packed_path_now()) else None
         stats = torch.empty(2 * N, device=x.device, dtype=torch.float32)
-        if pre is not None and pre.filled:       # sums came out of the producing convolution's epilogue
+        xb = 1 if x.dtype == torch.bfloat16 else 0           # bf16 storage of the pre-LayerNorm convolution output
+        if pre is not None and pre.filled:       # sums came out of the producing convolution's epilogue (from the unrounded values)
             check(L.jaf_layernorm_finalize(_s(), _p(pre.sums), N, pre.slots, C * H * W, eps, _p(stats)), "jaf_layernorm_finalize")
             pre.filled, pre.dirty = False, False     # consumed, and the kernel left the sums at zero
         else:
+            if xb:
+                raise RuntimeError("layernorm: a bf16-stored input must come with the statistics of its producing convolution")
             ws = torch.empty(2 * N, device=x.device, dtype=torch.float64)
             check(L.jaf_layernorm_stats(_s(), _p(x), N, C * H * W, eps, _p(ws), _p(stats)), "jaf_layernorm_stats")
         if dst is not None and packed_active():
@@ -1482,15 +1538,17 @@ class _LayerNormLReLUFn(Function):
                 raise RuntimeError("layernorm destination: slot does not fit")
             # keep_f32=False: only the convolution behind `dst` reads the result -> no fp32 tensor is written, the
             # returned tensor is a storage-less autograd handle (the backward pass needs x and the statistics, not y)
-            y = (torch.empty_like(x) if keep_f32 else
-                 torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=torch.float32))
-            check(L.jaf_layernorm_lrelu_fwd_packed_prec(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y) if keep_f32 else None,
-                                                        _p(dst.image.buf), dst.image.ng8, dst.coff, N, C, H * W, slope, _PRECISION),
-                  "jaf_layernorm_lrelu_fwd_packed_prec")
+            # (the handle takes the bf16 type under bf16 storage: the consumer's data gradient then comes back in bf16)
+            y = (torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32) if keep_f32 else
+                 torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device,
+                                     dtype=torch.bfloat16 if bf16_storage_active() else torch.float32))
+            check(L.jaf_layernorm_lrelu_fwd_packed_dt(_s(), _p(x), xb, _p(stats), _p(gamma), _p(beta), _p(y) if keep_f32 else None,
+                                                      _p(dst.image.buf), dst.image.ng8, dst.coff, N, C, H * W, slope, _PRECISION),
+                  "jaf_layernorm_lrelu_fwd_packed_dt")
         else:
-            y = torch.empty_like(x)
-            check(L.jaf_layernorm_lrelu_fwd(_s(), _p(x), _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
-                  "jaf_layernorm_lrelu_fwd")
+            y = torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32)
+            check(L.jaf_layernorm_lrelu_fwd_dt(_s(), _p(x), xb, _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
+                  "jaf_layernorm_lrelu_fwd_dt")
         ctx.eps, ctx.slope = eps, slope
         ctx.save_for_backward(x, gamma, beta, stats)
         return y
@@ -1500,6 +1558,9 @@ class _LayerNormLReLUFn(Function):
         x, gamma, beta, stats = ctx.saved_tensors
         N, C, H, W = x.shape
         dy = _c(dy)
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        db16, xb16 = (1 if dy.dtype == torch.bfloat16 else 0), (1 if x.dtype == torch.bfloat16 else 0)
         # the kernel accumulates (+=): parameters that already own a .grad buffer are updated in place
         gi, bi = _grad_inplace(gamma), _grad_inplace(beta)
         dgamma = gamma.grad if gi else torch.zeros_like(gamma)
@@ -1517,18 +1578,18 @@ class _LayerNormLReLUFn(Function):
                     dbt, acc = pb.grad, 1
                 else:
                     dbt = db = torch.empty(C, device=x.device, dtype=torch.float32)
-            with _hbm("ln_bwd_apply_packed_kernel", x.numel() * 8.0 + dzp.numel()):
-                check(lib().jaf_layernorm_lrelu_bwd_packed_prec(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dzp), _p(dgamma),
-                                                                _p(dbeta), _p(ws), _p(scratch), _p(dbt), acc, N, C, H * W, ctx.slope, ctx.eps,
-                                                                _PRECISION), "jaf_layernorm_lrelu_bwd_packed_prec")
+            with _hbm("ln_bwd_apply_packed_kernel", x.numel() * (dy.element_size() + x.element_size()) + dzp.numel()):
+                check(lib().jaf_layernorm_lrelu_bwd_packed_dt(_s(), _p(dy), db16, _p(x), xb16, _p(stats), _p(gamma), _p(beta), _p(dzp), _p(dgamma),
+                                                              _p(dbeta), _p(ws), _p(scratch), _p(dbt), acc, N, C, H * W, ctx.slope, ctx.eps,
+                                                              _PRECISION), "jaf_layernorm_lrelu_bwd_packed_dt")
             prod.fused = (dzp, db)
             FUSED_STATS["ln"] += 1
-            dx = torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=torch.float32)     # placeholder
+            dx = torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device, dtype=x.dtype)     # placeholder
             return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None, None, None
         dx = torch.empty_like(x)
-        check(lib().jaf_layernorm_lrelu_bwd(_s(), _p(dy), _p(x), _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
-                                            _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
-              "jaf_layernorm_lrelu_bwd")
+        check(lib().jaf_layernorm_lrelu_bwd_dt(_s(), _p(dy), db16, _p(x), xb16, _p(stats), _p(gamma), _p(beta), _p(dx), _p(dgamma),
+                                               _p(dbeta), _p(ws), N, C, H * W, ctx.slope, ctx.eps),
+              "jaf_layernorm_lrelu_bwd_dt")
         return dx, (None if gi else dgamma), (None if bi else dbeta), None, None, None, None, None, None
 
 
@@ -1536,7 +1597,7 @@ def layernorm_lrelu(x, gamma, beta, eps: float = 1e-5, slope: float = 0.01, pre:
                     dst: Optional[PackedDst] = None, keep_f32: bool = True, sole_consumer: bool = False):
     """`dst`: the consumer convolution's packed image slot; keep_f32=False: that convolution is the only reader, so no
     fp32 result is written (both on the packed bf16 path only, see PackedImage)."""
-    _chk(x, "layernorm x"); _chk(gamma, "gamma"); _chk(beta, "beta")
+    _chk(x, "layernorm x", torch.bfloat16 if x.dtype == torch.bfloat16 else torch.float32); _chk(gamma, "gamma"); _chk(beta, "beta")
     return _LayerNormLReLUFn.apply(x, gamma, beta, eps, slope, pre, dst, keep_f32, sole_consumer)
 
 

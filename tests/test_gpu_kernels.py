@@ -870,3 +870,91 @@ def test_atlas_slicing_into_the_packed_image_is_bit_identical(mode):
         assert torch.equal(out, ref)
     finally:
         ops.set_precision(prev)
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 STORAGE of the "bf16" arithmetic mode (ops.bf16_storage_active: BASELINE configs[2] "bf16 storage / fp32 accumulate")
+# ------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def test_bf16_storage_conv_output_is_the_rounded_fp32_output():
+    """jaf_packed_io.out_bf16: the same launch with its NCHW result stored in bf16 must hold exactly the RNE rounding of what it
+    stores in fp32 (plain epilogue, the statistics epilogue of the CRN LayerNorm, and the accumulate form), and the LayerNorm
+    statistics taken in the epilogue must not change (they are summed from the unrounded values)."""
+    ops = _ops()
+    from jafpro_amd._lib import ACT_NONE
+    prev = ops.set_precision("bf16")
+    try:
+        x, w, b = dev(R(1, 2, 24, 32, 32)), dev(R(2, 40, 24, 3, 3, lo=-0.2, hi=0.2)), dev(R(3, 40))
+        with torch.no_grad():
+            y32 = ops.conv2d(x, w, b, stride=1, pad=1, act=ACT_NONE)
+            y16 = ops.conv2d(x, w, b, stride=1, pad=1, act=ACT_NONE, out_dtype=torch.bfloat16)
+            assert y16.dtype == torch.bfloat16 and torch.equal(y16, y32.to(torch.bfloat16))
+            s32, s16 = ops.LNStats(), ops.LNStats()
+            z32 = ops.conv2d(x, w, b, stride=1, pad=1, act=ACT_NONE, ln_stats=s32)
+            z16 = ops.conv2d(x, w, b, stride=1, pad=1, act=ACT_NONE, ln_stats=s16, out_dtype=torch.bfloat16)
+            assert s32.filled and s16.filled and torch.equal(z16, z32.to(torch.bfloat16))
+            a, c = s32.sums.view(2, -1, 2).sum(1), s16.sums.view(2, -1, 2).sum(1)
+            assert torch.allclose(a, c, rtol=1e-6, atol=1e-6)
+            # 13 x 13 (odd plane: the scalar epilogue) and a strided 2-group layer
+            x2, w2 = dev(R(4, 3, 16, 13, 13)), dev(R(5, 24, 8, 3, 3, lo=-0.2, hi=0.2))
+            q32 = ops.conv2d(x2, w2, None, stride=1, pad=1, act=1, slope=0.2, groups=2)
+            q16 = ops.conv2d(x2, w2, None, stride=1, pad=1, act=1, slope=0.2, groups=2, out_dtype=torch.bfloat16)
+            assert torch.equal(q16, q32.to(torch.bfloat16))
+        off = ops.set_bf16_storage(False)
+        try:
+            with torch.no_grad():
+                assert ops.conv2d(x, w, b, stride=1, pad=1, act=ACT_NONE, out_dtype=torch.bfloat16).dtype == torch.float32
+        finally:
+            ops.set_bf16_storage(off)
+    finally:
+        ops.set_precision(prev)
+    with torch.no_grad():                                   # the parity-grade modes never store bf16
+        assert ops.conv2d(x, w, b, stride=1, pad=1, act=ACT_NONE, out_dtype=torch.bfloat16).dtype == torch.float32
+
+
+def test_bf16_storage_crn_block_and_convlstm_agree_with_fp32_storage():
+    """The CRN conv -> LayerNorm -> LeakyReLU block (src/crn_model.py:90-106) and the ConvLSTM (src/convLSTM.py:41-56) in bf16
+    arithmetic with bf16 storage (pre-LayerNorm output and its incoming gradient; cell state, d h and d c of the time loop) against
+    the same arithmetic with fp32 storage: outputs within 2e-2 of the output scale, every gradient within 3e-2 relative L2 -- the size
+    of one more bf16 rounding per stored tensor (a wrong element type or offset is O(1))."""
+    ops = _ops()
+    from jafpro_amd import synth
+    from jafpro_amd.crn_model import ConvBlock
+    prev = ops.set_precision("bf16")
+    res = {}
+    try:
+        for storage in (False, True):
+            pst = ops.set_bf16_storage(storage)
+            try:
+                torch.manual_seed(5)
+                blk = synth.load_synth(ConvBlock(2, 9, 32, (3, 3), 1), 77).cuda()
+                x = dev(R(6, 2, 9, 32, 32)).requires_grad_(True)
+                y = blk(x)
+                assert y.dtype == torch.float32
+                (y * dev(R(7, *y.shape))).sum().backward()
+                g = [x.grad.clone()] + [p.grad.clone() for p in blk.parameters()]
+                # ConvLSTM: T = 4, 2 groups of 8 hidden channels on 20 x 20 and the odd 13 x 13 plane
+                outs = []
+                for hw in (20, 13):
+                    xs = dev(R(8, 4, 2, 16, hw, hw)).requires_grad_(True)
+                    w = dev(R(9, 2 * 32, 16, 3, 3, lo=-0.15, hi=0.15)).requires_grad_(True)
+                    b = dev(R(10, 2 * 32)).requires_grad_(True)
+                    h, _ = ops.convlstm(xs, w, b, groups=2, return_all=False, return_state=False)
+                    (h * dev(R(11, *h.shape))).sum().backward()
+                    outs += [h.detach().clone(), xs.grad.clone(), w.grad.clone(), b.grad.clone()]
+                res[storage] = (y.detach().clone(), g, outs)
+            finally:
+                ops.set_bf16_storage(pst)
+    finally:
+        ops.set_precision(prev)
+    (y0, g0, o0), (y1, g1, o1) = res[False], res[True]
+    assert (y1 - y0).abs().max().item() <= 2e-2 * max(1.0, y0.abs().max().item())
+    for i, (a, b) in enumerate(zip(g1, g0)):
+        assert _rel(a, b) <= 3e-2, ("crn block gradient", i, _rel(a, b))
+    for i, (a, b) in enumerate(zip(o1, o0)):
+        assert _rel(a, b) <= 3e-2, ("convlstm", i, _rel(a, b))
+    assert any(not torch.equal(a, b) for a, b in zip(o1, o0)), "bf16 storage left every ConvLSTM result bit-identical: it did not run"
