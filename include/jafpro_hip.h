@@ -168,6 +168,11 @@ int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const float* y, const
 int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
                             int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                             void* packed, float* dz, float* dbias, int precision);
+/* Same with dy's element type given: dy_bf16 = 1 -- dy holds bf16, the gradient of a tensor kept in bf16 storage (JAF_PREC_BF16
+ * only; see jaf_packed_io.out_bf16). */
+int jaf_conv2d_pack_dz_dt(jaf_stream_t s, const void* dy, int dy_bf16, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                          int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                          void* packed, float* dz, float* dbias, int precision);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
  * [N][G][4C/8][H*W][8], CHANNEL-MAJOR: packed channel 4*c + gate (one item = 2 hidden channels x i,f,o,g; its consumers:
  * jaf_conv2d_pack(JAF_PACK_DGRAD_LSTM) + jaf_conv2d_fwd_packed_io for d[x, h], jaf_conv2d_wgrad_packed_lstm for dW), and
@@ -437,6 +442,9 @@ int jaf_resize_fwd(jaf_stream_t s, const float* x, float* y, int32_t N, int32_t 
 int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t N, int32_t C, int32_t H,
                    int32_t W, int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH,
                    int32_t OW, int align_corners);
+/* Same with dy's element type given (dy_bf16 = 1: bf16, the gradient of a tensor in bf16 storage); dx stays fp32. */
+int jaf_resize_bwd_dt(jaf_stream_t s, const void* dy, int dy_bf16, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
+                      int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH, int32_t OW, int align_corners);
 
 /* nn.ReflectionPad2d(p) (src/flow_net.py:13,51,113) and its adjoint. */
 int jaf_reflect_pad_fwd(jaf_stream_t s, const float* x, float* y, int32_t NC, int32_t H, int32_t W,

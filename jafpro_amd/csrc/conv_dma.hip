@@ -658,6 +658,7 @@ struct PackDzArgs {
     int N, G, C, H, W, ngroups8, act;
     float slope;
     int split;             // split-bf16 image (hi and lo planes per channel group): see PackInArgs
+    int dy_bf16;           // dy holds bf16 (the gradient of a bf16-stored tensor: jaf_conv2d_pack_dz_dt)
 };
 
 __device__ __forceinline__ float dz_of(float g, float yv, int act, float slope) {
@@ -705,7 +706,13 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
         if (live && c < a.C) {
             const long e = ((long)n * a.G * a.C + (long)g * a.C + c) * HW + (long)yy * a.W + x;
             if (V == 4) {
-                const f32x4 gq = *(const f32x4*)(a.dy + e);
+                f32x4 gq;
+                if (a.dy_bf16) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    gq = __builtin_convertvector(*(const bf16x4*)((const __bf16*)a.dy + e), f32x4);
+                } else {
+                    gq = *(const f32x4*)(a.dy + e);
+                }
                 f32x4 yq = {0.f, 0.f, 0.f, 0.f};
                 if (a.yp) { yq[0] = ypk[j][0]; yq[1] = ypk[j][V > 1 ? 1 : 0]; yq[2] = ypk[j][V > 2 ? 2 : 0]; yq[3] = ypk[j][V > 3 ? 3 : 0]; }
                 else if (a.act != JAF_ACT_NONE) yq = *(const f32x4*)(a.y + e);
@@ -718,7 +725,8 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
                 if (a.dz) *(f32x4*)(a.dz + e) = o;
                 part[j] = (o[0] + o[1]) + (o[2] + o[3]);
             } else {
-                const float o = dz_of(a.dy[e], a.yp ? ypk[j][0] : (a.act != JAF_ACT_NONE ? a.y[e] : 0.f), a.act, a.slope);
+                const float o = dz_of(a.dy_bf16 ? (float)((const __bf16*)a.dy)[e] : a.dy[e], a.yp ? ypk[j][0] : (a.act != JAF_ACT_NONE ? a.y[e] : 0.f),
+                                      a.act, a.slope);
                 v[j][0] = o;
                 if (a.dz) a.dz[e] = o;
                 part[j] = o;
@@ -764,8 +772,16 @@ extern "C" int jaf_conv2d_pack_dz_ex(jaf_stream_t s, const float* dy, const floa
 extern "C" int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const float* y, const void* y_packed, int32_t y_ng8_tot,
                                        int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                                        void* packed, float* dz, float* dbias, int precision) {
+    return jaf_conv2d_pack_dz_dt(s, dy, 0, y, y_packed, y_ng8_tot, y_coff, N, G, C, H, W, act, slope, packed, dz, dbias, precision);
+}
+
+extern "C" int jaf_conv2d_pack_dz_dt(jaf_stream_t s, const void* dy_, int dy_bf16, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                                     int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                                     void* packed, float* dz, float* dbias, int precision) {
+    const float* dy = (const float*)dy_;
     JAF_REQUIRE(dy && packed && N >= 1 && G >= 1 && C >= 1 && H >= 1 && W >= 1);
     JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
+    JAF_REQUIRE(!dy_bf16 || precision == JAF_PREC_BF16);
     JAF_REQUIRE(act == JAF_ACT_NONE || y || y_packed);
     // y from the packed image: only its sign is used (ReLU / LeakyReLU), which bf16 rounding keeps
     JAF_REQUIRE(!y_packed || ((act == JAF_ACT_LRELU || act == JAF_ACT_RELU) && y_coff >= 0 && (y_coff & 7) == 0 &&
@@ -774,6 +790,7 @@ extern "C" int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const fl
     a.dy = dy; a.y = y; a.out = (unsigned char*)packed; a.dz = dz; a.dbias = dbias;
     a.yp = (const unsigned char*)y_packed; a.yp_ng8 = y_ng8_tot; a.yp_cg0 = y_coff / 8;
     a.split = precision == JAF_PREC_BF16X3 ? 1 : 0;       // (then y_packed is a split image too: the sign is read from its hi planes)
+    a.dy_bf16 = dy_bf16 ? 1 : 0;
     const bool al = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
     if (al && W % 4 != 0 && ((long)H * W) % 4 == 0 && (long)H * W < (1L << 30)) { W = H * W; H = 1; }   // as in jaf_conv2d_pack_input
     a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;

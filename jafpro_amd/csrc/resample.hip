@@ -267,7 +267,8 @@ __device__ __forceinline__ float resize_w(int o, int i, float scale, int in, int
 
 #define RB_MAXC 8
 // grid (x blocks, input rows, planes)
-__global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
+template <typename DT>
+__global__ void resize_bwd_kernel(const DT* dy, float* dx, ResizeArgs a) {
     const int gx = blockIdx.x * blockDim.x + threadIdx.x;
     const int gy = blockIdx.y * blockDim.y + threadIdx.y;
     if (gx >= a.W || gy >= a.H) return;
@@ -278,7 +279,7 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
         int ylo, yhi, xlo, xhi;
         resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
         resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
-        const float* p = dy + nc * a.OH * a.OW;
+        const DT* p = dy + nc * a.OH * a.OW;
         if (xhi - xlo + 1 <= RB_MAXC) {
             float wx[RB_MAXC];
 #pragma unroll
@@ -286,12 +287,12 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
             for (int oy = ylo; oy <= yhi; ++oy) {
                 const float wy = resize_w(oy, iy, a.sy, a.ch, a.align);      // row-uniform: scalar work
                 if (wy == 0.f) continue;
-                const float* r = p + oy * a.OW + xlo;
+                const DT* r = p + oy * a.OW + xlo;
                 float row = 0.f;
 #pragma unroll
                 for (int j = 0; j < RB_MAXC; ++j) {
                     const int oxc = (xlo + j <= xhi) ? j : 0;              // clamped: the load is always in range,
-                    row += wx[j] * r[oxc];                                 // padding taps carry weight 0
+                    row += wx[j] * (float)r[oxc];                          // padding taps carry weight 0
                 }
                 acc += wy * row;
             }
@@ -302,7 +303,7 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
                 float row = 0.f;
                 for (int ox = xlo; ox <= xhi; ++ox) {
                     const float wxv = resize_w(ox, ix, a.sx, a.cw, a.align);
-                    if (wxv != 0.f) row += wxv * p[oy * a.OW + ox];
+                    if (wxv != 0.f) row += wxv * (float)p[oy * a.OW + ox];
                 }
                 acc += wy * row;
             }
@@ -317,7 +318,9 @@ __global__ void resize_bwd_kernel(const float* dy, float* dx, ResizeArgs a) {
 // align_corners weights and the exact 5x5 support of <= 2.2x up-sampling: 161 -> 124 us per launch on average).
 // Block (tx, ty) = one tile of tx x ty input pixels of one plane; the region is the union of the candidates of
 // the tile's first and last pixel (candidate ranges are monotonic in the pixel index).
-__global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __restrict__ dx, ResizeArgs a) {
+// DT: element type of dy (fp32, or bf16: the gradient of a bf16-stored handle, e.g. a decoder's lazily up-sampled input).
+template <typename DT>
+__global__ void resize_bwd_lds_kernel(const DT* __restrict__ dy, float* __restrict__ dx, ResizeArgs a) {
     extern __shared__ float s_reg[];
     // a.rows input rows per lane: the tile is blockDim.x x (blockDim.y * a.rows) input pixels, so one staging round trip
     // (all of a lane's 16-byte loads in flight before the first LDS store) serves a.rows times the outputs
@@ -340,7 +343,7 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
         resize_cand(ixl, a.sx, a.OW, a.align, lo, rx1);
         resize_cand(iyf, a.sy, a.OH, a.align, ry0, hi);
         resize_cand(iyl, a.sy, a.OH, a.align, lo, ry1);
-        const float* p = dy + nc * a.OH * a.OW;
+        const DT* p = dy + nc * a.OH * a.OW;
         if (a.vec) {
             // 16-byte staging: the region starts on a multiple of 4 columns (OW % 4 == 0, pitch a.rw % 4 == 0);
             // three rows per pass so that three independent loads are in flight before the first LDS write
@@ -362,7 +365,9 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
                         int c4 = idx - r * w4;
                         if (c4 < 0) { --r; c4 += w4; }
                         if (c4 >= w4) { ++r; c4 -= w4; }
-                        v[u] = *(const f32x4r*)(p + (long)(ry0 + r) * a.OW + rx0 + 4 * c4);
+                        float t4[4];
+                        jaf_ldv<4, DT>(p + (long)(ry0 + r) * a.OW + rx0 + 4 * c4, t4);
+                        v[u] = (f32x4r){t4[0], t4[1], t4[2], t4[3]};
                         so[u] = r * a.rw + 4 * c4;
                     }
                 }
@@ -375,7 +380,7 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
             if (ry1 > ry0 + a.rh - 1) ry1 = ry0 + a.rh - 1;
             for (int r = threadIdx.y; r <= ry1 - ry0; r += blockDim.y)
                 for (int c = threadIdx.x; c <= rx1 - rx0; c += blockDim.x)
-                    s_reg[r * a.rw + c] = p[(ry0 + r) * a.OW + rx0 + c];
+                    s_reg[r * a.rw + c] = (float)p[(ry0 + r) * a.OW + rx0 + c];
         }
     }
     __syncthreads();
@@ -450,13 +455,19 @@ __global__ void resize_bwd_lds_kernel(const float* __restrict__ dy, float* __res
 extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
                               int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH, int32_t OW,
                               int align_corners) {
+    return jaf_resize_bwd_dt(s, dy, 0, dx, N, C, H, W, y0, x0, ch, cw, OH, OW, align_corners);
+}
+
+extern "C" int jaf_resize_bwd_dt(jaf_stream_t s, const void* dy, int dy_bf16, float* dx, int32_t N, int32_t C, int32_t H, int32_t W,
+                                 int32_t y0, int32_t x0, int32_t ch, int32_t cw, int32_t OH, int32_t OW,
+                                 int align_corners) {
     JAF_REQUIRE(dy && dx && N >= 1 && C >= 1 && OH >= 1 && OW >= 1 && ch >= 1 && cw >= 1);
     JAF_REQUIRE(y0 >= 0 && x0 >= 0 && y0 + ch <= H && x0 + cw <= W);
     ResizeArgs a = {N, C, H, W, y0, x0, ch, cw, OH, OW, 0.f, 0.f, align_corners, 0};
     resize_scales(a);
     JAF_REQUIRE(H <= 65535 && (long)N * C <= 65535);
     const dim3 b = block2d(W);      // (squarer 32x8 / 64x4 tiles stage fewer halo rows but measured 6-8 % slower)
-    const bool vec = (OW % 4 == 0) && ((((uintptr_t)dy) & 15) == 0);
+    const bool vec = (OW % 4 == 0) && ((((uintptr_t)dy) & (dy_bf16 ? 7 : 15)) == 0);
     // candidate region of one (b.x, b.y * rows) tile: (pixels + 1) / scale + 4 per axis (resize_cand), capped by the image.
     // rows per lane: as many (<= 8, tile no taller than the plane) as keep the region within 40 KB and leave the launch >= 2048 workgroups
     long rw = 0, rh = 0;
@@ -479,10 +490,13 @@ extern "C" int jaf_resize_bwd(jaf_stream_t s, const float* dy, float* dx, int32_
         a.rows = rows;
         a.inv_sx = a.sx > 0.f ? 1.0f / a.sx : 0.f;
         a.inv_sy = a.sy > 0.f ? 1.0f / a.sy : 0.f;
-        hipLaunchKernelGGL(resize_bwd_lds_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y * rows), N * C), b, (size_t)(rw * rh * 4),
-                           (hipStream_t)s, dy, dx, a);
+        const dim3 grid(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y * rows), N * C);
+        if (dy_bf16) hipLaunchKernelGGL(resize_bwd_lds_kernel<__bf16>, grid, b, (size_t)(rw * rh * 4), (hipStream_t)s, (const __bf16*)dy, dx, a);
+        else hipLaunchKernelGGL(resize_bwd_lds_kernel<float>, grid, b, (size_t)(rw * rh * 4), (hipStream_t)s, (const float*)dy, dx, a);
     } else {
-        hipLaunchKernelGGL(resize_bwd_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C), b, 0, (hipStream_t)s, dy, dx, a);
+        const dim3 grid(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), N * C);
+        if (dy_bf16) hipLaunchKernelGGL(resize_bwd_kernel<__bf16>, grid, b, 0, (hipStream_t)s, (const __bf16*)dy, dx, a);
+        else hipLaunchKernelGGL(resize_bwd_kernel<float>, grid, b, 0, (hipStream_t)s, (const float*)dy, dx, a);
     }
     return jaf_launch_status();
 }

@@ -750,7 +750,10 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
         if skip_f32:
             # nothing reads this tensor in fp32: it exists only as the autograd edge (shape / dtype / device), its one
             # element is never written.  Any op that is not packed-aware rejects it (not contiguous).
-            out = torch.empty_strided((N, out_ctot, OH, OW), (0, 0, 0, 0), device=srcs[0].device, dtype=torch.float32)
+            # Under bf16 storage the handle is a bf16 tensor: autograd then expects -- and the layers behind it produce -- its
+            # gradient in bf16 (a data gradient that is not handed over as a packed dz, a GradSlot buffer).
+            out = torch.empty_strided((N, out_ctot, OH, OW), (0, 0, 0, 0), device=srcs[0].device,
+                                      dtype=torch.bfloat16 if (bf16_storage_active() and mode == PACK_FWD) else torch.float32)
         else:
             out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=out_dtype or torch.float32)
     out_bf16 = out.dtype == torch.bfloat16 and not skip_f32
@@ -826,7 +829,8 @@ class GradSlot:
     def take(self, shape):
         """The first gradient, viewed as `shape`, if the second consumer may add into it (bf16 packed path); clears the slot."""
         b, self.buf = self.buf, None
-        if b is None or not _packed_path_now() or not b.is_contiguous() or b.dtype != torch.float32 or b.numel() != math.prod(shape):
+        if b is None or not _packed_path_now() or not b.is_contiguous() or b.numel() != math.prod(shape) or not (
+                b.dtype == torch.float32 or (b.dtype == torch.bfloat16 and _PRECISION == PREC_BF16)):
             return None
         return b.view(shape)
 
@@ -1000,7 +1004,7 @@ class _ConvFn(Function):
         srcs = ctx.saved_tensors[2:]
         if getattr(ctx, "fused", None) is None:       # (a handed-over dz comes with a storage-less placeholder for dy)
             dy = _c(dy)
-            if dy.dtype != torch.float32:             # a bf16-stored output whose gradient did not come back as a packed dz (rare)
+            if dy.dtype != torch.float32 and not (dy.dtype == torch.bfloat16 and _packed_path_now() and _PRECISION == PREC_BF16):
                 dy = dy.float()
         L = lib()
         bias = ctx.bias_ref
@@ -1019,7 +1023,8 @@ class _ConvFn(Function):
             # one pass: activation backward + bias gradient + packed bf16 dz (+ fp32 dz only if the
             # weight gradient of this layer still runs on the fp32-input kernel); split-bf16: hi and lo planes
             need_f32 = ctx.needs_input_grad[0] and ctx.xp is None
-            dz = torch.empty_like(dy) if need_f32 else None
+            dz = torch.empty(dy.shape, device=dy.device, dtype=torch.float32) if need_f32 else None
+            dyb = 1 if dy.dtype == torch.bfloat16 else 0          # the gradient of a bf16-stored output (bf16_storage_active)
             dbt = None
             if want_db:
                 if _grad_inplace(bias):
@@ -1030,20 +1035,20 @@ class _ConvFn(Function):
             ng8 = (m.Cout + 7) // 8
             dzp = torch.empty(m.N * m.G * ng8 * m.OH * m.OW * 16 * (2 if _PRECISION == PREC_BF16X3 else 1), device=dy.device, dtype=torch.uint8)
             yimg = getattr(ctx, "y_img", None)
-            with _hbm("conv_pack_dz_kernel", dy.numel() * (4.0 + ((2.0 if yimg else 4.0) if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
+            with _hbm("conv_pack_dz_kernel", dy.numel() * (dy.element_size() + ((2.0 if yimg else 4.0) if m.act != ACT_NONE else 0.0) + (4.0 if dz is not None else 0.0)) + dzp.numel()):
                 per = dzp.numel() // m.N
                 for n0, n1 in _n_chunks(m.N, m.G * ng8):
                     if yimg is not None:
                         img, ycoff, yoff = yimg
                         yper = img.per_image
-                        check(L.jaf_conv2d_pack_dz_prec(_s(), _p(dy[n0:n1]), None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
-                                                        img.ng8, ycoff, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
-                                                        _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
-                                                        _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_prec")
+                        check(L.jaf_conv2d_pack_dz_dt(_s(), _p(dy[n0:n1]), dyb, None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
+                                                      img.ng8, ycoff, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
+                                                      _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
+                                                      _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_dt")
                         continue
-                    check(L.jaf_conv2d_pack_dz_prec(_s(), _p(dy[n0:n1]), _p(y[n0:n1]) if m.act != ACT_NONE else None, None, 0, 0,
-                                                    n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
-                                                    _p(dz[n0:n1]) if dz is not None else None, _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_prec")
+                    check(L.jaf_conv2d_pack_dz_dt(_s(), _p(dy[n0:n1]), dyb, _p(y[n0:n1]) if m.act != ACT_NONE else None, None, 0, 0,
+                                                  n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
+                                                  _p(dz[n0:n1]) if dz is not None else None, _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_dt")
         elif m.act != ACT_NONE:
             dz = torch.empty_like(dy)
             check(L.jaf_act_bwd(_s(), _p(dy), _p(y), _p(dz), dy.numel(), m.act, m.slope), "jaf_act_bwd")
@@ -1179,7 +1184,7 @@ def conv2d(srcs, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, stri
     m.OH, m.OW, m.KH, m.KW, m.cin_tot = _out_size(H, KH, stride, pad), _out_size(W, KW, stride, pad), KH, KW, cin_tot
     m.ln_stats = ln_stats
     m.prepacked, m.dst, m.keep_f32 = prepacked, dst, keep_f32
-    m.out_dtype = out_dtype if out_dtype == torch.bfloat16 else None
+    m.out_dtype = out_dtype if (out_dtype == torch.bfloat16 and act == ACT_NONE) else None      # (the activation backward reads y in fp32)
     m.lazy = [getattr(t, "_jaf_lazy", None) for t in srcs]
     if not any(l is not None for l in m.lazy):
         m.lazy = None
@@ -1347,7 +1352,9 @@ class _ConvLSTMFn(Function):
         if dh_out is None:          # only c_T was used downstream
             dh_out = torch.zeros_like(hs) if ctx.need_all else torch.zeros_like(hs[0])
         dh_out = _c(dh_out)
-        dx = torch.empty(x.shape, device=x.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        # (dx takes x's storage type: bf16 when x is the bf16 handle of an encoder layer under bf16 storage)
+        dx = torch.empty(x.shape, device=x.device, dtype=x.dtype if (x.dtype == torch.bfloat16 and ctx.xps is not None) else torch.float32) \
+            if ctx.needs_input_grad[0] else None
         # x has a second consumer (enc_{i+1}) whose data gradient may already exist: add into it (GradSlot)
         slot = getattr(ctx, "slot", None)
         dx_first = None
@@ -1772,16 +1779,20 @@ class _LazyResizeFn(Function):
     def forward(ctx, x, OH, OW, align):
         N, C, H, W = x.shape
         ctx.cfg = (N, C, H, W, OH, OW, align)
-        return torch.empty_strided((N, C, OH, OW), (0, 0, 0, 0), device=x.device, dtype=torch.float32)
+        # (bf16 storage: a bf16 handle, so that the consumer's data gradient -- OH*OW/(H*W) times the size of x -- arrives in bf16)
+        return torch.empty_strided((N, C, OH, OW), (0, 0, 0, 0), device=x.device,
+                                   dtype=torch.bfloat16 if bf16_storage_active() else torch.float32)
 
     @staticmethod
     def backward(ctx, dy):
         N, C, H, W, OH, OW, align = ctx.cfg
         dy = _c(dy)
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32)
         for n0, n1 in _n_chunks(N, C):
-            check(lib().jaf_resize_bwd(_s(), _p(dy[n0:n1]), _p(dx[n0:n1]), n1 - n0, C, H, W, 0, 0, H, W, OH, OW, 1 if align else 0),
-                  "jaf_resize_bwd")
+            check(lib().jaf_resize_bwd_dt(_s(), _p(dy[n0:n1]), 1 if dy.dtype == torch.bfloat16 else 0, _p(dx[n0:n1]), n1 - n0, C, H, W, 0, 0, H, W,
+                                          OH, OW, 1 if align else 0), "jaf_resize_bwd_dt")
         return dx, None, None, None
 
 
