@@ -901,9 +901,11 @@ def test_bf16_storage_conv_output_is_the_rounded_fp32_output():
             assert torch.allclose(a, c, rtol=1e-6, atol=1e-6)
             # 13 x 13 (odd plane: the scalar epilogue) and a strided 2-group layer
             x2, w2 = dev(R(4, 3, 16, 13, 13)), dev(R(5, 24, 8, 3, 3, lo=-0.2, hi=0.2))
-            q32 = ops.conv2d(x2, w2, None, stride=1, pad=1, act=1, slope=0.2, groups=2)
-            q16 = ops.conv2d(x2, w2, None, stride=1, pad=1, act=1, slope=0.2, groups=2, out_dtype=torch.bfloat16)
-            assert torch.equal(q16, q32.to(torch.bfloat16))
+            q32 = ops.conv2d(x2, w2, None, stride=1, pad=1, act=ACT_NONE, groups=2)
+            q16 = ops.conv2d(x2, w2, None, stride=1, pad=1, act=ACT_NONE, groups=2, out_dtype=torch.bfloat16)
+            assert q16.dtype == torch.bfloat16 and torch.equal(q16, q32.to(torch.bfloat16))
+            # an activated output stays fp32 (its backward reads y in fp32)
+            assert ops.conv2d(x2, w2, None, stride=1, pad=1, act=1, slope=0.2, groups=2, out_dtype=torch.bfloat16).dtype == torch.float32
         off = ops.set_bf16_storage(False)
         try:
             with torch.no_grad():
