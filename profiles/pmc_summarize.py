@@ -61,7 +61,7 @@ def main():
     with open(out, "w") as fh:
         extra = (" " + sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] else ""
         fh.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, profiles/pmc_traffic.sh) over\n"
-                 "# `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-config2 --parity-mode-steps 0 --serial-streams" + extra + "`\n"
+                 "# `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-config2 --parity-mode-steps 0 --no-frame-parity --serial-streams" + extra + "`\n"
                  "# (3 train steps, bf16 packed path).  KiB as rocprofv3 reports them; gfx950: wide streaming reads are tallied at half\n"
                  "# their bytes, writes exactly (MI355X_MICROARCH.md, HBM section): est. HBM MB per launch = (2*FETCH + WRITE) KiB.\n"
                  "# Rows sorted by total estimated bytes; every kernel of the step is listed (the gather / blend kernels of the\n"
