@@ -1243,6 +1243,52 @@ def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=
 _LSTM_FUSED_DGRAD_MAX_ROWS = int(os.environ.get("JAF_LSTM_FUSED_DGRAD_MAX_ROWS", "48"))
 
 
+class _StickyBuffers:
+    """The ConvLSTM's largest per-call tensors -- the saved gates (2.8 GB at the 200 x 200 level of a B = 8 step) and the cell states --
+    kept from one call of a layer to the next instead of going back to the caching allocator.  Both are written and read on the
+    stream the layer runs on only (cell kernel, gate backward), so the next call's kernels are ordered behind the last reader by
+    the stream itself.  Why: with two steps in flight the allocator now and then finds no free block for the 2.8 GB request and
+    answers with a fresh hipMalloc of that size -- 80-90 ms of HOST time, a 75-120 ms step every few steps
+    (profiles/experiments/r5_spikes.py).  A buffer is handed out again only when its previous user is done with it: the node that
+    took it has run its backward pass or has been destroyed; otherwise (two forward passes before a backward) the caller falls back
+    to an ordinary allocation."""
+
+    def __init__(self):
+        self.slots = {}
+
+    def take(self, owner, key, shape, dtype, device, anchor=None):
+        """`anchor`: the object the key's identity comes from (the layer's weight): entries whose anchor has died are dropped."""
+        for k in [k for k, e in self.slots.items() if e[3] is not None and e[3]() is None]:
+            del self.slots[k]
+        ent = self.slots.get(key)
+        if ent is not None and (ent[1] is None or ent[1]() is None) and ent[0].shape == tuple(shape) and ent[0].dtype == dtype \
+                and ent[0].device == device and ent[2] == torch.cuda.current_stream(device).cuda_stream:
+            self.slots[key] = (ent[0], weakref.ref(owner), ent[2], ent[3])
+            return ent[0]
+        if ent is not None and ent[1] is not None and ent[1]() is not None:
+            return torch.empty(shape, device=device, dtype=dtype)           # still owned by a node whose backward has not run
+        t = torch.empty(shape, device=device, dtype=dtype)
+        if len(self.slots) > 64:
+            self.slots.clear()
+        self.slots[key] = (t, weakref.ref(owner), torch.cuda.current_stream(device).cuda_stream,
+                           weakref.ref(anchor) if anchor is not None else None)
+        return t
+
+    def release(self, owner):
+        for k, ent in list(self.slots.items()):
+            if ent[1] is not None and ent[1]() is owner:
+                self.slots[k] = (ent[0], None, ent[2], ent[3])
+
+
+_STICKY = _StickyBuffers()
+_STICKY_MIN_BYTES = 256 << 20
+
+
+class _LstmOwner:
+    """What a ConvLSTM node holds on to while it still needs its sticky buffers (weakly referenced by _StickyBuffers)."""
+    __slots__ = ("__weakref__",)
+
+
 class _ConvLSTMFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, G: int, need_all: bool, h0, c0, seq_image=None, final_dst=None, want_c: bool = True):
@@ -1254,27 +1300,34 @@ class _ConvLSTMFn(Function):
         L = lib()
         keep = any(ctx.needs_input_grad[:3]) or ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
         ctx.set_materialize_grads(False)
-        hs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
-        cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.float32)
         # on the packed bf16 path the saved gates are bf16 (they are the dominant traffic of the cell epilogue
         # and of the gate backward, which reads them exactly once)
         g16 = _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
-        gates = torch.empty((T, N, 4 * GC, H, W), device=x.device, dtype=torch.bfloat16 if g16 else torch.float32) if keep else None
         # bf16 storage: the cell state (written once, read by the next step and twice by the gate backward) in bf16 too -- whenever
         # it stays inside this node (zero initial state, c_T not handed out)
         st16 = g16 and bf16_storage_active() and h0 is None and not want_c
-        if st16:
-            cs = torch.empty((T, N, GC, H, W), device=x.device, dtype=torch.bfloat16)
-        xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
         use_img = seq_image is not None and packed_active() and h0 is None
-        if use_img:
-            _check_image(seq_image, T * N, G, 2 * C, H, W, "convlstm")
         # with the images, h_t for t < T-1 exists only as bf16 inside the next step's image (nothing reads it in fp32:
         # the fused gate backward needs c_t and the gates, the weight gradient the packed images)
         skip_h = use_img and g16 and not need_all
+        owner = ctx.sticky = _LstmOwner()
+
+        def big(tag, shape, dtype):
+            n = math.prod(shape) * (2 if dtype == torch.bfloat16 else 4)
+            if n < _STICKY_MIN_BYTES or not weight.is_leaf or torch.cuda.is_current_stream_capturing():
+                return torch.empty(shape, device=x.device, dtype=dtype)
+            return _STICKY.take(owner, (id(weight), tag), tuple(shape), dtype, x.device, anchor=weight)
+        # (only h_T is ever written when the intermediate states are skipped: one step's worth of memory instead of T)
+        hs = torch.empty((1 if skip_h else T, N, GC, H, W), device=x.device, dtype=torch.float32)
+        cs = big("c", (T, N, GC, H, W), torch.bfloat16 if st16 else torch.float32)
+        gates = big("gates", (T, N, 4 * GC, H, W), torch.bfloat16 if g16 else torch.float32) if keep else None
+        xps = []         # packed (x_t, h_{t-1}) images: reused by the weight gradient
+        if use_img:
+            _check_image(seq_image, T * N, G, 2 * C, H, W, "convlstm")
         for t in range(T):
             first = t == 0 and h0 is None
-            hprev = h0 if t == 0 else hs[t - 1]
+            hprev = h0 if t == 0 else (None if skip_h else hs[t - 1])
+            ht = hs[0] if skip_h else hs[t]              # (skip_h: steps before the last write no fp32 h at all)
             cprev = c0 if t == 0 else cs[t - 1]
             specs = [(C, GC, 0, C)] if first else [(C, GC, 0, C), (C, GC, 0, C)]
             Cin = C if first else 2 * C
@@ -1302,7 +1355,7 @@ class _ConvLSTMFn(Function):
                 if keep:
                     xps.append(xp)
                 check(L.jaf_convlstm_cell_fwd_packed_io(_s(), ctypes.byref(d), ctypes.byref(pl), _p(xp), _p(wpk), _p(bias),
-                                                        None if first else _p(cprev), _p(hs[t]), _p(cs[t]),
+                                                        None if first else _p(cprev), _p(ht), _p(cs[t]),
                                                         _p(gates[t]) if keep else None, 1 if g16 else 0,
                                                         ctypes.byref(io) if io is not None else None),
                       "jaf_convlstm_cell_fwd_packed_io")
@@ -1333,9 +1386,11 @@ class _ConvLSTMFn(Function):
         if use_img and keep and src is not None and _FUSED_DZ and ctx.slot is not None and src.dim() == 4 and src.shape[0] == T * N:
             ctx.prod = _fusable_producer(src, (C, GC, 0, C))
         c_last = cs[T - 1].clone() if want_c else None          # (a copy: cs is saved for backward)
+        if not keep:
+            _STICKY.release(owner)
         if need_all:
             return hs, c_last
-        return hs[T - 1], c_last
+        return hs[-1], c_last
 
     @staticmethod
     def backward(ctx, dh_out, dc_last=None):
@@ -1390,7 +1445,7 @@ class _ConvLSTMFn(Function):
             pslope = prod.meta.slope if prod.meta.act == ACT_LRELU else 0.0
         for t in range(T - 1, -1, -1):
             first = t == 0 and not ctx.has_state
-            hprev = h0 if t == 0 else hs[t - 1]
+            hprev = h0 if t == 0 else (hs[t - 1] if hs.shape[0] == T else None)     # (None: h_{t-1} was never written in fp32, and the fused path below never reads it)
             cprev = c0 if t == 0 else cs[t - 1]
             if ctx.need_all:
                 dht = dh_out[t] if dh is None else dh_out[t] + dh
@@ -1482,6 +1537,10 @@ class _ConvLSTMFn(Function):
             slot.buf = dx
             SLOT_STATS["first"] += 1
         _wgrad_enqueued(weight)
+        owner = getattr(ctx, "sticky", None)
+        if owner is not None:
+            _STICKY.release(owner)          # (a second backward through this node would read buffers the next call may have overwritten:
+            ctx.sticky = None               #  autograd frees the saved tensors after the first one anyway)
         return dx, (None if w_inplace else dw), (None if b_inplace else db), None, None, dh0, dc0, None, None, None
 
 

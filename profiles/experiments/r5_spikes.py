@@ -25,8 +25,14 @@ batch = _to_dev(synth.stage4_batch(1300, 8), "cuda")
 hp = ops.chain_stream()
 hp.wait_stream(torch.cuda.current_stream())
 torch.cuda.set_stream(hp)
-for _ in range(5):
+warm = int(os.environ.get("R5_WARM", "5"))
+spare = float(os.environ.get("R5_SPARE_GB", "0"))
+for i in range(warm):
     tr.train_step(batch, next_batch=batch)
+    if i == 0 and spare > 0:
+        t = torch.empty(int(spare * 2 ** 30), dtype=torch.uint8, device="cuda")
+        del t
+print("after warm-up: reserved %.1f GB, peak allocated %.1f GB" % (torch.cuda.memory_reserved() / 2 ** 30, torch.cuda.max_memory_allocated() / 2 ** 30))
 gc.collect()
 gc.freeze()
 torch.cuda.synchronize()
