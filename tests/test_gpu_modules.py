@@ -324,6 +324,9 @@ def test_packed_images_are_bit_identical_to_the_packing_pass(mode):
     from jafpro_amd.networks import Accumulate_LSTM_no_loss, UNet_inpainter, VGG19_CRN
     prev = ops.set_precision(mode)
     prev_lazy = ops.set_lazy_resize(False)      # (the fused up-sampling has its own test; it is not bit-identical by design)
+    # bf16 storage rides on the packed images (ops.bf16_storage_active) and rounds the stored tensors once more: the identity
+    # under test is that of the images themselves, fp32 storage in both arms (tests/test_gpu_kernels.py covers the storage)
+    prev_storage = ops.set_bf16_storage(False)
     try:
         for cls, seed, T_ in ((Accumulate_LSTM_no_loss, 21, 3), (UNet_inpainter, 31, 1), (CRN_smaller, 41, 0), (VGG19_CRN, 71, 0)):
             res = []
@@ -382,6 +385,7 @@ def test_packed_images_are_bit_identical_to_the_packing_pass(mode):
     finally:
         ops.set_precision(prev)
         ops.set_lazy_resize(prev_lazy)
+        ops.set_bf16_storage(prev_storage)
 
 
 def test_lazy_resize_matches_resize_then_pack():
