@@ -173,6 +173,10 @@ int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const float* y, con
 int jaf_conv2d_pack_dz_dt(jaf_stream_t s, const void* dy, int dy_bf16, const float* y, const void* y_packed, int32_t y_ng8_tot,
                           int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                           void* packed, float* dz, float* dbias, int precision);
+/* ... and with y_packed a SPLIT-bf16 image (y_split = 1) while the dz image written is plain bf16 (JAF_PREC_BF16): "mixed" arithmetic. */
+int jaf_conv2d_pack_dz_dt2(jaf_stream_t s, const void* dy, int dy_bf16, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                           int32_t y_coff, int y_split, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                           void* packed, float* dz, float* dbias, int precision);
 /* jaf_convlstm_gates_bwd with the gate gradients written ONLY as the packed bf16 image
  * [N][G][4C/8][H*W][8], CHANNEL-MAJOR: packed channel 4*c + gate (one item = 2 hidden channels x i,f,o,g; its consumers:
  * jaf_conv2d_pack(JAF_PACK_DGRAD_LSTM) + jaf_conv2d_fwd_packed_io for d[x, h], jaf_conv2d_wgrad_packed_lstm for dW), and
@@ -258,6 +262,8 @@ typedef struct jaf_packed_io {
      * the float* / void* parameters.  The statistics of jaf_conv2d_fwd_packed_stats are taken from the unrounded values.
      * Reference: src/convLSTM.py:41-56 (c), src/crn_model.py:78-106 (pre-LayerNorm conv output), all fp32 there.          */
     int32_t out_bf16, out2_bf16, state_bf16;
+    int32_t dz_mask_split;   /* JAF_PREC_BF16 launches: `dz_mask` is a SPLIT-bf16 image (the sign is read from its hi planes) -- the forward
+                              * ran in JAF_PREC_BF16X3, this data gradient in bf16 ("mixed" arithmetic) */
 } jaf_packed_io;
 int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,
                              const void* packed_in, const void* packed_w, const float* bias, float* out,
@@ -292,6 +298,12 @@ int64_t jaf_conv2d_wgrad_packed_ws_bytes(const jaf_conv_desc* d, int32_t hidden)
 int jaf_conv2d_wgrad_packed_ws(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
                                const void* packed_dz, float* dw, int accumulate, int32_t hidden, void* workspace,
                                int64_t workspace_bytes);
+/* Same with the layout of packed_x given: x_split = 1 -- packed_x is a SPLIT-bf16 image (hi and lo plane per channel group, as the
+ * JAF_PREC_BF16X3 forward made it) of which this JAF_PREC_BF16 launch reads the hi planes only (a hi plane is exactly the bf16
+ * image): the "mixed" arithmetic of the host mirror -- parity-grade forward, bf16 backward. */
+int jaf_conv2d_wgrad_packed_ws_x(jaf_stream_t s, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot, int x_split,
+                                 const void* packed_dz, float* dw, int accumulate, int32_t hidden, void* workspace,
+                                 int64_t workspace_bytes);
 
 /* dW[G][Cout][w_cin_tot][KH][KW] (+)= sum over n,pixels of dz * input patch; dz is laid out as
  * the forward output (out_ctot/out_coff).  accumulate=0 zeroes the touched slice first.        */

@@ -84,7 +84,8 @@ class PackedIO(ctypes.Structure):
                 ("out2", ctypes.c_void_p), ("split_rows", ctypes.c_int32),
                 ("dz_mask", ctypes.c_void_p), ("dz_mask_ng8", ctypes.c_int32), ("dz_mask_coff", ctypes.c_int32),
                 ("dz_slope", ctypes.c_float), ("dz_dbias", ctypes.c_void_p),
-                ("out_bf16", ctypes.c_int32), ("out2_bf16", ctypes.c_int32), ("state_bf16", ctypes.c_int32)]
+                ("out_bf16", ctypes.c_int32), ("out2_bf16", ctypes.c_int32), ("state_bf16", ctypes.c_int32),
+                ("dz_mask_split", ctypes.c_int32)]
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4

@@ -659,6 +659,7 @@ struct PackDzArgs {
     float slope;
     int split;             // split-bf16 image (hi and lo planes per channel group): see PackInArgs
     int dy_bf16;           // dy holds bf16 (the gradient of a bf16-stored tensor: jaf_conv2d_pack_dz_dt)
+    int yp_split;          // the sign image `yp` is a split-bf16 image (hi planes read) whatever `split` says of the output
 };
 
 __device__ __forceinline__ float dz_of(float g, float yv, int act, float slope) {
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256) void conv_pack_dz_kernel(const PackDzArgs a) {
     float part[8];
     float ypk[8][V];       // y from the packed image: item (pixel i) holds this lane's 8 channels
     if (a.yp && live) {
-        const unsigned char* ip = a.yp + cd_item_off(((long)n * a.G + g) * a.yp_ng8 + a.yp_cg0, 1, cg, HW, (long)yy * a.W + x, a.split);
+        const unsigned char* ip = a.yp + cd_item_off(((long)n * a.G + g) * a.yp_ng8 + a.yp_cg0, 1, cg, HW, (long)yy * a.W + x, a.yp_split);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             const u32x4 w = *(const u32x4*)(ip + i * 16);
@@ -778,6 +779,13 @@ extern "C" int jaf_conv2d_pack_dz_prec(jaf_stream_t s, const float* dy, const fl
 extern "C" int jaf_conv2d_pack_dz_dt(jaf_stream_t s, const void* dy_, int dy_bf16, const float* y, const void* y_packed, int32_t y_ng8_tot,
                                      int32_t y_coff, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
                                      void* packed, float* dz, float* dbias, int precision) {
+    return jaf_conv2d_pack_dz_dt2(s, dy_, dy_bf16, y, y_packed, y_ng8_tot, y_coff, precision == JAF_PREC_BF16X3 ? 1 : 0, N, G, C, H, W, act,
+                                  slope, packed, dz, dbias, precision);
+}
+
+extern "C" int jaf_conv2d_pack_dz_dt2(jaf_stream_t s, const void* dy_, int dy_bf16, const float* y, const void* y_packed, int32_t y_ng8_tot,
+                                      int32_t y_coff, int y_split, int32_t N, int32_t G, int32_t C, int32_t H, int32_t W, int act, float slope,
+                                      void* packed, float* dz, float* dbias, int precision) {
     const float* dy = (const float*)dy_;
     JAF_REQUIRE(dy && packed && N >= 1 && G >= 1 && C >= 1 && H >= 1 && W >= 1);
     JAF_REQUIRE(precision == JAF_PREC_BF16 || precision == JAF_PREC_BF16X3);
@@ -791,6 +799,8 @@ extern "C" int jaf_conv2d_pack_dz_dt(jaf_stream_t s, const void* dy_, int dy_bf1
     a.yp = (const unsigned char*)y_packed; a.yp_ng8 = y_ng8_tot; a.yp_cg0 = y_coff / 8;
     a.split = precision == JAF_PREC_BF16X3 ? 1 : 0;       // (then y_packed is a split image too: the sign is read from its hi planes)
     a.dy_bf16 = dy_bf16 ? 1 : 0;
+    a.yp_split = y_split ? 1 : 0;
+    JAF_REQUIRE(!(precision == JAF_PREC_BF16X3 && y_packed && !y_split));      // (a split output next to a plain sign image: no such caller)
     const bool al = ((((uintptr_t)dy) | ((uintptr_t)y) | ((uintptr_t)dz)) & 15) == 0;
     if (al && W % 4 != 0 && ((long)H * W) % 4 == 0 && (long)H * W < (1L << 30)) { W = H * W; H = 1; }   // as in jaf_conv2d_pack_input
     a.N = N; a.G = G; a.C = C; a.H = H; a.W = W; a.ngroups8 = jaf_cdiv(C, 8); a.act = act; a.slope = slope;
@@ -1477,6 +1487,7 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.dz_slope = 0.f;
     a.dz_dbias = nullptr;
     a.out_bf16 = a.out2_bf16 = a.state_bf16 = 0;
+    a.dz_mask_split = 0;
 }
 
 static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm) {
@@ -1505,6 +1516,7 @@ static bool cd_io_ok(const jaf_conv_desc* d, const jaf_packed_io* io, bool lstm)
     if (io->out2 && (lstm || io->skip_f32 || (io->dst && !io->dz_mask) || io->split_rows < 1 || io->split_rows >= d->Cout)) return false;
     // bf16 storage of the NCHW outputs / the cell state: bf16 arithmetic only (the parity-grade modes keep fp32 tensors)
     if ((io->out_bf16 || io->out2_bf16 || io->state_bf16) && d->precision != JAF_PREC_BF16) return false;
+    if (io->dz_mask_split && (d->precision != JAF_PREC_BF16 || !io->dz_mask)) return false;
     if (io->state_bf16 && !lstm) return false;
     if ((io->out_bf16 || io->out2_bf16) && lstm) return false;
     return true;
@@ -1530,6 +1542,7 @@ static void cd_apply_io(ConvDArgs& a, const jaf_packed_io* io) {
     a.out_bf16 = io->out_bf16 ? 1 : 0;
     a.out2_bf16 = (io->out2 && io->out2_bf16) ? 1 : 0;
     a.state_bf16 = io->state_bf16 ? 1 : 0;
+    a.dz_mask_split = (io->dz_mask && io->dz_mask_split) ? 1 : 0;
 }
 
 extern "C" int jaf_conv2d_fwd_packed_io(jaf_stream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan,

@@ -48,6 +48,7 @@ struct ConvDArgs {
     // bf16 STORAGE of the NCHW tensors this launch writes (jaf_packed_io.out_bf16 / out2_bf16 / state_bf16; bf16 arithmetic only):
     // `out` (and what acc_out reads), `out2`, and the ConvLSTM's cell state (c_prev read, c_out written) hold bf16 instead of fp32
     int out_bf16, out2_bf16, state_bf16;
+    int dz_mask_split;     // the sign image of the dz mode is a split-bf16 image although this launch computes in bf16 ("mixed" arithmetic)
 };
 
 // Destination of channel `dc` (within a group) of pixel `pix` of (image, group) `ng` in a packed image with `ng8`
@@ -171,8 +172,9 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     for (int nt = 0; nt < NT; ++nt) {
                         mk[nt][0] = mk[nt][1] = 0u;
                         if (opix[nt] >= 0) {
-                            const unsigned int* xp2 = (const unsigned int*)cd_dst_ptr_s<SPD>((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8,
-                                                                                             a.dz_mask_coff + co0, OHW, opix[nt], 0);
+                            const unsigned int* xp2 = (!SPD && a.dz_mask_split)
+                                ? (const unsigned int*)cd_dst_ptr_s<true>((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8, a.dz_mask_coff + co0, OHW, opix[nt], 0)
+                                : (const unsigned int*)cd_dst_ptr_s<SPD>((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8, a.dz_mask_coff + co0, OHW, opix[nt], 0);
                             mk[nt][0] = xp2[0];
                             mk[nt][1] = xp2[1];
                         }

@@ -49,6 +49,8 @@ struct WgDArgs {
     float* ws;             // conv_wgrad_fast_kernel: split-K partials [nsplit][dW layout] (plain stores) instead of atomics into dw; NULL: atomics
     long ws_stride;        // floats of one partial = G * Cout * w_cin_tot * 9
     int off_lo;            // SPLIT: byte offset of the lo tiles from the hi tiles inside a tile buffer (patch and dz alike)
+    int xmul;              // !SPLIT: 2 when the x image is a split-bf16 image of which only the hi planes are read ("mixed" mode:
+                           // forward in split-bf16, backward in bf16 -- a hi plane IS the bf16 image), else 1
 };
 
 // PAIR (Cin <= 8, i.e. one packed item per position): the 16 columns of an MFMA are TWO taps x 8 channels instead of one
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         const int grp8 = (ci0 >> 3) + 2 * tci + half;
         const bool live = (i < nxi) && (r < a.PH) && (c < a.PW) && (grp8 < a.ngin8);
         x_rc[j] = live ? ((r << 16) | c) : -1;
-        x_goff[j] = ((SPLIT ? 2 * grp8 : grp8) * HW + r * d.W + c) * 16;
+        x_goff[j] = ((SPLIT ? 2 : a.xmul) * grp8 * HW + r * d.W + c) * 16;
     }
     // dz: instruction (co tile j, chunk = wave) covers slots [64*wave, +64) of co tile j (256 slots)
     int z_yx, z_goff, z_half;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
-    const int xbytes = a.xng8 * HW * 16 * (SPLIT ? 2 : 1);
+    const int xbytes = a.xng8 * HW * 16 * (SPLIT ? 2 : a.xmul);
     const int zbytes = a.ngout8 * OHW * 16 * (SPLIT ? 2 : 1);
 
     // DMA of one tile (image, pixel tile) into the buffer at byte offset `boff`
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
         slot_rc(i, r, c, hf);
         const int grp8 = (ci0 >> 3) + 2 * (i >> 3) + hf;
         const bool live = (r < PH) && (c < PW) && (grp8 < a.ngin8);
-        x_goff[j] = live ? ((SPLIT ? 2 * grp8 : grp8) * HW + r * d.W + c) * 16 : WD_OOB;
+        x_goff[j] = live ? ((SPLIT ? 2 : a.xmul) * grp8 * HW + r * d.W + c) * 16 : WD_OOB;
     }
     int z_yx, z_goff, z_half;
     {
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_fast_kernel(const WgDArgs a
 
     const int tiles = a.tiles_x * a.tiles_y;
     const int items = d.N * tiles;
-    const int xbytes = a.xng8 * HW * 16 * (SPLIT ? 2 : 1);
+    const int xbytes = a.xng8 * HW * 16 * (SPLIT ? 2 : a.xmul);
     const int zbytes = a.ngout8 * OHW * 16 * (SPLIT ? 2 : 1);
     const int count = split < items ? (items - split + a.nsplit - 1) / a.nsplit : 0;       // tiles of this pixel split
 
@@ -763,19 +765,19 @@ extern "C" int jaf_conv2d_wgrad_packed_ex(jaf_stream_t s_, const jaf_conv_desc* 
 }
 
 static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot, const void* packed_dz, float* dw,
-                    int accumulate, int32_t hidden, const WgWs* wr);
+                    int accumulate, int32_t hidden, const WgWs* wr, int x_split);
 
 extern "C" int jaf_conv2d_wgrad_packed_lstm(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot,
                                             const void* packed_dz, float* dw, int accumulate, int32_t hidden) {
     JAF_REQUIRE(d && packed_x && packed_dz && dw);
-    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, nullptr);
+    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, nullptr, 0);
 }
 
 extern "C" int64_t jaf_conv2d_wgrad_packed_ws_bytes(const jaf_conv_desc* d, int32_t hidden) {
     if (!d) return JAF_EINVAL;
     long need = 0;
     const WgWs wr = {nullptr, 0, &need};
-    const int rc = wgd_core(nullptr, d, nullptr, 0, nullptr, nullptr, 1, hidden, &wr);
+    const int rc = wgd_core(nullptr, d, nullptr, 0, nullptr, nullptr, 1, hidden, &wr, 0);
     return rc == JAF_OK ? (int64_t)need : (int64_t)rc;
 }
 
@@ -784,11 +786,20 @@ extern "C" int jaf_conv2d_wgrad_packed_ws(jaf_stream_t s_, const jaf_conv_desc* 
                                           int64_t workspace_bytes) {
     JAF_REQUIRE(d && packed_x && packed_dz && dw);
     const WgWs wr = {(float*)workspace, (long)workspace_bytes, nullptr};
-    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, workspace ? &wr : nullptr);
+    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, workspace ? &wr : nullptr, 0);
+}
+
+extern "C" int jaf_conv2d_wgrad_packed_ws_x(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot, int x_split,
+                                            const void* packed_dz, float* dw, int accumulate, int32_t hidden, void* workspace,
+                                            int64_t workspace_bytes) {
+    JAF_REQUIRE(d && packed_x && packed_dz && dw);
+    JAF_REQUIRE(!x_split || d->precision == JAF_PREC_BF16);
+    const WgWs wr = {(float*)workspace, (long)workspace_bytes, nullptr};
+    return wgd_core(s_, d, packed_x, x_ng8_tot, packed_dz, dw, accumulate, hidden, workspace ? &wr : nullptr, x_split ? 1 : 0);
 }
 
 static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_x, int32_t x_ng8_tot, const void* packed_dz, float* dw,
-                    int accumulate, int32_t hidden, const WgWs* wr) {
+                    int accumulate, int32_t hidden, const WgWs* wr, int x_split) {
     const bool query = wr && wr->need;
     JAF_REQUIRE(hidden == 0 || (hidden > 0 && d->KH == 3 && d->Cout == 4 * hidden));
     JAF_REQUIRE(x_ng8_tot == 0 || x_ng8_tot >= jaf_cdiv(d->Cin, 8));
@@ -849,7 +860,8 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     a.ngout8 = jaf_cdiv(d->Cout, 8);
     a.xng8 = x_ng8_tot ? x_ng8_tot : a.ngin8;
     a.inv_pwp = 1.0f / (float)a.PWp;
-    JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 * (split ? 2 : 1) < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 * (split ? 2 : 1) < WD_OOB);
+    a.xmul = (x_split && !split) ? 2 : 1;
+    JAF_REQUIRE((long)a.xng8 * d->H * d->W * 16 * (split ? 2 : a.xmul) < WD_OOB && (long)a.ngout8 * d->OH * d->OW * 16 * (split ? 2 : 1) < WD_OOB);
     int lds = a.off_dz + MTW * 4096;
     a.off_lo = split ? lds : 0;
     if (split) lds *= 2;

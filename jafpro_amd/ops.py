@@ -81,7 +81,11 @@ _PRECISION = PREC_F32
 # The bf16 modes run on the packed-input (DMA-staged) kernels of csrc/conv_dma.hip / conv_dma_split.hip -- the only bf16 kernels
 # there are since round 5 (the fp32-input staging kernels of rounds 1-2 were deleted); f32 runs on csrc/conv.hip.
 _USE_PACKED = True
-_PREC_NAMES = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3}
+_PREC_NAMES = {"f32": PREC_F32, "bf16": PREC_BF16, "bf16x3": PREC_BF16X3, "mixed": PREC_BF16X3}
+# "mixed": the forward pass in split-bf16 (parity-grade: the generated frame and every loss <= 1e-3 of the fp32 oracle), the backward
+# pass -- data and weight gradients -- in plain bf16.  The forward's saved operand images are split images; a backward launch reads
+# their hi planes, which ARE the bf16 images (jaf_conv2d_wgrad_packed_ws_x, jaf_packed_io.dz_mask_split, jaf_conv2d_pack_dz_dt2).
+_MIXED = False
 
 
 def set_precision(name: str) -> str:
@@ -89,16 +93,28 @@ def set_precision(name: str) -> str:
     JAF_PREC_*): "f32" exact fp32 MFMA (the <=1e-3 parity path), "bf16" bf16 operands / fp32
     accumulate (BASELINE configs[2]), "bf16x3" split-bf16 (hi+lo) emulation of fp32 products.
     Tensors stay fp32 in HBM in every mode.  Returns the previous setting."""
-    global _PRECISION
+    global _PRECISION, _MIXED
     if name not in _PREC_NAMES:
         raise ValueError("precision must be one of %s" % sorted(_PREC_NAMES))
     prev = get_precision()
     _PRECISION = _PREC_NAMES[name]
+    _MIXED = name == "mixed"
     return prev
 
 
 def get_precision() -> str:
-    return {v: k for k, v in _PREC_NAMES.items()}[_PRECISION]
+    if _MIXED:
+        return "mixed"
+    return {PREC_F32: "f32", PREC_BF16: "bf16", PREC_BF16X3: "bf16x3"}[_PRECISION]
+
+
+def _bwd_mode():
+    """(arithmetic, packed) a node created now runs its backward pass in: the forward's, except under "mixed"."""
+    return (PREC_BF16 if _MIXED else _PRECISION, _USE_PACKED)
+
+
+def _fwd_key():
+    return (_PRECISION, _MIXED)
 
 
 # bf16 STORAGE in the "bf16" arithmetic mode (BASELINE configs[2] names bf16; SURVEY 8(d) "bf16 storage / fp32 accumulate"): tensors
@@ -128,13 +144,14 @@ class _arith:
         self.mode = mode
 
     def __enter__(self):
-        global _PRECISION, _USE_PACKED
-        self.prev = (_PRECISION, _USE_PACKED)
+        global _PRECISION, _USE_PACKED, _MIXED
+        self.prev = (_PRECISION, _USE_PACKED, _MIXED)
         _PRECISION, _USE_PACKED = self.mode
+        _MIXED = False              # (inside a backward pass every launch is of the one arithmetic the node says)
 
     def __exit__(self, *exc):
-        global _PRECISION, _USE_PACKED
-        _PRECISION, _USE_PACKED = self.prev
+        global _PRECISION, _USE_PACKED, _MIXED
+        _PRECISION, _USE_PACKED, _MIXED = self.prev
         return False
 
 
@@ -398,8 +415,9 @@ def _io_struct(prepacked: Optional[PackedImage], dst: Optional[PackedDst], skip_
     io = PackedIO()
     io.out_bf16, io.out2_bf16, io.state_bf16 = int(out_bf16), int(out2_bf16), int(state_bf16)
     if dz_fuse is not None:       # (mask image buffer, its planes per (image, group), channel offset, act' below zero, dbias or None)
-        mbuf, mng8, mcoff, mslope, dbias = dz_fuse
+        mbuf, mng8, mcoff, mslope, dbias = dz_fuse[:5]
         io.dz_mask, io.dz_mask_ng8, io.dz_mask_coff, io.dz_slope = mbuf.data_ptr(), int(mng8), int(mcoff), float(mslope)
+        io.dz_mask_split = 1 if (len(dz_fuse) > 5 and dz_fuse[5] and _PRECISION == PREC_BF16) else 0
         io.dz_dbias = dbias.data_ptr() if dbias is not None else None
     io.accumulate_f32 = 1 if accumulate else 0
     if out2 is not None:
@@ -899,7 +917,7 @@ def _fusable_producer(t: torch.Tensor, spec):
     if fn is None or type(fn).__name__ != "_ConvFnBackward" or spec[3] == 0:
         return None
     pm = getattr(fn, "meta", None)
-    if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or not _packed_path_now() or getattr(fn, "mode", None) != (_PRECISION, True):
+    if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or not _packed_path_now() or getattr(fn, "fwd_key", None) != _fwd_key():
         return None
     if pm.G * pm.Cout != t.shape[1] or spec[0] != pm.Cout:          # the whole output, group for group
         return None
@@ -937,8 +955,8 @@ def _conv_wgrad(ctx, m, weight, srcs, dz, dzp, inplace: bool, stream=None):
                              [(m.Cout, m.G * m.Cout, 0, m.Cout)], 1, 0, m.G, 0, ACT_NONE, 0.0)
             dzp = pack_input([dz], dzd)
         wsp, wsb = _wgrad_workspace(d, 0, sh.value if stream is not None else torch.cuda.current_stream().cuda_stream, dw.device)
-        check(L.jaf_conv2d_wgrad_packed_ws(sh, ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), _p(dzp), _p(dw),
-                                           1 if inplace else 0, 0, wsp, wsb), "jaf_conv2d_wgrad_packed_ws")
+        check(L.jaf_conv2d_wgrad_packed_ws_x(sh, ctypes.byref(d), _p(ctx.xp), getattr(ctx, "xp_ng8", 0), 1 if getattr(ctx, "x_split", False) else 0,
+                                             _p(dzp), _p(dw), 1 if inplace else 0, 0, wsp, wsb), "jaf_conv2d_wgrad_packed_ws_x")
         wname = _launched() if ev is not None else ""
     else:
         check(L.jaf_conv2d_wgrad(sh, ctypes.byref(d), ps[0], ps[1], ps[2], _p(dz), _p(dw), 1 if inplace else 0),
@@ -972,7 +990,9 @@ class _ConvFn(Function):
         ctx.xp = xp if (xp is not None and ctx.needs_input_grad[0] and _wgrad_packed_ok(m)) else None
         ctx.xp_ng8 = m.prepacked.ng8 if (use_img and m.prepacked is not None) else 0
         ctx.meta = m
-        ctx.mode = (_PRECISION, _USE_PACKED)
+        ctx.mode = _bwd_mode()
+        ctx.fwd_key = _fwd_key()
+        ctx.x_split = _MIXED            # the saved images are split images read by a bf16 backward pass
         ctx.has_bias = bias is not None
         ctx.bias_ref = bias
         ctx.slots = [_slot_of(t) for t in srcs]
@@ -1041,10 +1061,10 @@ class _ConvFn(Function):
                     if yimg is not None:
                         img, ycoff, yoff = yimg
                         yper = img.per_image
-                        check(L.jaf_conv2d_pack_dz_dt(_s(), _p(dy[n0:n1]), dyb, None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
-                                                      img.ng8, ycoff, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
-                                                      _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
-                                                      _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_dt")
+                        check(L.jaf_conv2d_pack_dz_dt2(_s(), _p(dy[n0:n1]), dyb, None, _p(img.buf[(yoff + n0) * yper:(yoff + n1) * yper]),
+                                                       img.ng8, ycoff, 1 if img.split else 0, n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope,
+                                                       _p(dzp[n0 * per:n1 * per]), _p(dz[n0:n1]) if dz is not None else None,
+                                                       _p(dbt), _PRECISION), "jaf_conv2d_pack_dz_dt2")
                         continue
                     check(L.jaf_conv2d_pack_dz_dt(_s(), _p(dy[n0:n1]), dyb, _p(y[n0:n1]) if m.act != ACT_NONE else None, None, 0, 0,
                                                   n1 - n0, m.G, m.Cout, m.OH, m.OW, m.act, m.slope, _p(dzp[n0 * per:n1 * per]),
@@ -1087,7 +1107,7 @@ class _ConvFn(Function):
                                        m.OH, m.OW, m.H, m.W, m.KH, m.KW, 1, pad_d, pad_d, m.stride, m.cin_tot, coff, ACT_NONE, 0.0,
                                        xp=dzp, want_xp=True, out=first, out_ctot=(m.G * c) if first is not None else None,
                                        accumulate=first is not None, dst=dzimg.slot(0, 0, pad_tail=True), skip_f32=first is None,
-                                       dz_fuse=(mbuf, mng8, coff, pm.slope if pm.act == ACT_LRELU else 0.0, pdb))
+                                       dz_fuse=(mbuf, mng8, coff, pm.slope if pm.act == ACT_LRELU else 0.0, pdb, getattr(ctx, "x_split", False)))
                     if first is None and g.dtype != t.dtype:
                         g = torch.empty_strided(tuple(g.shape), (0, 0, 0, 0), device=g.device, dtype=t.dtype)     # (placeholder in the edge's type)
                     prod.fused = (dzimg.buf, _dz_bias_finish(prod, pdb, m.G * c))
@@ -1376,7 +1396,9 @@ class _ConvLSTMFn(Function):
         ctx.xp_ng8 = seq_image.ng8 if use_img else 0
         ctx.h_skipped = skip_h
         ctx.st16 = st16
-        ctx.mode = (_PRECISION, _USE_PACKED)        # backward uses the arithmetic the forward ran in
+        ctx.mode = _bwd_mode()                      # backward uses the arithmetic the forward ran in ("mixed": bf16)
+        ctx.fwd_key = _fwd_key()
+        ctx.x_split = _MIXED
         if keep:
             ctx.save_for_backward(x, weight, hs, cs, gates, h0, c0)
         ctx.slot = _slot_of(x)
@@ -1477,8 +1499,8 @@ class _ConvLSTMFn(Function):
                     ev = _PROF.begin() if _PROF is not None else None
                     # (the packed gate gradients are channel-major, 4 c + gate: the kernel permutes the rows of dW)
                     wsp, wsb = _wgrad_workspace(d, C, torch.cuda.current_stream().cuda_stream, dw.device)
-                    check(L.jaf_conv2d_wgrad_packed_ws(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, _p(gtp), _p(dw),
-                                                       1 if w_inplace else acc, C, wsp, wsb), "jaf_conv2d_wgrad_packed_ws")
+                    check(L.jaf_conv2d_wgrad_packed_ws_x(_s(), ctypes.byref(d), _p(ctx.xps[t]), ctx.xp_ng8, 1 if getattr(ctx, "x_split", False) else 0,
+                                                         _p(gtp), _p(dw), 1 if w_inplace else acc, C, wsp, wsb), "jaf_conv2d_wgrad_packed_ws_x")
                     if ev is not None:
                         _PROF.end(_launched(), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:
@@ -1510,14 +1532,14 @@ class _ConvLSTMFn(Function):
                 # gradients (4C channels) are read once instead of twice
                 dh = torch.empty((N, GC, H, W), device=x.device, dtype=sdt)
                 fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
-                                                    dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
+                                                    dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb, getattr(ctx, "x_split", False)))
                 _, gtp = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, 2 * C, H, W, H, W, 3, 3, 1, 1, 1,
                                    1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=2 * GC, out_coff=0, xp=gtp, want_xp=True,
                                    accumulate=dx_first is not None, out2=dh, split=C, **(fz or {}))
             else:
                 if dx is not None:
                     fz = None if prod is None else dict(dst=dzimg.images(t * N, N).slot(0, 0, pad_tail=True),
-                                                        dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb))
+                                                        dz_fuse=(ctx.xps[t], ctx.xp_ng8, 0, pslope, pdb, getattr(ctx, "x_split", False)))
                     _, gtp = _conv_raw([gt], gspec, weight, 4 * C, dmode, None, N, G, 4 * C, C, H, W, H, W, 3, 3, 1, 1, 1,
                                        1, 2 * C, 0, ACT_NONE, 0.0, out=dx[t], out_ctot=GC, out_coff=0, xp=gtp, want_xp=True,
                                        accumulate=dx_first is not None, **(fz or {}))
@@ -1573,7 +1595,7 @@ def _ln_producer(x: torch.Tensor):
     if not _FUSED_DZ or fn is None or type(fn).__name__ != "_ConvFnBackward":
         return None
     pm = getattr(fn, "meta", None)
-    if pm is None or pm.act != ACT_NONE or pm.G != 1 or pm.Cout != x.shape[1] or getattr(fn, "mode", None) != (_PRECISION, True):
+    if pm is None or pm.act != ACT_NONE or pm.G != 1 or pm.Cout != x.shape[1] or getattr(fn, "fwd_key", None) != _fwd_key():
         return None
     if getattr(fn, "y_img", None) is not None or (fn.needs_input_grad[0] and fn.xp is None):
         return None
@@ -1616,11 +1638,17 @@ class _LayerNormLReLUFn(Function):
             check(L.jaf_layernorm_lrelu_fwd_dt(_s(), _p(x), xb, _p(stats), _p(gamma), _p(beta), _p(y), N, C, H * W, slope),
                   "jaf_layernorm_lrelu_fwd_dt")
         ctx.eps, ctx.slope = eps, slope
+        ctx.mode = _bwd_mode()
         ctx.save_for_backward(x, gamma, beta, stats)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        with _arith(ctx.mode):
+            return _LayerNormLReLUFn._backward(ctx, dy)
+
+    @staticmethod
+    def _backward(ctx, dy):
         x, gamma, beta, stats = ctx.saved_tensors
         N, C, H, W = x.shape
         dy = _c(dy)
@@ -1633,7 +1661,7 @@ class _LayerNormLReLUFn(Function):
         dbeta = beta.grad if bi else torch.zeros_like(beta)
         ws = torch.empty(32 * N, device=x.device, dtype=torch.float64)      # [N][16 slots][2], include/jafpro_hip.h
         prod = getattr(ctx, "prod", None)
-        if prod is not None and _packed_path_now() and prod.mode == (_PRECISION, True):
+        if prod is not None and _packed_path_now() and prod.mode == ctx.mode:
             ctx.prod = None
             dzp = torch.empty(N * ((C + 7) // 8) * H * W * 16 * (2 if _PRECISION == PREC_BF16X3 else 1), device=x.device, dtype=torch.uint8)
             scratch = torch.empty(2 * N * C, device=x.device, dtype=torch.float32)

@@ -143,7 +143,7 @@ def test_train_step_with_gradient_overlap_on_one_rank_group():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "mixed"])
 def test_forward_clip_parity(mode):
     """BASELINE config 2 (test/conv_pro_test.py -n 4, forward only, fp32): B=2 clips, 3 target frames each,
     every frame propagated from the reference nearest in time: pred_target <= 1e-3 L-inf vs the CPU oracle's

@@ -143,6 +143,23 @@ def test_train_step_bf16x3_is_parity_grade():
     check_step_golden("s330_u0123_p0", out, mods, grad_bars=SUBSET_GRAD_BARS, bn_tol=1e-4, tag="bf16x3")
 
 
+def test_train_step_mixed_forward_is_parity_grade():
+    """ops.set_precision("mixed"): forward in split-bf16 -- frame <= 1e-3 L-inf, losses 2e-3, BatchNorm statistics 1e-4, the fp32
+    bars -- and the whole backward pass in plain bf16 reading the hi planes of the forward's split images (weight gradients:
+    jaf_conv2d_wgrad_packed_ws_x; sign masks of the fused activation backward: jaf_packed_io.dz_mask_split, jaf_conv2d_pack_dz_dt2):
+    gradients within the bf16 bars (measured well inside them: the forward they start from is exact)."""
+    from jafpro_amd import ops
+    M, tr, _, batch, dbatch, mods = build(2, seed=322)
+    prev = ops.set_precision("mixed")
+    try:
+        assert ops.get_precision() == "mixed"
+        out = tr.train_step(dbatch)
+    finally:
+        ops.set_precision(prev)
+    assert ops.get_precision() == prev
+    check_step_golden("s322_b2", out, mods, frame_tol=1e-3, loss_tol=2e-3, grad_bars=BF16_GRAD_BARS, bn_tol=1e-4, tag="mixed B=2")
+
+
 def test_bf16_second_step_uses_refreshed_weight_images():
     """Two bf16 steps; the packed weight images were re-made IN PLACE on a side stream after each Adam
     (ops.refresh_packed_weights).  A forward that uses those cached images must equal, bit for bit, a forward that
