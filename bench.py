@@ -185,7 +185,7 @@ def main():
     ap.add_argument("--no-config2", action="store_true", help="skip the forward-only BASELINE configs[1] figure (N=1 only)")
     ap.add_argument("--no-frame-parity", action="store_true",
                     help="skip the in-run frame L-inf of each arithmetic mode against the oracle's B=8 fixture (N=1, 256 only)")
-    ap.add_argument("--preheat", type=float, default=float(os.environ.get("JAF_BENCH_PREHEAT", "0")),
+    ap.add_argument("--preheat", type=float, default=0.0,
                     help="seconds of synthetic matrix-multiply load before the warm-up steps (not steps; reported as preheat_s)")
     ap.add_argument("--no-prefetch", action="store_true", help="prepare each clip inside its own step instead of one step ahead")
     ap.add_argument("--graph", action="store_true",
@@ -274,7 +274,7 @@ def main():
     # warp, frozen background CRN) is issued on the side HIP stream under this clip's loss backward.
     # Every step still performs exactly one preparation (the same synthetic clip is fed again).
     nb = None if args.no_prefetch else batch
-    if os.environ.get("JAF_CHAIN_PRIORITY", "1") == "1" and not args.serial_streams:
+    if not args.serial_streams:
         # the training loop runs under a HIGH-PRIORITY HIP stream (ops.chain_stream): the step's dependent chain then wins
         # the CUs whenever it competes with the side streams' work (weight gradients, next clip's preparation, perceptual
         # loss, weight re-packing).  Measured 63.63 -> 63.28 ms/step (two A/B pairs on one box).

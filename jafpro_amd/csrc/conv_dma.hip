@@ -571,7 +571,7 @@ extern "C" int jaf_conv2d_pack_input_resized(jaf_stream_t s, const jaf_conv_desc
     const bool al = ((((uintptr_t)src0) | ((uintptr_t)src1) | ((uintptr_t)src2)) & 15) == 0;
     // Channel groups inside one resized source: conv_pack_up_kernel; the others (label / skip channels, groups that straddle two
     // sources): the general kernels over the remaining group ranges.  JAF_PACK_UP=0 sends everything through the general kernels.
-    static const int up_env = getenv("JAF_PACK_UP") ? atoi(getenv("JAF_PACK_UP")) : 1;
+    const int up_env = 1;
     const bool up_ok = up_env && staged && d->W % 4 == 0;
     const int cb[4] = {0, d->src_c[0], d->src_c[0] + (d->nsrc > 1 ? d->src_c[1] : 0), d->Cin};
     const float* srcs[3] = {src0, src1, src2};
@@ -976,8 +976,7 @@ extern "C" int jaf_convlstm_gates_bwd_packed_dt(jaf_stream_t s, int32_t N, int32
     const int per_block = 256 * V;
     // one pixel block per workgroup: measured 0.63 / 0.31 / 0.155 ms at the 200 / 100 / 50 levels against 0.68 / 0.34-0.45 / 0.17
     // with 4-8 blocks per workgroup (fewer bias atomics, but fewer and unevenly loaded workgroups)
-    static const int it_env = getenv("JAF_LSTM_GATES_ITERS") ? atoi(getenv("JAF_LSTM_GATES_ITERS")) : 0;
-    const int iters = it_env > 0 ? it_env : 1;
+    const int iters = 1;
     const dim3 grid(jaf_cdiv(HW, per_block * iters), C / 2, N * G);
 #define JAF_LGC(V_, T_, D_, S_)                                                                                  \
     hipLaunchKernelGGL((lstm_gates_bwd_cmajor_kernel<V_, T_, D_, S_>), grid, dim3(256), 0, (hipStream_t)s, G, C, HW, (const D_*)dh, \
@@ -1248,8 +1247,7 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     const int ngcap = 4;          // channel groups of 8 per chunk (slot table and DMA rounds are sized for <= 4)
     const int cand_tw[4] = {16, 32, 64, d->OW};
     // experiment hooks (scratch/mb_part.py): restrict the search to one NT / one tile width
-    static const int force_nt = getenv("JAF_PLAN_NT") ? atoi(getenv("JAF_PLAN_NT")) : 0;
-    static const int force_tw = getenv("JAF_PLAN_TW") ? atoi(getenv("JAF_PLAN_TW")) : 0;
+    const int force_nt = 0, force_tw = 0;
     for (int cMT = mt_hi; cMT >= mt_lo; --cMT)
     for (int ci = 0; ci < 4; ++ci) {
         const int TW = cand_tw[ci];
@@ -1296,7 +1294,7 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 // the 256 -> 256 layer add up): where a launch has at least 4 workgroups per CU to run, 4 resident ones on half-size
                 // chunks beat 2 on full-size chunks by 2-11 % in spite of 10 % of padded k-steps (measured, 64 x 64 .. 256 x 256
                 // layers); with fewer workgroups than that the larger chunks win by 15-19 % (32 x 32 layers)
-                static const double pen2 = getenv("JAF_PLAN_PEN2") ? atof(getenv("JAF_PLAN_PEN2")) : 1.25;
+                const double pen2 = 1.25;
                 const double nblocks0 = (double)tiles_x * tiles_p * jaf_cdiv(M, 16 * MT) * d->N * d->G;
                 const bool big = nblocks0 >= 1024.0;
                 const double occ_pen = bl >= 4 ? 1.0 : (bl == 3 ? (big ? 0.5 * (1.0 + pen2) : 1.0) : (bl == 2 ? (big ? pen2 : 1.1) : 1.4));
@@ -1410,8 +1408,7 @@ static int cd_launch_one(const ConvDArgs& a_in, hipStream_t s) {
         }
     }
     if constexpr (!LSTM) {
-        static const int no_plain = getenv("JAF_NO_PLAIN_CONV") ? 1 : 0;
-        if (!no_plain && !a.dst && !a.stats && !a.acc_out && !a.out2 && !a.skip_f32) {
+        if (!a.dst && !a.stats && !a.acc_out && !a.out2 && !a.skip_f32) {
             auto kp = conv_dma_kernel<MT, NT, false, false, true>;
             static int optin_p[JAF_MAX_DEVICES];
             if (lds > 48 * 1024) {

@@ -18,7 +18,7 @@ static inline long jaf_wgrad_nsplit(long items, long outblocks, long dw_floats, 
     const double atomics_per_s = 3e11;
     // experiment hook: workgroup slots a weight-gradient launch is sized for (768 = the whole chip at 3 per CU; the kernels run
     // beside the data-gradient chain on their own stream)
-    static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
+    const double slots_env = 0.0;
     if (slots_env > 0.0 && slots == 768.0) slots = slots_env;
     long best = 1;
     double best_t = 1e30;

@@ -471,9 +471,8 @@ extern "C" int jaf_resize_bwd_dt(jaf_stream_t s, const void* dy, int dy_bf16, fl
     // candidate region of one (b.x, b.y * rows) tile: (pixels + 1) / scale + 4 per axis (resize_cand), capped by the image.
     // rows per lane: as many (<= 8, tile no taller than the plane) as keep the region within 40 KB and leave the launch >= 2048 workgroups
     long rw = 0, rh = 0;
-    static const int rows_env = getenv("JAF_RESIZE_BWD_ROWS") ? atoi(getenv("JAF_RESIZE_BWD_ROWS")) : 0;      // experiment hook
     // 8 rows per lane on planes of at least 50 rows: -5..13 % against 4 on the 50 -> 100 .. 128 -> 256 adjoints (32 -> 64: +30 %)
-    int rows = rows_env > 0 ? rows_env : (H >= 50 ? 8 : 4);
+    int rows = H >= 50 ? 8 : 4;
     for (;; rows >>= 1) {
         rw = a.sx > 0.f ? (long)ceilf(((float)b.x + 1.f) / a.sx) + 4 : OW;
         rh = a.sy > 0.f ? (long)ceilf(((float)(b.y * rows) + 1.f) / a.sy) + 4 : OH;

@@ -678,7 +678,7 @@ static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long
         const int e = jaf_lds_optin((const void*)k, optin);
         if (e) return e;
     }
-    static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
+    const double slots_env = 0.0;
     const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
     a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
@@ -686,8 +686,8 @@ static int wgd_launch_fast(WgDArgs& a, int lds, long items, long outblocks, long
     a.ws_stride = (long)a.d.G * a.d.Cout * a.d.w_cin_tot * 9;
     if (wr) {
         // a split costs a store + a load of dW at HBM rate instead of an atomic pass (~4x cheaper): the optimum has more splits
-        static const double part_rate = getenv("JAF_WGRAD_PART_RATE") ? atof(getenv("JAF_WGRAD_PART_RATE")) : 1.0e12;
-        static const long part_min = getenv("JAF_WGRAD_PART_MIN") ? atol(getenv("JAF_WGRAD_PART_MIN")) : 6000000L;      // floats of atomic traffic
+        const double part_rate = 1.0e12;
+        const long part_min = 6000000L;      // floats of atomic traffic
         const int nsp = (int)jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots, 2.5e-6, JAF_WGRAD_MAX_SPLIT, part_rate);
         constexpr int WKC = 4 / WC;        // waves that share an input-channel tile hold partial sums over their own k-steps: one copy each
         const long need = (nsp >= 2 && (long)a.nsplit * dw_floats >= part_min) ? (long)nsp * WKC * a.ws_stride * 4 : 0;
@@ -725,7 +725,7 @@ static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long d
     }
     // every pixel split adds one fp32 atomic pass over dW (profiles/round1_b_pmc_hbm_traffic.txt: ~116 MB of atomic
     // traffic per launch at 1536 workgroups) and contends for the same addresses: see jaf_wgrad_nsplit
-    static const double slots_env = getenv("JAF_WGRAD_SLOTS") ? atof(getenv("JAF_WGRAD_SLOTS")) : 0.0;
+    const double slots_env = 0.0;
     const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
     a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
                                      : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
@@ -836,8 +836,8 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     // split-bf16: hi and lo tiles of both operands; keep two workgroups per CU (<= 80 KB) where the channel tiling allows
     while (split && a.WC > 1 && 2 * (a.WC * a.xplane + MTW * 4096) > 80 * 1024) a.WC >>= 1;
     // narrower input-channel tiles where that lets the split tile be double-buffered (<= 40 KB): bf16x3 step 116.2 -> 115.5 ms
-    // (two alternating pairs); JAF_WGRAD_SPLIT_DB=0 switches it off
-    static const int split_db = getenv("JAF_WGRAD_SPLIT_DB") ? atoi(getenv("JAF_WGRAD_SPLIT_DB")) : 1;
+    // (two alternating pairs)
+    const int split_db = 1;
     if (split && split_db && d->stride == 1 && 2 * (a.xplane + MTW * 4096) <= 40 * 1024)
         while (a.WC > 1 && 2 * (a.WC * a.xplane + MTW * 4096) > 40 * 1024) a.WC >>= 1;
     {   // launches that cannot fill the chip: smaller output blocks = more, shorter workgroups (see jafb_wgrad)
@@ -866,8 +866,8 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     a.off_lo = split ? lds : 0;
     if (split) lds *= 2;
     // two tile buffers when two workgroups per CU still fit (see the kernel's header)
-    static const int no_db = getenv("JAF_WGRAD_NO_DB") ? 1 : 0;
-    static const int db_max = getenv("JAF_WGRAD_DB_MAX_KB") ? atoi(getenv("JAF_WGRAD_DB_MAX_KB")) : 40;      // experiment hook
+    const int no_db = 0;
+    const int db_max = 40;
     const bool db = (!split || split_db) && !no_db && lds <= db_max * 1024;
     a.bufsz = db ? lds : 0;
     if (db) lds *= 2;
@@ -878,9 +878,9 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
     const long outblocks = (long)d->G * a.coblocks * a.ciblocks;
     const long dw_floats = (long)d->G * d->Cout * d->Cin * KS * KS;
-    // the stride-1 3 x 3 layers: conv_wgrad_fast_kernel, in the buffering the rules above give each tiling (JAF_WGRAD_FAST=0, or a
-    // JAF_WGRAD_* experiment hook that changes the buffering, falls back to the general kernel)
-    static const int fast_env = getenv("JAF_WGRAD_FAST") ? atoi(getenv("JAF_WGRAD_FAST")) : 1;
+    // the stride-1 3 x 3 layers: conv_wgrad_fast_kernel, in the buffering the rules above give each tiling (the general kernel
+    // takes what they do not cover)
+    const int fast_env = 1;
     if (fast_env && !split && KS == 3 && d->stride == 1 && a.nx == 8 && a.PWp == 24) {
 #define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_>(a, lds, items, outblocks, dw_floats, s, wr)
         JAF_WGF(1, true, 4); JAF_WGF(2, true, 4); JAF_WGF(3, false, 4); JAF_WGF(4, false, 4);
@@ -889,7 +889,7 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
 #undef JAF_WGF
     }
     // split-bf16: the tilings the LDS rules above produce (64 rows: 32 or 16 channels single-buffered; fewer rows: 16 channels double-buffered)
-    static const int fast_split_env = getenv("JAF_WGRAD_FAST_SPLIT") ? atoi(getenv("JAF_WGRAD_FAST_SPLIT")) : 1;
+    const int fast_split_env = 1;
     if (fast_env && fast_split_env && split && KS == 3 && d->stride == 1 && a.nx == 8 && a.PWp == 24) {
 #define JAF_WGF(MT_, DB_, WC_) if (MTW == MT_ && db == DB_ && a.WC == WC_) return wgd_launch_fast<MT_, DB_, WC_, true>(a, lds, items, outblocks, dw_floats, s, wr)
         JAF_WGF(4, false, 2); JAF_WGF(4, false, 1); JAF_WGF(3, true, 1); JAF_WGF(2, true, 1); JAF_WGF(1, true, 2); JAF_WGF(1, true, 1);

@@ -25,9 +25,8 @@ NPARTS = 24
 ENC_NC = [12, 24, 24, 24, 24, 48, 48, 96, 96]          # src/networks.py:1602
 ENC_K = [5, 3, 3, 3, 3, 3, 3, 3, 3]                     # enc1 is 5x5 pad 2 (:1294)
 ENC_S = [1, 2, 1, 2, 1, 2, 1, 2, 1]
-_DEC_PACKED_OUT = os.environ.get("JAF_DEC_PACKED_OUT", "1") != "0"      # dec4 writes the output convolution's packed image
-_VGG_SKIP_F32 = os.environ.get("JAF_VGG_SKIP_F32", "1") != "0"      # untapped VGG conv -> conv layers write no fp32 output
-_ENC_KEEP_S2 = os.environ.get("JAF_ENC_KEEP_S2", "0") == "1"      # A/B: the (unread) fp32 copies in front of the wide stride-2 layers
+_DEC_PACKED_OUT = True      # dec4 writes the output convolution's packed image
+_VGG_SKIP_F32 = True        # untapped VGG conv -> conv layers write no fp32 output
 SIZES = [200, 100, 50, 25, 13]
 
 
@@ -131,8 +130,8 @@ class _PartEncoderMixin:
             # fp32 copy of the output only where something still reads it: in the inpainter, the decoder's skip / resize inputs.
             # (Until round 4 also in front of the stride-2 layers wider than 16 channels, whose weight gradient once ran on the
             # fp32-input kernel; it has long read the packed image, and those copies -- 737 + 184 + 92 MB per step in the accumulate
-            # net alone -- were written for nobody: -0.35 ms per step, JAF_ENC_KEEP_S2=1 brings them back.)
-            keep = (_ENC_KEEP_S2 and i < 8 and ENC_S[i + 1] == 2 and c > 16) or (tap is None and i % 2 == 0)
+            # net alone -- were written for nobody: -0.35 ms per step.)
+            keep = tap is None and i % 2 == 0
             x = _lrelu_conv(x, getattr(self, "enc%d_w" % (i + 1)), getattr(self, "enc%d_b" % (i + 1)), stride=s, pad=k // 2,
                             prepacked=img_in, dst=dst, keep_f32=keep)
             if i % 2 == 1:

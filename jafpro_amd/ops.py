@@ -374,7 +374,7 @@ class PackedDst:
         self.image, self.coff, self.img_off, self.pad_tail = image, int(coff), int(img_off), bool(pad_tail)
 
 
-_PACKED_IMAGES = os.environ.get("JAF_NO_PACKED_IMAGES") is None
+_PACKED_IMAGES = True
 
 
 def set_packed_images(flag: bool) -> bool:
@@ -384,8 +384,8 @@ def set_packed_images(flag: bool) -> bool:
     return prev
 
 
-_Y_SIGN_FROM_IMAGE = os.environ.get("JAF_NO_Y_SIGN_FROM_IMAGE") is None
-_LAZY_RESIZE = os.environ.get("JAF_NO_LAZY_RESIZE") is None
+_Y_SIGN_FROM_IMAGE = True
+_LAZY_RESIZE = True
 
 
 def set_lazy_resize(flag: bool) -> bool:
@@ -537,14 +537,14 @@ def refresh_packed_weights(params) -> None:
         e.event, e.waited = ev, (set() if ev is not None else {main.cuda_stream})
 
 
-_BATCHED_REPACK = os.environ.get("JAF_NO_BATCHED_REPACK") is None
+_BATCHED_REPACK = True
 
 # Split-K partial sums of the packed weight-gradient kernel (include/jafpro_hip.h, jaf_conv2d_wgrad_packed_ws): one scratch buffer per
 # stream that launches weight gradients (launches on a stream run one after the other, and the reduction pass of a launch has read the
-# partials before the next launch overwrites them).  Opt-in (JAF_WGRAD_PARTIALS=1 / set_wgrad_partials): measured neutral on the step
+# partials before the next launch overwrites them).  Opt-in (set_wgrad_partials): measured neutral on the step
 # (profiles/experiments/round4_x4.log); what it buys is a fixed summation order -- bit-reproducible weight gradients -- on the layers
 # whose atomic traffic is large enough for the library to take the workspace.
-_WGRAD_PARTIALS = os.environ.get("JAF_WGRAD_PARTIALS", "0") == "1"
+_WGRAD_PARTIALS = False
 _WGRAD_WS: dict = {}            # stream handle -> uint8 tensor
 _WGRAD_WS_OLD: list = []        # outgrown buffers stay allocated (a launch enqueued earlier may still use them)
 _WGRAD_WS_NEED: dict = {}       # (descriptor identity, hidden) -> bytes (0: the layer stays on atomics)
@@ -670,7 +670,7 @@ def set_wgrad_stream(stream):
 
 
 _WGRAD_PENDING = [False, None]      # [enqueued on the weight-gradient stream since the last join, the stream that joined last]
-_LAZY_JOIN = os.environ.get("JAF_LAZY_JOIN", "1") != "0"
+_LAZY_JOIN = True
 
 
 def wgrad_stream():
@@ -876,8 +876,7 @@ def _slot_of(t) -> Optional["GradSlot"]:
     return getattr(t, "_jaf_gradslot", None)
 
 
-_FUSED_DZ = os.environ.get("JAF_NO_FUSED_DZ") is None
-_FUSED_DZ_MIN_G = int(os.environ.get("JAF_FUSED_DZ_MIN_G", "1"))      # experiment hook: hand dz over only in layers with >= this many groups
+_FUSED_DZ = True
 
 
 def mark_single_consumer(t: torch.Tensor) -> torch.Tensor:
@@ -889,7 +888,7 @@ def mark_single_consumer(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-_DZ_BIAS_SLOTS = 16       # JAF_DZ_BIAS_SLOTS
+_DZ_BIAS_SLOTS = 16       # = JAF_DZ_BIAS_SLOTS of include/jafpro_hip.h
 
 
 def _dz_bias_slots(prod, n: int, device):
@@ -920,8 +919,6 @@ def _fusable_producer(t: torch.Tensor, spec):
     if pm is None or pm.act not in (ACT_LRELU, ACT_RELU) or not _packed_path_now() or getattr(fn, "fwd_key", None) != _fwd_key():
         return None
     if pm.G * pm.Cout != t.shape[1] or spec[0] != pm.Cout:          # the whole output, group for group
-        return None
-    if pm.G < _FUSED_DZ_MIN_G:
         return None
     if fn.needs_input_grad[0] and fn.xp is None:                      # its weight gradient needs an fp32 dz
         return None
@@ -1260,7 +1257,7 @@ def conv2d_direct(srcs, weight, bias=None, stride=1, pad=0, act=ACT_NONE, slope=
 # ConvLSTM (whole sequence, one autograd node; BPTT in backward)
 # --------------------------------------------------------------------------------------------
 # widest [x, h] data gradient taken in one launch (see _ConvLSTMFn._backward); measured: a gain up to 48 rows (levels with 12 and 24 hidden channels), none above
-_LSTM_FUSED_DGRAD_MAX_ROWS = int(os.environ.get("JAF_LSTM_FUSED_DGRAD_MAX_ROWS", "48"))
+_LSTM_FUSED_DGRAD_MAX_ROWS = 48
 
 
 class _StickyBuffers:
@@ -1731,7 +1728,7 @@ class _BatchNormActFn(Function):
             (dy if has_res else None), None, None
 
 
-_SPLIT_BN_ONE_LAUNCH = os.environ.get("JAF_SPLIT_BN_ONE_LAUNCH", "1") != "0"
+_SPLIT_BN_ONE_LAUNCH = True          # (tests flip it: the per-chunk launches are the reference of the one-launch form)
 
 
 class _SplitBatchNormActFn(Function):
@@ -2223,7 +2220,7 @@ def backward_from(loss: torch.Tensor) -> None:
     torch.autograd.backward([loss], [one.view_as(loss)])
 
 
-_LINEAR_FUSED_BWD = os.environ.get("JAF_LINEAR_FUSED_BWD", "1") != "0"
+_LINEAR_FUSED_BWD = True          # (tests flip it)
 
 
 class _LinearFn(Function):

@@ -31,8 +31,8 @@ LRS = {"accu": 1e-5, "inpaint": 1e-5, "refine": 1e-5, "flow": 5e-5, "D": 3e-6, "
 
 # "on": True while a train step is being captured into a hipGraph; "settling": while GraphedTrainStep warms the host caches
 _CAPTURE = {"on": False, "settling": False}
-GRAPH_HOT = int(os.environ.get("JAF_GRAPH_HOT", "2"))          # a key is captured the GRAPH_HOT-th time it is seen in a row
-GRAPH_CACHE = int(os.environ.get("JAF_GRAPH_CACHE", "4"))      # graphs kept per trainer (each owns a private memory pool)
+GRAPH_HOT = 2          # a key is captured the GRAPH_HOT-th time it is seen in a row
+GRAPH_CACHE = 4      # graphs kept per trainer (each owns a private memory pool)
 
 
 class FlatParams:
@@ -145,24 +145,24 @@ def _to_dev(batch: Dict[str, np.ndarray], device) -> Dict[str, torch.Tensor]:
 _FLAG_CACHE = {}
 
 
-WGRAD_STREAM = os.environ.get("JAF_WGRAD_STREAM", "1") != "0"     # weight gradients on a second side stream
+WGRAD_STREAM = True     # weight gradients on a second side stream
 # Where the next clip's preparation (side stream 0) is issued.  "d" (default): its matrix-core part -- the frozen
 # background CRN (2.4 TFLOP at B=8) and the frozen VGG's target features -- at the start of the discriminator phase, which is
 # ~330 launches of 5-40 us in one dependent chain and leaves most of the chip idle; its renderer part (SMPL projection,
 # rasteriser, barycentric flow, flow warp) right before the VGG + GAN loss backward, which it overlaps (north star).
 # "bwd": everything right before the loss backward, where the CRN competes with the backward's own kernels.
 # Measured at B=8: 68.6 vs 70.4 ms/step.
-PREP_AT = os.environ.get("JAF_PREP_AT", "")        # "d" / "b": see Stage4Trainer._prep_at (default: "d" on one GPU, "b" with an active reducer)
+PREP_AT = ""        # "d" / "b": see Stage4Trainer._prep_at (default: "d" on one GPU, "b" with an active reducer)
 # the discriminators' real and generated passes as one batch with per-half BatchNorm statistics (train_step); 0: two passes
-D_BATCHED = os.environ.get("JAF_D_BATCHED", "1") == "1"
+D_BATCHED = True          # (tests flip it: the two-call form is the reference of the batched one)
 # the VGG + L1 loss and its gradient w.r.t. the generated frame on side stream 3, beside the discriminator phase
-VGG_SIDE = os.environ.get("JAF_VGG_SIDE", "1") != "0"
+VGG_SIDE = True
 # the two BCE terms of a batched discriminator pass (and their sum) in one launch each way; 0: two bce_loss calls on slices
-BCE_PAIR = os.environ.get("JAF_BCE_PAIR", "1") != "0"
+BCE_PAIR = True
 # optimiser steps of the modules whose backward has finished, issued under the accumulate net's last weight gradients (train_step)
-EARLY_ADAM = os.environ.get("JAF_EARLY_ADAM", "1") != "0"
+EARLY_ADAM = True
 DIST_ISSUE_ON_WGRAD = os.environ.get("JAF_DIST_ISSUE_ON_WGRAD", "1") != "0"     # multi-rank: gradient messages issued from the weight-gradient stream
-ATLAS_PACKED = os.environ.get("JAF_ATLAS_PACKED", "1") != "0"     # atlas slicing straight into enc1's packed input image
+ATLAS_PACKED = True     # atlas slicing straight into enc1's packed input image
 RUN_AHEAD = int(os.environ.get("JAF_RUN_AHEAD", "2"))     # steps the host may have in flight (0: unbounded)
 RANK_CHECK_EVERY = int(os.environ.get("JAF_RANK_CHECK_EVERY", "200"))     # multi-rank: steps between cross-rank checksum comparisons (0: never)
 ACCU_SPLIT = os.environ.get("JAF_ACCU_SPLIT", "1") != "0"     # multi-rank: the accumulate net's gradient message and optimiser step in two parameter ranges

@@ -303,3 +303,35 @@ def test_run_stage4_loop_bookkeeping_without_a_gpu(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         train.run_stage4(_Trainer(), items, draws=[((1, 0), 3)], device="cpu")
+
+
+def test_environment_switches_are_read_once_at_import():
+    """The environment switches the product still reads: JAF_RUN_AHEAD, JAF_RANK_CHECK_EVERY, JAF_DIST_ISSUE_ON_WGRAD,
+    JAF_ACCU_SPLIT (jafpro_amd/step.py), JAF_HW_QUEUES (dist.py, covered above), JAFPRO_HIP_LIB (_lib.py).  A child interpreter per
+    setting: the values are module constants."""
+    import subprocess, sys
+    code = ("import jafpro_amd.step as s, jafpro_amd._lib as l; "
+            "print(s.RUN_AHEAD, s.RANK_CHECK_EVERY, s.DIST_ISSUE_ON_WGRAD, s.ACCU_SPLIT, l.LIB_PATH.endswith('libjafpro_hip.so'))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(env):
+        e = dict(os.environ)
+        for k in ("JAF_RUN_AHEAD", "JAF_RANK_CHECK_EVERY", "JAF_DIST_ISSUE_ON_WGRAD", "JAF_ACCU_SPLIT", "JAFPRO_HIP_LIB"):
+            e.pop(k, None)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout.split()
+
+    assert run({}) == ["2", "200", "True", "True", "True"]
+    assert run({"JAF_RUN_AHEAD": "0", "JAF_RANK_CHECK_EVERY": "7", "JAF_DIST_ISSUE_ON_WGRAD": "0", "JAF_ACCU_SPLIT": "0",
+                "JAFPRO_HIP_LIB": "/nonexistent/other.so"}) == ["0", "7", "False", "False", "False"]
+    # no other JAF_* switch is read anywhere in the product (the A/B hooks of rounds 1-4 are gone)
+    import re
+    seen = set()
+    for dirpath, _, files in os.walk(os.path.join(root, "jafpro_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                seen |= set(re.findall(r"(?:environ(?:\.get)?\(|environ\[|getenv\()\s*\"(JAF\w+)\"", text))
+    assert seen == {"JAF_RUN_AHEAD", "JAF_RANK_CHECK_EVERY", "JAF_DIST_ISSUE_ON_WGRAD", "JAF_ACCU_SPLIT", "JAF_HW_QUEUES", "JAFPRO_HIP_LIB"}, seen
