@@ -323,7 +323,8 @@ def test_environment_switches_are_read_once_at_import():
         assert r.returncode == 0, r.stderr[-2000:]
         return r.stdout.split()
 
-    assert run({}) == ["2", "200", "True", "True", "True"]
+    assert run({}) == ["1", "200", "True", "True", "True"]      # (default JAF_RUN_AHEAD=1.5: one and a half steps in flight, step.RUN_AHEAD_HALF)
+    assert run({"JAF_RUN_AHEAD": "2"})[0] == "2"
     assert run({"JAF_RUN_AHEAD": "0", "JAF_RANK_CHECK_EVERY": "7", "JAF_DIST_ISSUE_ON_WGRAD": "0", "JAF_ACCU_SPLIT": "0",
                 "JAFPRO_HIP_LIB": "/nonexistent/other.so"}) == ["0", "7", "False", "False", "False"]
     # no other JAF_* switch is read anywhere in the product (the A/B hooks of rounds 1-4 are gone)
