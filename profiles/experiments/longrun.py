@@ -14,6 +14,7 @@ for i in range(n + 1):
     if i % 100 == 0:
         torch.cuda.synchronize()
         st = torch.cuda.memory_stats()
-        print("step %4d allocated %.1f MB reserved %.1f MB peak_alloc %.1f MB segments %d inactive_split %.1f MB" % (
+        print("step %4d allocated %.1f MB reserved %.1f MB peak_alloc %.1f MB segments %d inactive_split %.1f MB hipMalloc calls so far %d" % (
             i, torch.cuda.memory_allocated()/1e6, torch.cuda.memory_reserved()/1e6,
-            torch.cuda.max_memory_allocated()/1e6, st["segment.all.current"], st["inactive_split_bytes.all.current"]/1e6), flush=True)
+            torch.cuda.max_memory_allocated()/1e6, st["segment.all.current"], st["inactive_split_bytes.all.current"]/1e6,
+            st["num_device_alloc"]), flush=True)
