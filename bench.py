@@ -205,12 +205,21 @@ def main():
     if world > 1 or os.environ.get("JAF_BENCH_ONE_RANK_GROUP") == "1":
         from jafpro_amd.dist import limit_hw_queues
         limit_hw_queues()           # RCCL's own hardware queue on top of the step's five oversubscribes the GPU's (dist.limit_hw_queues)
+    # ONE JSON line on stdout, nothing else: RCCL prints a version banner to stdout when its first communicator comes up, and any
+    # library may chatter.  File descriptor 1 is pointed at stderr for the whole run; the result line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     if args.cpu_baseline_only:
         # child process of the default run (below): the CPU oracle alone, one JSON line
         from jafpro_amd import synth as _synth
         _, _fidx = _synth.body_mesh()
         _M, _mods = build_models(_fidx, args.size)
-        print(json.dumps(cpu_baseline(_mods, _fidx, args.size)))
+        emit(cpu_baseline(_mods, _fidx, args.size))
         return
     # CPU baseline first (rank 0, N=1), in a CHILD process started before this one touches the GPU: the oracle's 16 OpenMP
     # threads and its ~40 GB of host memory are gone when the timed loop starts (run in-process they left 80-95 ms
@@ -495,7 +504,7 @@ def main():
     if cpu_result is not None:
         result["cpu_baseline"] = cpu_result
     if rank == 0:
-        print(json.dumps(result))
+        emit(result)
     if world > 1:
         dist.barrier()              # ranks > 0 wait here while rank 0 takes its roofline step
         dist.destroy_process_group()

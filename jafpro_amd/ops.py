@@ -701,14 +701,29 @@ def watch_wgrads(weights, callback=None) -> None:
     backward pass visits them in.  An event recorded on the weight-gradient stream inside the callback therefore marks 'every
     gradient of this parameter range is complete'.  watch_wgrads(None) clears a watch that has not fired."""
     _WGRAD_WATCH[0] = None if not weights else ({id(w) for w in weights}, callback)
+    _WGRAD_FIRED.clear()
+    if weights:
+        _WGRAD_FIRED_ARMED[0] = {id(w) for w in weights}
+    else:
+        _WGRAD_FIRED_ARMED[0] = None
+
+
+_WGRAD_FIRED: set = set()             # ids of the watched weights once the callback has run (until the next watch_wgrads call)
+_WGRAD_FIRED_ARMED = [None]
 
 
 def _wgrad_enqueued(weight) -> None:
+    if id(weight) in _WGRAD_FIRED:
+        # the callback told its listener "every gradient of this parameter range is complete" (the multi-rank trainer starts the
+        # range's all-reduce there): a later weight-gradient launch into the range would race with the message (ADVICE r4)
+        raise RuntimeError("a weight gradient was launched after its parameter range had been declared complete")
     w = _WGRAD_WATCH[0]
     if w is not None and id(weight) in w[0]:
         w[0].discard(id(weight))
         if not w[0]:
             _WGRAD_WATCH[0] = None
+            if _WGRAD_FIRED_ARMED[0]:
+                _WGRAD_FIRED.update(_WGRAD_FIRED_ARMED[0])
             w[1]()
 
 

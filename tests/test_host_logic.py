@@ -140,6 +140,13 @@ def test_wgrad_watch_fires_once_after_the_last_weight():
     assert fired == []
     ops._wgrad_enqueued(a)
     assert fired == ["ab"]
+    # once the range has been declared complete, another weight-gradient launch into it would race with the message that is
+    # already travelling: it raises -- until the watch is cleared at the end of the backward pass
+    import pytest
+    with pytest.raises(RuntimeError, match="declared complete"):
+        ops._wgrad_enqueued(a)
+    ops._wgrad_enqueued(c)                       # (an unwatched weight is nobody's business)
+    ops.watch_wgrads(None)
     ops._wgrad_enqueued(a); ops._wgrad_enqueued(b)
     assert fired == ["ab"]
     ops.watch_wgrads([a], lambda: fired.append("a"))
