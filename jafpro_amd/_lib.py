@@ -99,6 +99,10 @@ def lib():
     """Loads the HIP library (once).  Raises if it has not been built: there is no fallback."""
     global _LIB
     if _LIB is None:
+        # PyTorch first: it ships its own HIP runtime, and the process must hold exactly one.  Loaded the other way round (this
+        # library before the first `import torch`), the runtime /opt/rocm resolves for us is already in place when torch brings its
+        # copy, and the first launch fails with hipErrorNoDevice (seen with `python __graft_entry__.py --smoke`, which builds first).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "libjafpro_hip.so is missing (%s). Build it with `python -m jafpro_amd.build`; "
