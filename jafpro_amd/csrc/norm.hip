@@ -138,7 +138,7 @@ extern "C" int jaf_layernorm_lrelu_fwd_dt(jaf_stream_t s, const void* x, int x_b
     const bool v4 = (HW % 4 == 0) && al16(x, y);
 #define JAF_LNF(V_, T_) hipLaunchKernelGGL((ln_lrelu_fwd_kernel<V_, T_>), dim3(jaf_cdiv(HW / V_, 256), C, N), dim3(256), 0, (hipStream_t)s, \
                                            (const T_*)x, stats, gamma, beta, y, C, HW, slope)
-    if (x_bf16) { if (v4 && HW % 8 == 0) JAF_LNF(8, __bf16); else if (v4) JAF_LNF(4, __bf16); else JAF_LNF(1, __bf16); }
+    if (x_bf16) { if (v4) JAF_LNF(4, __bf16); else JAF_LNF(1, __bf16); }
     else { if (v4) JAF_LNF(4, float); else JAF_LNF(1, float); }
 #undef JAF_LNF
     return jaf_launch_status();
@@ -225,8 +225,9 @@ extern "C" int jaf_layernorm_lrelu_fwd_packed_dt(jaf_stream_t s, const void* x, 
 #define JAF_LNP(V_, T_) hipLaunchKernelGGL((ln_lrelu_fwd_packed_kernel<V_, T_>), dim3(jaf_cdiv(HW / V_, 256), jaf_cdiv(C, 8), N), block, 0, \
                                            (hipStream_t)s, (const T_*)x, stats, gamma, beta, y, (unsigned char*)dst, dst_ng8_tot,          \
                                            dst_coff / 8, C, HW, slope, split)
-    // (bf16 x: 8 pixels per lane = the same 16-byte loads as 4 fp32 ones)
-    if (x_bf16) { if (v4 && HW % 8 == 0) JAF_LNP(8, __bf16); else if (v4) JAF_LNP(4, __bf16); else JAF_LNP(1, __bf16); }
+    // (bf16 x with 8 pixels per lane -- 16-byte loads -- measured SLOWER than 4: 0.97 vs 0.83 ms per step, round 5: the lane then
+    // holds 64 values and fewer lanes are in flight)
+    if (x_bf16) { if (v4) JAF_LNP(4, __bf16); else JAF_LNP(1, __bf16); }
     else { if (v4) JAF_LNP(4, float); else JAF_LNP(1, float); }
 #undef JAF_LNP
     return jaf_launch_status();
@@ -493,10 +494,9 @@ extern "C" int jaf_layernorm_lrelu_bwd_packed_dt(jaf_stream_t s_, const void* dy
 #define LN_APP(V_, D_, X_) hipLaunchKernelGGL((ln_bwd_apply_packed_kernel<V_, D_, X_>), dim3(jaf_cdiv(HW / V_, 256), jaf_cdiv(C, 8), N), dim3(256), \
                                               0, s, (const D_*)dy, (const X_*)x, stats, gamma, beta, workspace, (unsigned char*)packed_dx, C, HW,  \
                                               slope, eps, split)
-    const bool v8 = v4 && dy_bf16 && x_bf16 && HW % 8 == 0;          // both tensors in bf16: 16-byte loads take 8 pixels
-    if (v8) LN_RED(8, __bf16, __bf16); else if (v4) LN_DISPATCH(LN_RED, 4); else LN_DISPATCH(LN_RED, 1);
+    if (v4) LN_DISPATCH(LN_RED, 4); else LN_DISPATCH(LN_RED, 1);
     hipLaunchKernelGGL(ln_bwd_fold_kernel, dim3(jaf_cdiv(N, 64)), dim3(64), 0, s, workspace, N);
-    if (v8) LN_APP(8, __bf16, __bf16); else if (v4) LN_DISPATCH(LN_APP, 4); else LN_DISPATCH(LN_APP, 1);
+    if (v4) LN_DISPATCH(LN_APP, 4); else LN_DISPATCH(LN_APP, 1);
 #undef LN_RED
 #undef LN_APP
     if (conv_dbias)
