@@ -67,6 +67,8 @@ __device__ __forceinline__ unsigned char* cd_dst_ptr_s(unsigned char* base, long
 // v - bf16(v): what the lo plane of a split-bf16 image holds
 __device__ __forceinline__ float cd_resid(float v) { return v - (float)(__bf16)v; }
 
+#define cd_L2E 1.4426950408889634f
+
 __device__ __forceinline__ unsigned int cd_pack2(float a, float b) {
     f32x2 v = {a, b};
     bf16x2 r = __builtin_convertvector(v, bf16x2);
@@ -419,15 +421,20 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                         cp = *(const fvec*)(a.c_prev + hc + opix[0]);
                     }
                 }
+                // The launch is vector-instruction-issue bound, and the gate math is most of the epilogue: the biases are
+                // folded into the exponent's fma (sigmoid(z + b) = 1 / (1 + 2^(-z L - b L)), L = log2 e) and tanh(x) is taken as
+                // 1 - 2 / (1 + 2^(2 L x)) -- 5 instructions instead of 8, saturating cleanly through 2^(+-inf) -- : 28 instead of 40
+                // vector instructions per hidden pixel, |error| ~1e-7 either way.
+                const float nbi = -cd_L2E * bi, nbf = -cd_L2E * bf, nbo = -cd_L2E * bo, pbg = 2.f * cd_L2E * bg;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    vi[nt] = jaf_sigmoid(acc[mt][nt][0] + bi);
-                    vf[nt] = jaf_sigmoid(acc[mt][nt][1] + bf);
-                    vo[nt] = jaf_sigmoid(acc[mt][nt][2] + bo);
-                    vg[nt] = jaf_tanh(acc[mt][nt][3] + bg);
+                    vi[nt] = jaf_rcp(1.f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][0], -cd_L2E, nbi)));
+                    vf[nt] = jaf_rcp(1.f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][1], -cd_L2E, nbf)));
+                    vo[nt] = jaf_rcp(1.f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][2], -cd_L2E, nbo)));
+                    vg[nt] = 1.f - 2.f * jaf_rcp(1.f + __builtin_amdgcn_exp2f(__builtin_fmaf(acc[mt][nt][3], 2.f * cd_L2E, pbg)));
                     const float c_old = a.c_prev ? cp[nt] : 0.f;
                     vc[nt] = vf[nt] * c_old + vi[nt] * vg[nt];
-                    vh[nt] = vo[nt] * jaf_tanh(vc[nt]);
+                    vh[nt] = vo[nt] * (1.f - 2.f * jaf_rcp(1.f + __builtin_amdgcn_exp2f(vc[nt] * (2.f * cd_L2E))));
                     hs4[nt & 3] = vh[nt];
                 }
                 if (live) {
