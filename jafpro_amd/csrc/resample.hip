@@ -385,6 +385,24 @@ __global__ void resize_bwd_lds_kernel(const DT* __restrict__ dy, float* __restri
     }
     __syncthreads();
     if (gx >= a.W) return;
+    // the lane's column: its five x taps and their weights are the same for every row it visits (hoisted out of the row loop in
+    // round 5: the kernel is vector-instruction bound, ~1200 per wave, and these were a seventh of them)
+    const bool fast = a.align && a.sx >= 0.45f && a.sy >= 0.45f;
+    float wx[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    int cx[5] = {0, 0, 0, 0, 0};
+    {
+        const int ix = gx - a.x0;
+        if (fast && ix >= 0 && ix < a.cw) {
+            int xl = (int)floorf((float)(ix - 1) * a.inv_sx) + 1;
+            if (xl < rx0) xl = rx0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int o = xl + j;
+                wx[j] = o <= rx1 ? fmaxf(0.f, 1.f - fabsf(a.sx * (float)o - (float)ix)) : 0.f;
+                cx[j] = (o <= rx1 ? o : rx1) - rx0;
+            }
+        }
+    }
     for (int rr = 0; rr < a.rows; ++rr) {
     const int gy = gy0 + threadIdx.y + (int)blockDim.y * rr;
     if (gy >= a.H) return;
@@ -392,21 +410,12 @@ __global__ void resize_bwd_lds_kernel(const DT* __restrict__ dy, float* __restri
     float acc = 0.f;
     if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
         int ylo, yhi, xlo, xhi;
-        if (a.align && a.sx >= 0.45f && a.sy >= 0.45f) {
+        if (fast) {
             // up-sampling by <= 2.2x with align_corners (every decoder of the path): the tent max(0, 1 - |s*o - i|)
             // is non-zero on at most 5 consecutive outputs per axis, o > (i-1)/s: 25 taps, no candidate margins.
             // Taps past the support carry weight 0; their index is clamped into the staged region.
-            int xl = (int)floorf((float)(ix - 1) * a.inv_sx) + 1, yl = (int)floorf((float)(iy - 1) * a.inv_sy) + 1;
-            if (xl < rx0) xl = rx0;
+            int yl = (int)floorf((float)(iy - 1) * a.inv_sy) + 1;
             if (yl < ry0) yl = ry0;
-            float wx[5];
-            int cx[5];
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                const int o = xl + j;
-                wx[j] = o <= rx1 ? fmaxf(0.f, 1.f - fabsf(a.sx * (float)o - (float)ix)) : 0.f;
-                cx[j] = (o <= rx1 ? o : rx1) - rx0;
-            }
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const int o = yl + r;
