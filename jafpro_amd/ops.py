@@ -135,6 +135,13 @@ def bf16_storage_active() -> bool:
     return _BF16_STORAGE and _PRECISION == PREC_BF16 and _PACKED_IMAGES
 
 
+def bf16_handles_active() -> bool:
+    """Storage-less autograd handles are made bf16 tensors -- so that the gradients autograd carries for them are produced and
+    consumed in bf16 -- under bf16 storage, and in the "mixed" mode, whose backward pass is a bf16 pass (a handle holds no data:
+    the parity-grade forward is untouched)."""
+    return bf16_storage_active() or (_BF16_STORAGE and _MIXED and _PACKED_IMAGES)
+
+
 class _arith:
     """`with _arith(ctx.mode):` -- a backward pass runs in the arithmetic its forward ran in, whatever
     set_precision says by then (its saved packed images / bf16 gates belong to that mode)."""
@@ -786,7 +793,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
             # Under bf16 storage the handle is a bf16 tensor: autograd then expects -- and the layers behind it produce -- its
             # gradient in bf16 (a data gradient that is not handed over as a packed dz, a GradSlot buffer).
             out = torch.empty_strided((N, out_ctot, OH, OW), (0, 0, 0, 0), device=srcs[0].device,
-                                      dtype=torch.bfloat16 if (bf16_storage_active() and mode == PACK_FWD) else torch.float32)
+                                      dtype=torch.bfloat16 if (bf16_handles_active() and mode == PACK_FWD) else torch.float32)
         else:
             out = torch.empty((N, out_ctot, OH, OW), device=srcs[0].device, dtype=out_dtype or torch.float32)
     out_bf16 = out.dtype == torch.bfloat16 and not skip_f32
@@ -1641,7 +1648,7 @@ class _LayerNormLReLUFn(Function):
             # (the handle takes the bf16 type under bf16 storage: the consumer's data gradient then comes back in bf16)
             y = (torch.empty(tuple(x.shape), device=x.device, dtype=torch.float32) if keep_f32 else
                  torch.empty_strided(tuple(x.shape), (0, 0, 0, 0), device=x.device,
-                                     dtype=torch.bfloat16 if bf16_storage_active() else torch.float32))
+                                     dtype=torch.bfloat16 if bf16_handles_active() else torch.float32))
             check(L.jaf_layernorm_lrelu_fwd_packed_dt(_s(), _p(x), xb, _p(stats), _p(gamma), _p(beta), _p(y) if keep_f32 else None,
                                                       _p(dst.image.buf), dst.image.ng8, dst.coff, N, C, H * W, slope, _PRECISION),
                   "jaf_layernorm_lrelu_fwd_packed_dt")
@@ -1880,7 +1887,7 @@ class _LazyResizeFn(Function):
         ctx.cfg = (N, C, H, W, OH, OW, align)
         # (bf16 storage: a bf16 handle, so that the consumer's data gradient -- OH*OW/(H*W) times the size of x -- arrives in bf16)
         return torch.empty_strided((N, C, OH, OW), (0, 0, 0, 0), device=x.device,
-                                   dtype=torch.bfloat16 if bf16_storage_active() else torch.float32)
+                                   dtype=torch.bfloat16 if bf16_handles_active() else torch.float32)
 
     @staticmethod
     def backward(ctx, dy):
