@@ -459,9 +459,10 @@ def _packed(weight: torch.Tensor, w_rows_tot: int, d: ConvDesc, pl: ConvPlan, mo
     hit = _PACK_CACHE.get(ck)
     if hit is not None and hit.ref() is weight:
         if hit.event is not None:        # image made or refreshed on another stream: order this stream behind it
-            cur = torch.cuda.current_stream()
-            sid = cur.cuda_stream
+            # (the raw handle first: building a torch Stream object costs ~12 us, and this runs for every convolution launch)
+            sid = _RAW_STREAM(_RAW_DEVICE()) if _RAW_STREAM is not None else torch.cuda.current_stream().cuda_stream
             if sid not in hit.waited:
+                cur = torch.cuda.current_stream()
                 cur.wait_event(hit.event)
                 hit.buf.record_stream(cur)          # ... and keep the block from being reused under this stream's reads
                 hit.waited.add(sid)
