@@ -9,7 +9,7 @@ i=0
 while read -r line; do
   [ -z "$line" ] && continue
   i=$((i+1))
-  timeout 280 rocprofv3 --pmc $line --output-format csv -d $R/gpurun_out/pmc_mix_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-config2 --parity-mode-steps 0 --serial-streams $JAF_PROFILE_ARGS > $R/gpurun_out/pmc_mix_$i.log 2>&1; echo "pass $i rc=$?"
+  timeout 280 rocprofv3 --pmc $line --output-format csv -d $R/gpurun_out/pmc_mix_$i -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-config2 --parity-mode-steps 0 --no-frame-parity --serial-streams $JAF_PROFILE_ARGS > $R/gpurun_out/pmc_mix_$i.log 2>&1; echo "pass $i rc=$?"
 done <<'LIST'
 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_INSTS_VMEM_WR
