@@ -96,13 +96,14 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
         typedef __bf16 phvec __attribute__((ext_vector_type(NT == 1 ? 2 : NT)));
         const bool pv = a.vec && (NT > 1);
         const bool hb = a.out_bf16 != 0;
+        const long prow = ((long)n * d.out_ctot + d.out_coff + g * d.Cout + mb * MR + q * 4) * (long)OHW;      // the lane's row at mt = 0, j = 0
 #define CD_EPILOGUE_PLAIN(ACT_)                                                                       \
         _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                           \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
                 const int co = mb * MR + mt * 16 + q * 4 + j;                                         \
                 if (co < d.Cout) {                                                                    \
                     const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
-                    const long ooff = ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW;    \
+                    const long ooff = prow + (long)((mt * 16 + j) * OHW);                             \
                     float* op = a.out + ooff;                                                         \
                     __bf16* hp = (__bf16*)a.out + ooff;      /* out_bf16: the same tensor in bf16 */   \
                     if (pv) {                                                                         \
@@ -148,6 +149,23 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             // dz mode with a second fp32 output (the ConvLSTM's d[x_t, h_{t-1}] launch): only the rows below `split` (dx) are the
             // producer's dz; the rows from `split` on (dh) leave through out2 as always
             const int dC = (DZ && a.out2) ? a.split : d.Cout;
+            // Address arithmetic, strength-reduced by hand (round 5; these launches are vector-instruction-issue bound and every
+            // store used to recompute ((ng * ng8 + (dc >> 3)) * OHW + pix) * 16 with 64-bit multiplies, ~12 instructions of which 4
+            // quarter-rate): the lane's FIRST destination channel is dcl (row tile 0); row tile mt is 16 channels = two planes
+            // further, the residual plane of a split image one plane further, pixel p 16 p bytes further.
+            const long plane16 = (long)OHW * 16;
+            const int dcl = a.dst_coff + mb * MR + q * 4;
+            unsigned char* const dlane = a.dst + ((ngd * a.dst_ng8 + (dcl >> 3)) * (SPD ? 2 : 1)) * plane16 + (dcl & 7) * 2;
+            const long dmt = 2 * (SPD ? 2 : 1) * plane16;
+            // the sign image of the dz mode, the same way (a split image under bf16 arithmetic in the mixed mode)
+            const bool msplit = SPD || (DZ && a.dz_mask_split);
+            const int mcl = a.dz_mask_coff + mb * MR + q * 4;
+            const unsigned char* const mlane = DZ ? a.dz_mask + (((((long)n) * d.G + g) * a.dz_mask_ng8 + (mcl >> 3)) * (msplit ? 2 : 1)) * plane16 + (mcl & 7) * 2
+                                                  : nullptr;
+            const long mmt = 2 * (msplit ? 2 : 1) * plane16;
+            // element offset of the lane's first row (row tile 0, j = 0) of the first consumer's gradient in `out` (dz mode + acc_out)
+            const long prow0 = (a.out2 ? (((long)n * d.G + g) * a.split + mb * MR + q * 4)
+                                       : ((long)n * d.out_ctot + d.out_coff + g * d.Cout + mb * MR + q * 4)) * (long)OHW;
             float wsum[MT][4];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -169,14 +187,12 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 // load above a store to a pointer that may alias it)
                 unsigned int mk[NT][2];
                 if (DZ) {
-                    const long ngm = ((long)n) * d.G + g;
+                    const unsigned char* const mrow = mlane + mt * mmt;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         mk[nt][0] = mk[nt][1] = 0u;
                         if (opix[nt] >= 0) {
-                            const unsigned int* xp2 = (!SPD && a.dz_mask_split)
-                                ? (const unsigned int*)cd_dst_ptr_s<true>((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8, a.dz_mask_coff + co0, OHW, opix[nt], 0)
-                                : (const unsigned int*)cd_dst_ptr_s<SPD>((unsigned char*)a.dz_mask, ngm, a.dz_mask_ng8, a.dz_mask_coff + co0, OHW, opix[nt], 0);
+                            const unsigned int* xp2 = (const unsigned int*)(mrow + (unsigned long)(unsigned)opix[nt] * 16u);
                             mk[nt][0] = xp2[0];
                             mk[nt][1] = xp2[1];
                         }
@@ -191,8 +207,7 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) part[j][nt] = 0.f;
                         if (co0 + j < dC) {
-                            const long poff = a.out2 ? (((long)n * d.G + g) * a.split + co0 + j) * OHW
-                                                     : ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co0 + j) * OHW;
+                            const long poff = prow0 + (long)((mt * 16 + j) * OHW);      // (lane's row at mt = 0, j = 0) + uniform rows
                             const float* pp = a.out + poff;
                             const __bf16* ph = (const __bf16*)a.out + poff;
                             if (vec) {
@@ -256,11 +271,12 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                     wl[nt] = cd_pack2(v[0], v[1]);
                     wh[nt] = cd_pack2(v[2], v[3]);
                     if (pair_ok) continue;
+                    unsigned char* const dpx = dlane + mt * dmt + (SPD ? sp * plane16 : 0) + (unsigned long)(unsigned)opix[nt] * 16u;
                     if (co0 + 4 <= cpad || a.dst_pad_tail) {
                         const u32x2 w = {wl[nt], wh[nt]};
-                        *(u32x2*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt], sp) = w;
+                        *(u32x2*)dpx = w;
                     } else {           // a 4-group that straddles the end of this source: channel by channel
-                        unsigned short* hp = (unsigned short*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, a.dst_coff + co0, OHW, opix[nt], sp);
+                        unsigned short* hp = (unsigned short*)dpx;
                         const unsigned int ww[2] = {wl[nt], wh[nt]};
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
@@ -276,14 +292,16 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                                  "v_permlane16_swap_b32 %4, %6\n\tv_permlane16_swap_b32 %5, %7\n\ts_nop 1"
                                  : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(e0), "+v"(e1));
                     const int pA = (q & 1) ? opix[2 % NT] : opix[0], pB = (q & 1) ? opix[3 % NT] : opix[1 % NT];
-                    const int cbase = a.dst_coff + (co0 & ~4);
+                    // the pair's item starts at channel co0 & ~4: for the odd row group that is 4 channels = 8 bytes below its own half
+                    // (dst_coff % 8 == 0 here, so neither the plane nor the item changes)
+                    unsigned char* const dpair = dlane + mt * dmt + (SPD ? sp * plane16 : 0) - ((q & 1) ? 8 : 0);
                     if (pA >= 0) {
                         const u32x4 w = {a0, a1, b0, b1};
-                        *(u32x4*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, cbase, OHW, pA, sp) = w;
+                        *(u32x4*)(dpair + (unsigned long)(unsigned)pA * 16u) = w;
                     }
                     if (pB >= 0) {
                         const u32x4 w = {c0, c1, e0, e1};
-                        *(u32x4*)cd_dst_ptr_s<SPD>(a.dst, ngd, a.dst_ng8, cbase, OHW, pB, sp) = w;
+                        *(u32x4*)(dpair + (unsigned long)(unsigned)pB * 16u) = w;
                     }
                 }
                 if (DZ && a.dz_dbias && (!SPD || sp == 0)) {       // the 16 lanes of a q-group hold the same 4 channels: fold them
@@ -317,6 +335,10 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
             }
         }
         if (a.skip_f32 || (DZ && !a.out2)) return;
+        // element offsets of the lane's row (row tile 0, j = 0) in `out` / `out2`: every other row is a uniform number of planes further
+        const long orow1 = (a.out2 ? (((long)n * d.G + g) * a.split + mb * MR + q * 4)
+                                   : ((long)n * d.out_ctot + d.out_coff + g * d.Cout + mb * MR + q * 4)) * (long)OHW;
+        const long orow2 = (((long)n * d.G + g) * (d.Cout - a.split) + (mb * MR + q * 4 - a.split)) * (long)OHW;
 // one output row (channel `co`) of the lane's NT pixels: OP_ / HP_ = the row's base as fp32 / bf16 elements, HB_: bf16 storage,
 // ACCP_: add what is there (GradSlot).  A macro, not a pointer select: selecting between the kernel's two output pointers at run
 // time made the compiler park them in scratch memory.
@@ -358,11 +380,10 @@ __device__ __forceinline__ void cd_epilogue(const ConvDArgs& a, const f32x4 (&ac
                 if (co < d.Cout && !(DZ && co < a.split)) {      /* (dz rows went to `dst`) */  \
                     const float b = a.bias ? a.bias[g * d.Cout + co] : 0.f;                           \
                     if (a.out2 && co >= a.split) {                                                    \
-                        const long ooff = (((long)n * d.G + g) * (d.Cout - a.split) + (co - a.split)) * OHW; \
+                        const long ooff = orow2 + (long)((mt * 16 + j) * OHW);                        \
                         CD_STORE_ROW(ACT_, ST_, a.out2 + ooff, (__bf16*)a.out2 + ooff, a.out2_bf16, false)   \
                     } else {                                                                          \
-                        const long ooff = a.out2 ? (((long)n * d.G + g) * a.split + co) * OHW         \
-                                                 : ((long)n * d.out_ctot + d.out_coff + g * d.Cout + co) * OHW; \
+                        const long ooff = orow1 + (long)((mt * 16 + j) * OHW);                        \
                         CD_STORE_ROW(ACT_, ST_, a.out + ooff, (__bf16*)a.out + ooff, a.out_bf16, a.acc_out)  \
                     }                                                                                 \
                 }                                                                                     \
