@@ -998,6 +998,9 @@ extern "C" int jaf_convlstm_gates_bwd_packed_dt(jaf_stream_t s, int32_t N, int32
 // Minimum resident workgroups per CU the register allocator must leave room for (256 threads = one wave per SIMD each, so
 // k workgroups = k waves per SIMD = at most 512 / k registers per lane).  Without it the allocator spreads: <4,4> plain took
 // 148 registers (3 waves per SIMD) where 110 do.
+#ifndef CD_WS_CAND
+#define CD_WS_CAND 3      // k-steps per weight sub-load the planner may choose (jaf_conv_plan.pf)
+#endif
 #ifndef CD_MIN_WG
 #define CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN) (((NT) == 4 && (MT) >= 3 && !((LSTM) && (MT) == 4)) ? 4 : 1)
 #endif
@@ -1146,52 +1149,60 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
     const long wchunk_bytes = (long)P.nsteps * MT * 1024;
     const unsigned char* wbase = a.wpk + ((long)(g * P.mblocks + mb) * P.nchunks) * wchunk_bytes;
 
+    // plan.pf > 0: the chunk's weights pass through LDS `pf` k-steps at a time (the patch stays): a 4-group chunk (9 exact k-steps
+    // of a 3 x 3 layer, no padded half step) then needs the LDS of a 2-group one and keeps 4 workgroups per CU
+    const int wsub = P.pf > 0 ? P.pf : P.nsteps;
     for (int chunk = 0; chunk < P.nchunks; ++chunk) {
         const bool last = (chunk == P.nchunks - 1);
         const int ngc = last ? P.ng_last : NG;
         const int nst = last ? P.nsteps_last : P.nsteps;
-        __syncthreads();   // previous chunk consumed (first pass: slot table visible)
+        const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
+        for (int s0 = 0; s0 < nst; s0 += wsub) {
+            const int s1 = s0 + wsub < nst ? s0 + wsub : nst;
+            __syncthreads();   // previous (sub-)chunk consumed (first pass: slot table visible)
 
-        // ---- weights and patch: DMA straight into LDS.  Overlap with the matrix cores comes from the
-        // 2-6 workgroups resident per CU (LDS/VGPR footprint is small); an intra-workgroup second
-        // buffer measured slower than the extra resident workgroup it costs. ----
-        {
-            const unsigned char* wsrc = wbase + (long)chunk * wchunk_bytes;
-            for (int e = wave; e < nst * MT; e += 4)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + e * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
-            const unsigned char* cbase = xbase + (long)(chunk * NG) * plane_bytes;
-            for (int grp = 0; grp < ngc; ++grp) {
-                const __amdgpu_buffer_rsrc_t rs =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)grp * plane_bytes), 0, plane_bytes, 0x00020000);
+            // ---- weights and patch: DMA straight into LDS.  Overlap with the matrix cores comes from the
+            // 2-6 workgroups resident per CU (LDS/VGPR footprint is small); an intra-workgroup second
+            // buffer measured slower than the extra resident workgroup it costs. ----
+            {
+                const unsigned char* wsrc = wbase + (long)chunk * wchunk_bytes + (long)s0 * MT * 1024;
+                for (int e = wave; e < (s1 - s0) * MT; e += 4)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + e * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
+                if (s0 == 0) {
+                    const unsigned char* cbase = xbase + (long)(chunk * NG) * plane_bytes;
+                    for (int grp = 0; grp < ngc; ++grp) {
+                        const __amdgpu_buffer_rsrc_t rs =
+                            __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)grp * plane_bytes), 0, plane_bytes, 0x00020000);
 #pragma unroll
-                for (int j = 0; j < CD_RPW; ++j) {
-                    const int round = wave + 4 * j;
-                    if (round < nrounds)
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(s_patch + grp * plane + round * 1024),
-                                                                 16, dvoff[j], 0, 0, 0);
+                        for (int j = 0; j < CD_RPW; ++j) {
+                            const int round = wave + 4 * j;
+                            if (round < nrounds)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(s_patch + grp * plane + round * 1024),
+                                                                         16, dvoff[j], 0, 0, 0);
+                        }
+                    }
                 }
             }
-        }
-        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
-        __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
+            __syncthreads();
 
-        // ---- MFMA over the chunk's steps ----
-        const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
-        u32x4 tnext = *(const u32x4*)tab;                 // slot-table entry fetched one step ahead
-        for (int st = 0; st < nst; ++st) {
-            const u32x4 t4 = tnext;
-            tnext = *(const u32x4*)(tab + 16 * (st + 1 < nst ? st + 1 : st));
-            const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
-            bf16x8 bh[NT];
+            // ---- MFMA over the (sub-)chunk's steps ----
+            u32x4 tnext = *(const u32x4*)(tab + 16 * s0);     // slot-table entry fetched one step ahead
+            for (int st = s0; st < s1; ++st) {
+                const u32x4 t4 = tnext;
+                tnext = *(const u32x4*)(tab + 16 * (st + 1 < s1 ? st + 1 : st));
+                const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+                bf16x8 bh[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
+                for (int nt = 0; nt < NT; ++nt) bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const bf16x8 ah = *(const bf16x8*)(s_w + (st * MT + mt) * 1024 + lane * 16);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 ah = *(const bf16x8*)(s_w + ((st - s0) * MT + mt) * 1024 + lane * 16);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -1243,7 +1254,7 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     const int sb = split ? 2 : 1;
 
     double bestCost = 1e300;
-    int bTW = 0, bNT = 0, bNG = 0, bMT = 0;
+    int bTW = 0, bNT = 0, bNG = 0, bMT = 0, bWS = 0;
     const int ngcap = 4;          // channel groups of 8 per chunk (slot table and DMA rounds are sized for <= 4)
     const int cand_tw[4] = {16, 32, 64, d->OW};
     // experiment hooks (scratch/mb_part.py): restrict the search to one NT / one tile width
@@ -1281,7 +1292,19 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 const int ng_last = groups - (nchunks - 1) * NG;
                 const int nsteps = jaf_cdiv(taps * NG, 4);
                 const int nsteps_last = jaf_cdiv(taps * ng_last, 4);
-                const long lds = (long)sb * NG * plane + (long)sb * nsteps * MT * 1024 + 2L * 16 * nsteps * 4 + 64;
+#ifdef CD_FORCE_NG
+                if (!split && d->G == 1 && M >= 64 && groups >= 4 && NG != CD_FORCE_NG) continue;
+#endif
+                // WS: k-steps of weights resident at a time (0: the whole chunk).  Sub-loads keep the LDS of a chunk with many channel
+                // groups (no padded half k-step: 3 x 3 taps x 4 groups = 9 exact steps) at that of a small one.
+                for (int wi = 0; wi < 2; ++wi) {
+                const int WS = wi == 0 ? 0 : CD_WS_CAND;
+                if (WS && (split || WS >= nsteps)) continue;
+#ifdef CD_FORCE_WSUB
+                if (!split && d->G == 1 && M >= 64 && groups >= 4 && WS != ((CD_FORCE_WSUB) < nsteps ? (CD_FORCE_WSUB) : 0)) continue;
+#endif
+                const int wl = WS ? WS : nsteps;
+                const long lds = (long)sb * NG * plane + (long)sb * wl * MT * 1024 + 2L * 16 * nsteps * 4 + 64;
                 if (lds > 150 * 1024) continue;
                 const double total_steps = (double)(nchunks - 1) * nsteps + nsteps_last;
                 const double mfma = (double)MT * NT * 16.0 * (split ? 3.0 : 1.0);
@@ -1306,9 +1329,14 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 const double per_cu = nblocks / 256.0;
                 const int conc = per_cu >= bl ? bl : (per_cu <= 1.0 ? 1 : (int)per_cu);
                 const double ovl = 1.0 / (double)(conc < 1 ? 1 : conc);   // resident workgroups hide each other's staging
-                const double per_block = total_steps * t_step * occ_pen + nchunks * (stage * ovl + 250.0) + fixed;
+                const double subs = WS ? (double)(nchunks - 1) * (jaf_cdiv(nsteps, WS) - 1) + (jaf_cdiv(nsteps_last, WS) - 1) : 0.0;
+                // (calibrated on profiles/experiments/round5_weight_subloads.txt: a sub-load costs its own latency where nothing else is
+                // resident, a quarter of it at four workgroups per CU)
+                const double wstage = 500.0 + (double)wl * MT * 1024.0 / 48.0;
+                const double per_block = total_steps * t_step * occ_pen + nchunks * (stage * ovl + 250.0) + subs * (wstage * ovl + 50.0) + fixed;
                 const double cost = (per_cu > 1.0 ? per_cu : 1.0) * per_block;
-                if (cost < bestCost) { bestCost = cost; bTW = TW; bNT = NT; bNG = NG; bMT = MT; }
+                if (cost < bestCost) { bestCost = cost; bTW = TW; bNT = NT; bNG = NG; bMT = MT; bWS = WS; }
+                }
             }
         }
     }
@@ -1336,7 +1364,7 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     plan->PH = (rows_span - 1) * d->stride + d->KH;
     plan->PW = (bTW - 1) * d->stride + d->KW;
     plan->ilv = (!linear && bNT > 1 && !no_ilv) ? 1 : 0;
-    plan->pf = 0;
+    plan->pf = bWS;
     plan->PWp = plan->ilv ? rup_d(plan->PW, bNT) : plan->PW;
     plan->npos = plan->PH * plan->PWp;
     plan->plane = rup_d(plan->npos * 16, 1024);
@@ -1347,7 +1375,7 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
     plan->nsteps = jaf_cdiv(taps * bNG, 4);
     plan->nsteps_last = jaf_cdiv(taps * plan->ng_last, 4);
     plan->mblocks = jaf_cdiv(M, 16 * MT);
-    plan->lds_bytes = (int)((long)sb * bNG * plan->plane + (long)sb * plan->nsteps * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
+    plan->lds_bytes = (int)((long)sb * bNG * plan->plane + (long)sb * (bWS ? bWS : plan->nsteps) * MT * 1024 + 2L * 16 * plan->nsteps * 4 + 64);
     // (split: the hi image and the residual image of every chunk, [chunk][image][k-step]: the layout jaf_conv2d_pack makes)
     plan->packed_floats = ((int64_t)d->G * plan->mblocks * plan->nchunks * sb * plan->nsteps * MT * 1024) / 4;
     return JAF_OK;
@@ -1382,7 +1410,8 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     }
     if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
     if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
-    if (p->lds_bytes < sb * p->NG * p->plane + sb * p->nsteps * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
+    if (p->pf < 0 || p->pf > p->nsteps || (p->pf && sb != 1)) return false;
+    if (p->lds_bytes < sb * p->NG * p->plane + sb * (p->pf ? p->pf : p->nsteps) * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
     if (p->lds_bytes > 160 * 1024) return false;
     if ((long)d->H * d->W * 16 >= CD_OOB) return false;
     return true;
@@ -1457,7 +1486,7 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.p = *plan;
     const int sb = d->precision == JAF_PREC_BF16X3 ? 2 : 1;        // split: [hi planes][lo planes][hi weights][lo weights][table]
     a.off_w = sb * plan->NG * plan->plane;
-    a.off_tab = a.off_w + sb * plan->nsteps * plan->MT * 1024;
+    a.off_tab = a.off_w + sb * (plan->pf ? plan->pf : plan->nsteps) * plan->MT * 1024;
     a.ntiles = plan->tiles_x * plan->tiles_p;
     a.ngroups8 = jaf_cdiv(d->Cin, 8);
     a.inv_pwp = 1.0f / (float)plan->PWp;
