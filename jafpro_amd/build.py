@@ -32,7 +32,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-re
 
 def _digest(path: str, flags) -> str:
     h = hashlib.sha256()
-    for p in (path, os.path.join(CSRC, "jaf_common.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(CSRC, "conv_dma_kernel.h"),
+    for p in (path, os.path.join(CSRC, "jaf_common.h"), os.path.join(CSRC, "conv_internal.h"), os.path.join(CSRC, "conv_dma_kernel.h"), os.path.join(CSRC, "jaf_fdiv.h"),
               os.path.join(HERE, "..", "include", "jafpro_hip.h")):
         with open(p, "rb") as f:
             h.update(f.read())

@@ -1037,17 +1037,18 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
         const int xcd = bid & 7, j = bid >> 3, qn = nblk >> 3, rn = nblk & 7;
         L = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
     }
-    const int mb = L % P.mblocks;
-    L /= P.mblocks;
-    const int tile = L % a.ntiles;
-    const int ngi = L / a.ntiles;
-    const int n = ngi / d.G;
+    // (divisions by launch constants: multiply-high + shift, jaf_fdiv.h)
+    const int Lm = (int)jaf_fdiv_q((unsigned)L, a.dv_mblocks);
+    const int mb = L - Lm * P.mblocks;
+    const int ngi = (int)jaf_fdiv_q((unsigned)Lm, a.dv_ntiles);
+    const int tile = Lm - ngi * a.ntiles;
+    const int n = (int)jaf_fdiv_q((unsigned)ngi, a.dv_G);
     const int g = ngi - n * d.G;
-    const int tx = tile % P.tiles_x;
-    const int tb = tile / P.tiles_x;
+    const int tb = (int)jaf_fdiv_q((unsigned)tile, a.dv_tiles_x);
+    const int tx = tile - tb * P.tiles_x;
     const int x0 = tx * P.TWIN;
     const int pbase = tb * (64 * NT);
-    const int oy0 = pbase / P.TWIN;
+    const int oy0 = (int)jaf_fdiv_q((unsigned)pbase, a.dv_twin);
     const int iy0 = oy0 * d.stride - d.pad_t;
     const int ix0 = x0 * d.stride - d.pad_l;
     const int OHW = d.OH * d.OW;
@@ -1056,7 +1057,7 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
     // ---- one-time table: (slot, tile nt) -> patch byte offset; [0]: full chunk, [1]: last chunk ----
     {
         const int taps = d.KH * d.KW;
-        const float inv_kw = 1.0f / (float)d.KW;
+        const float inv_kw = a.inv_kw;
         for (int e = tid; e < 2 * 16 * P.nsteps; e += 256) {
             const int nt = e & 3;
             int s = e >> 2;
@@ -1065,10 +1066,10 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
             const int ngc = which ? P.ng_last : NG;
             int v = 0;
             if (s < taps * ngc) {
-                const int tap = (int)(((float)s + 0.5f) / (float)ngc), grp = s - tap * ngc;
-                const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - ky * d.KW;
+                const int tap = (int)(((float)s + 0.5f) * (which ? a.inv_ng_last : a.inv_ng)), grp = s - __mul24(tap, ngc);
+                const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - __mul24(ky, d.KW);
                 const int xk = (a.ilv ? d.stride * nt : 0) + kx;
-                v = grp * plane + (ky * PWp + (xk & cmask) * PWq + (xk >> lg)) * 16;
+                v = __mul24(grp, plane) + (__mul24(ky, PWp) + __mul24(xk & cmask, PWq) + (xk >> lg)) * 16;
             }
             s_tab[e] = v;
         }
@@ -1081,11 +1082,11 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
     for (int nt = 0; nt < NT; ++nt) {
         const int p = a.ilv ? (pbase + wave * 16 * NT + li * NT + nt) : (pbase + (wave * NT + nt) * 16 + li);
         const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
-        const int oxr = p - oy * P.TWIN;
+        const int oxr = p - __mul24(oy, P.TWIN);
         const int ox = x0 + oxr;
         const bool valid = (oy < d.OH) && (ox < d.OW);
-        boff[nt] = valid ? (((oy - oy0) * d.stride * PWp + (oxr >> lg) * d.stride) * 16) : 0;
-        opix[nt] = valid ? (oy * d.OW + ox) : -1;
+        boff[nt] = valid ? ((__mul24(oy - oy0, d.stride * PWp) + __mul24(oxr >> lg, d.stride)) * 16) : 0;
+        opix[nt] = valid ? (__mul24(oy, d.OW) + ox) : -1;
     }
 
     // ---- DMA source offsets: wave w fills rounds w and w+4 (64 slots each) of every group plane ----
@@ -1099,9 +1100,9 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
         for (int j = 0; j < CD_RPW; ++j) {
             const int slot = lane + 64 * (wave + 4 * j);
             const int r = (int)(((float)slot + 0.5f) * a.inv_pwp);
-            const int rem = slot - r * PWp;
+            const int rem = slot - __mul24(r, PWp);
             const int cls = (int)(((float)rem + 0.5f) * a.inv_pwq);
-            const int x = ((rem - cls * PWq) << lg) + cls;               // patch column held by this slot
+            const int x = ((rem - __mul24(cls, PWq)) << lg) + cls;               // patch column held by this slot
             const int iyd = iy0 + r, ixd = ix0 + x;
             bool ok = (slot < npos) && (x < PW) && (iyd >= 0) && (ixd >= 0) && (iyd < Hd) && (ixd < Wd);
             int iy = iyd, ix = ixd;
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(256, CD_MIN_WG(MT, NT, LSTM, DZ, PLAIN)) void conv_
                 iy = iyd >> 1;
                 ix = ixd >> 1;
             }
-            dvoff[j] = ok ? ((iy * d.W + ix) * 16) : CD_OOB;
+            dvoff[j] = ok ? ((__mul24(iy, d.W) + ix) * 16) : CD_OOB;
         }
     }
     // plane (group8 = 0) of this (image, group); consecutive group8 planes are HW*16 bytes apart
@@ -1226,6 +1227,8 @@ static bool cd_desc_ok(const jaf_conv_desc* d) {
     if (d->w_cin_off < 0 || d->w_cin_tot < 1) return false;
     if (d->out_coff < 0 || d->out_coff + d->G * d->Cout > d->out_ctot) return false;
     if (d->pad_t < 0 || d->pad_l < 0) return false;
+    // (the kernels' per-lane index arithmetic uses 24-bit multiplies)
+    if (d->H >= (1 << 22) || d->W >= (1 << 22) || d->OH >= (1 << 22) || d->OW >= (1 << 22)) return false;
     // JAF_PREC_BF16X3: the same kernels' split-bf16 form (conv_dma_split.hip) over hi / lo operand images
     if (d->precision != JAF_PREC_BF16 && d->precision != JAF_PREC_BF16X3) return false;
     return true;
@@ -1492,6 +1495,14 @@ static void cd_fill(ConvDArgs& a, const jaf_conv_desc* d, const jaf_conv_plan* p
     a.inv_pwp = 1.0f / (float)plan->PWp;
     a.inv_pwq = 1.0f / (float)(plan->ilv ? plan->PWp / plan->NT : plan->PWp);
     a.inv_twin = 1.0f / (float)plan->TWIN;
+    a.dv_mblocks = jaf_fdiv_make((uint32_t)plan->mblocks);
+    a.dv_ntiles = jaf_fdiv_make((uint32_t)a.ntiles);
+    a.dv_G = jaf_fdiv_make((uint32_t)d->G);
+    a.dv_tiles_x = jaf_fdiv_make((uint32_t)plan->tiles_x);
+    a.dv_twin = jaf_fdiv_make((uint32_t)plan->TWIN);
+    a.inv_kw = 1.0f / (float)d->KW;
+    a.inv_ng = 1.0f / (float)plan->NG;
+    a.inv_ng_last = 1.0f / (float)plan->ng_last;
     a.ilv = plan->ilv;
     a.vec = (plan->ilv && d->OW % plan->NT == 0) ? 1 : 0;
     a.c_prev = nullptr;

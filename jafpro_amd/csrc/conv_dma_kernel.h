@@ -2,6 +2,7 @@
 // instructions per product): the launch arguments of the packed-input convolution kernels and their epilogue.
 #pragma once
 #include "conv_internal.h"
+#include "jaf_fdiv.h"
 #include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -27,6 +28,9 @@ struct ConvDArgs {
     int off_w, off_tab;
     int ntiles, ngroups8;
     float inv_pwp, inv_pwq, inv_twin;
+    // the prologue's divisions of the block index by launch constants (jaf_fdiv.h) and the slot table's reciprocals
+    jaf_fdiv dv_mblocks, dv_ntiles, dv_G, dv_tiles_x, dv_twin;
+    float inv_kw, inv_ng, inv_ng_last;
     int ilv, vec;      // pixel interleave (a lane's NT tiles = NT consecutive pixels); vector epilogue allowed
     int gates_bf16;    // LSTM: gates_out is a bf16 tensor (halves the dominant epilogue traffic)
     double* stats;     // nullable: [N][slots][2] += (sum, sum of squares) of the image's outputs (act NONE, G == 1):

@@ -43,17 +43,18 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
         const int xcd = bid & 7, j = bid >> 3, qn = nblk >> 3, rn = nblk & 7;
         L = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + j;
     }
-    const int mb = L % P.mblocks;
-    L /= P.mblocks;
-    const int tile = L % a.ntiles;
-    const int ngi = L / a.ntiles;
-    const int n = ngi / d.G;
+    // (divisions by launch constants: multiply-high + shift, jaf_fdiv.h)
+    const int Lm = (int)jaf_fdiv_q((unsigned)L, a.dv_mblocks);
+    const int mb = L - Lm * P.mblocks;
+    const int ngi = (int)jaf_fdiv_q((unsigned)Lm, a.dv_ntiles);
+    const int tile = Lm - ngi * a.ntiles;
+    const int n = (int)jaf_fdiv_q((unsigned)ngi, a.dv_G);
     const int g = ngi - n * d.G;
-    const int tx = tile % P.tiles_x;
-    const int tb = tile / P.tiles_x;
+    const int tb = (int)jaf_fdiv_q((unsigned)tile, a.dv_tiles_x);
+    const int tx = tile - tb * P.tiles_x;
     const int x0 = tx * P.TWIN;
     const int pbase = tb * (64 * NT);
-    const int oy0 = pbase / P.TWIN;
+    const int oy0 = (int)jaf_fdiv_q((unsigned)pbase, a.dv_twin);
     const int iy0 = oy0 * d.stride - d.pad_t;
     const int ix0 = x0 * d.stride - d.pad_l;
     const int OHW = d.OH * d.OW;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
     // ---- one-time table: (slot, tile nt) -> patch byte offset; [0]: full chunk, [1]: last chunk ----
     {
         const int taps = d.KH * d.KW;
-        const float inv_kw = 1.0f / (float)d.KW;
+        const float inv_kw = a.inv_kw;
         for (int e = tid; e < 2 * 16 * P.nsteps; e += 256) {
             const int nt = e & 3;
             int s = e >> 2;
@@ -71,10 +72,10 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
             const int ngc = which ? P.ng_last : NG;
             int v = 0;
             if (s < taps * ngc) {
-                const int tap = (int)(((float)s + 0.5f) / (float)ngc), grp = s - tap * ngc;
-                const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - ky * d.KW;
+                const int tap = (int)(((float)s + 0.5f) * (which ? a.inv_ng_last : a.inv_ng)), grp = s - __mul24(tap, ngc);
+                const int ky = (int)(((float)tap + 0.5f) * inv_kw), kx = tap - __mul24(ky, d.KW);
                 const int xk = (a.ilv ? d.stride * nt : 0) + kx;
-                v = grp * plane + (ky * PWp + (xk & cmask) * PWq + (xk >> lg)) * 16;
+                v = __mul24(grp, plane) + (__mul24(ky, PWp) + __mul24(xk & cmask, PWq) + (xk >> lg)) * 16;
             }
             s_tab[e] = v;
         }
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
     for (int nt = 0; nt < NT; ++nt) {
         const int p = a.ilv ? (pbase + wave * 16 * NT + li * NT + nt) : (pbase + (wave * NT + nt) * 16 + li);
         const int oy = (int)(((float)p + 0.5f) * a.inv_twin);
-        const int oxr = p - oy * P.TWIN;
+        const int oxr = p - __mul24(oy, P.TWIN);
         const int ox = x0 + oxr;
         const bool valid = (oy < d.OH) && (ox < d.OW);
-        boff[nt] = valid ? (((oy - oy0) * d.stride * PWp + (oxr >> lg) * d.stride) * 16) : 0;
-        opix[nt] = valid ? (oy * d.OW + ox) : -1;
+        boff[nt] = valid ? ((__mul24(oy - oy0, d.stride * PWp) + __mul24(oxr >> lg, d.stride)) * 16) : 0;
+        opix[nt] = valid ? (__mul24(oy, d.OW) + ox) : -1;
     }
 
     // ---- DMA source offsets: wave w fills rounds w and w+4 (64 slots each) of every group plane ----
@@ -105,9 +106,9 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
         for (int j = 0; j < CD_RPW; ++j) {
             const int slot = lane + 64 * (wave + 4 * j);
             const int r = (int)(((float)slot + 0.5f) * a.inv_pwp);
-            const int rem = slot - r * PWp;
+            const int rem = slot - __mul24(r, PWp);
             const int cls = (int)(((float)rem + 0.5f) * a.inv_pwq);
-            const int x = ((rem - cls * PWq) << lg) + cls;
+            const int x = ((rem - __mul24(cls, PWq)) << lg) + cls;
             const int iyd = iy0 + r, ixd = ix0 + x;
             bool ok = (slot < npos) && (x < PW) && (iyd >= 0) && (ixd >= 0) && (iyd < Hd) && (ixd < Wd);
             int iy = iyd, ix = ixd;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
                 iy = iyd >> 1;
                 ix = ixd >> 1;
             }
-            dvoff[j] = ok ? ((iy * d.W + ix) * 16) : CD_OOB;
+            dvoff[j] = ok ? ((__mul24(iy, d.W) + ix) * 16) : CD_OOB;
         }
     }
     // split image: channel group cg of this (image, group) has its hi plane at 2 cg and its lo plane at 2 cg + 1

@@ -343,3 +343,39 @@ def test_environment_switches_are_read_once_at_import():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 seen |= set(re.findall(r"(?:environ(?:\.get)?\(|environ\[|getenv\()\s*\"(JAF\w+)\"", text))
     assert seen == {"JAF_RUN_AHEAD", "JAF_RANK_CHECK_EVERY", "JAF_DIST_ISSUE_ON_WGRAD", "JAF_ACCU_SPLIT", "JAF_HW_QUEUES", "JAFPRO_HIP_LIB"}, seen
+
+
+def test_division_by_launch_constants_is_exact(tmp_path):
+    """csrc/jaf_fdiv.h (the convolution kernels' block-index divisions: multiply-high + shift with a host-made magic number) against
+    the C `/` for every divisor up to 70 000, the edge numerators of each and a sweep of small numerators; compiled with gcc."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include "jaf_fdiv.h"
+int main(void) {
+    unsigned long bad = 0;
+    for (uint32_t d = 1; d <= 70000; ++d) {
+        jaf_fdiv f = jaf_fdiv_make(d);
+        uint32_t ns[] = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 12345678u, 0x7fffffffu, 0x7ffffffeu, 0x40000000u,
+                         (0x7fffffffu / d) * d, (0x7fffffffu / d) * d - 1};
+        for (unsigned i = 0; i < sizeof(ns) / sizeof(ns[0]); ++i) { uint32_t n = ns[i] & 0x7fffffffu; if (jaf_fdiv_host(n, f) != n / d) ++bad; }
+        if (d < 2000) for (uint32_t n = 0; n < 100000; n += 7) if (jaf_fdiv_host(n, f) != n / d) ++bad;
+    }
+    uint32_t big[] = {0x7fffffffu, 0x40000001u, 0x3fffffffu, 1000003u, 16777259u};
+    for (unsigned i = 0; i < 5; ++i) {
+        jaf_fdiv f = jaf_fdiv_make(big[i]);
+        for (uint32_t n = 0x7fffff00u; n >= 0x7fffff00u && n <= 0x7fffffffu; ++n) if (jaf_fdiv_host(n, f) != n / big[i]) ++bad;
+    }
+    printf("%lu\n", bad);
+    return bad != 0;
+}
+''')
+    exe = tmp_path / "t"
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "jafpro_amd", "csrc")
+    subprocess.run(["gcc", "-O2", "-I", csrc, str(src), "-o", str(exe)], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "0", r.stdout
