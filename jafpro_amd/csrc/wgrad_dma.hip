@@ -49,6 +49,8 @@ struct WgDArgs {
     float* ws;             // conv_wgrad_fast_kernel: split-K partials [nsplit][dW layout] (plain stores) instead of atomics into dw; NULL: atomics
     long ws_stride;        // floats of one partial = G * Cout * w_cin_tot * 9
     int off_lo;            // SPLIT: byte offset of the lo tiles from the hi tiles inside a tile buffer (patch and dz alike)
+    int ky0, kyn;          // 7 x 7: the kernel rows [ky0, ky0 + kyn) this launch accumulates (49 accumulator tiles do not fit the
+                           // register file: two launches of 4 + 3 rows); other sizes: 0, KS
     int xmul;              // !SPLIT: 2 when the x image is a split-bf16 image of which only the hi planes are read ("mixed" mode:
                            // forward in split-bf16, backward in bf16 -- a hi plane IS the bf16 image), else 1
 };
@@ -71,7 +73,9 @@ struct WgDArgs {
 template <int MTW, int KS, bool PAIR, bool DB, int XI, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a) {
     constexpr int NTAP = KS * KS;
-    constexpr int NACC = PAIR ? (NTAP + 1) / 2 : NTAP;
+    constexpr int KYN = KS == 7 ? 4 : KS;            // kernel rows per launch (WgDArgs.ky0 / kyn)
+    constexpr int NACC = PAIR ? (NTAP + 1) / 2 : KYN * KS;
+    static_assert(!(PAIR && KS == 7), "the paired form keeps all taps in one launch");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const jaf_conv_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -300,8 +304,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                 }
             } else
 #pragma unroll
-            for (int ky = 0; ky < KS; ++ky) {
-                const int rowoff = ((2 * ks * s + ky) * PWp) * 32;
+            for (int ky = 0; ky < KYN; ++ky) {
+                if constexpr (KS == 7) { if (ky >= a.kyn) break; }
+                const int rowoff = ((2 * ks * s + ky + (KS == 7 ? a.ky0 : 0)) * PWp) * 32;
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
                     const int a0 = (bbase[0][kx] + rowoff) ^ bswz[0][kx];
@@ -372,6 +377,32 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
                     }
                 }
             }
+        }
+    } else if constexpr (KS == 7) {
+        // 7 x 7 (the propagater's first and last layers: dW is a few thousand floats, every workgroup adds to all of it).  A lane's
+        // taps of one (output channel, input channel) pair are 196 bytes apart from its neighbour's: issued straight from the
+        // accumulators, every lane of an atomic instruction hit its own cache line (0.38 ms per launch, ~40 G lane-atomics per
+        // second).  The waves' k-step partials are summed in LDS first ([tile][row][channel][tap], ds_add_f32) and the
+        // workgroup then walks dW in memory order: a quarter of the atomics, 16 lanes per cache line.
+        static_assert(MTW == 1, "one 16-row tile per workgroup");
+        float* s_ep = (float*)smem;
+        const int per_tile = 16 * 16 * NACC;
+        __syncthreads();            // every wave is done with the tile buffers
+        for (int e = tid; e < WC * per_tile; e += 256) s_ep[e] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) atomicAdd(&s_ep[((wc * 16 + q * 4 + j) * 16 + li) * NACC + t], acc[0][t][j]);
+        __syncthreads();
+        const int ntap = a.kyn * KS;
+        for (int e = tid; e < WC * per_tile; e += 256) {
+            const int tci = e / per_tile, r0 = e - tci * per_tile;
+            const int row = r0 / (16 * NACC), r1 = r0 - row * (16 * NACC);
+            const int cil = r1 / NACC, t = r1 - cil * NACC;
+            const int co = co0 + row, ci = ci0 + tci * 16 + cil;
+            if (co < d.Cout && ci < d.Cin && t < ntap)
+                atomicAdd(a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + ci) * NTAP + a.ky0 * KS + t, s_ep[e]);
         }
     } else {
         const int ci = cit + li;
@@ -728,7 +759,8 @@ static int wgd_launch_xi(WgDArgs& a, int lds, long items, long outblocks, long d
     const double slots_env = 0.0;
     const double slots = slots_env > 0.0 ? slots_env : (double)jaf_kernel_slots((const void*)k, lds, occ);
     a.nsplit = (int)(slots_env < 0.0 ? jaf_wgrad_nsplit(items, outblocks, dw_floats)
-                                     : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots));
+                     : (KS == 7 ? jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots, 1.0e-5, 1024)      // (49 taps: ~10 us per tile, measured)
+                                : jaf_wgrad_nsplit_rounds(items, outblocks, dw_floats, slots)));
     a.ws = nullptr;
     const long nblk = outblocks * a.nsplit;
     if (nblk > 0x7fffffffL) return JAF_EINVAL;
@@ -803,7 +835,7 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     const bool query = wr && wr->need;
     JAF_REQUIRE(hidden == 0 || (hidden > 0 && d->KH == 3 && d->Cout == 4 * hidden));
     JAF_REQUIRE(x_ng8_tot == 0 || x_ng8_tot >= jaf_cdiv(d->Cin, 8));
-    JAF_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5) && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
+    JAF_REQUIRE(d->KH == d->KW && (d->KH == 1 || d->KH == 3 || d->KH == 5 || d->KH == 7) && d->dil_in == 1 && d->stride >= 1 && d->stride <= 2);
     const int KS = d->KH;
     JAF_REQUIRE(d->N >= 1 && d->G >= 1 && d->Cin >= 1 && d->Cout >= 1 && d->w_cin_off >= 0 && d->w_cin_off + d->Cin <= d->w_cin_tot);
     hipStream_t s = (hipStream_t)s_;
@@ -819,7 +851,7 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     a.lstmC = hidden;
     int MTW = 1;
     long bestPad = 1L << 60;
-    for (int mt = (KS == 5 ? 1 : 4); mt >= 1; --mt) {
+    for (int mt = (KS >= 5 ? 1 : 4); mt >= 1; --mt) {      // (5 x 5, 7 x 7: 25 / 49 accumulator tiles per 16 rows)
         long pad = (long)jaf_cdiv(d->Cout, 16 * mt) * 16 * mt;
         if (pad < bestPad) { bestPad = pad; MTW = mt; }
     }
@@ -833,6 +865,7 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     a.WC = d->Cin <= 16 ? 1 : (d->Cin <= 32 ? 2 : 4);
     // stride-2 patches are 22 KB per 16 channels: at most 32 channels per workgroup (more input-channel blocks instead)
     while (a.WC > 1 && jaf_cdiv(a.WC * a.nx, 4) > WD_XI) a.WC >>= 1;
+    if (KS == 7 && a.WC > 2) a.WC = 2;          // (the 7 x 7 epilogue sums 16 x 16 x 28 floats per input-channel tile in LDS)
     // split-bf16: hi and lo tiles of both operands; keep two workgroups per CU (<= 80 KB) where the channel tiling allows
     while (split && a.WC > 1 && 2 * (a.WC * a.xplane + MTW * 4096) > 80 * 1024) a.WC >>= 1;
     // narrower input-channel tiles where that lets the split tile be double-buffered (<= 40 KB): bf16x3 step 116.2 -> 115.5 ms
@@ -843,7 +876,7 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     {   // launches that cannot fill the chip: smaller output blocks = more, shorter workgroups (see jafb_wgrad)
         const long items0 = (long)d->N * jaf_cdiv(d->OW, WD_TW) * jaf_cdiv(d->OH, WD_TH);
         const long sp = items0 < JAF_WGRAD_MAX_SPLIT ? items0 : JAF_WGRAD_MAX_SPLIT;
-        while (KS != 5 && (long)d->G * jaf_cdiv(d->Cout, 16 * MTW) * jaf_cdiv(d->Cin, 16 * a.WC) * sp < 512) {
+        while (KS < 5 && (long)d->G * jaf_cdiv(d->Cout, 16 * MTW) * jaf_cdiv(d->Cin, 16 * a.WC) * sp < 512) {
             if (MTW > 1) MTW = (MTW == 4) ? 2 : 1;
             else if (a.WC > 1) a.WC >>= 1;
             else break;
@@ -873,6 +906,7 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     if (db) lds *= 2;
     const int lds_ep = 4 * 16 * WD_EP * 4;
     if (KS == 3 && lds < lds_ep) lds = lds_ep;
+    if (KS == 7 && lds < a.WC * 16 * 16 * 28 * 4) lds = a.WC * 16 * 16 * 28 * 4;
     JAF_REQUIRE(lds <= 160 * 1024);
     JAF_REQUIRE(!(KS == 5 && d->Cin <= 8) || (a.WK == 4 && a.xplane <= 65536));     // PAIR: see padr in the kernel
     const long items = (long)d->N * a.tiles_x * a.tiles_y;
@@ -900,6 +934,17 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
 #define JAF_WGDP(MT_, KS_, PAIR_) \
     return db ? wgd_launch<MT_, KS_, PAIR_, true>(a, lds, items, outblocks, dw_floats, s) \
               : wgd_launch<MT_, KS_, PAIR_, false>(a, lds, items, outblocks, dw_floats, s)
+    a.ky0 = 0;
+    a.kyn = KS;
+    if (KS == 7) {          // kernel rows 0-3, then 4-6 (see WgDArgs.ky0)
+        a.kyn = 4;
+        const int rc = db ? wgd_launch<1, 7, false, true>(a, lds, items, outblocks, dw_floats, s)
+                          : wgd_launch<1, 7, false, false>(a, lds, items, outblocks, dw_floats, s);
+        if (rc != JAF_OK) return rc;
+        a.ky0 = 4;
+        a.kyn = 3;
+        JAF_WGD(1, 7);
+    }
     if (KS == 5 && d->Cin <= 8) JAF_WGDP(1, 5, true);
     else if (KS == 5) JAF_WGD(1, 5);
     else if (KS == 1) switch (MTW) {

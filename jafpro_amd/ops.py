@@ -845,7 +845,7 @@ def _conv_raw(srcs: Sequence[torch.Tensor], specs, weight: torch.Tensor, w_rows_
 
 
 def _wgrad_packed_ok(m) -> bool:
-    return m.KH == m.KW and m.KH in (1, 3, 5) and m.stride in (1, 2)
+    return m.KH == m.KW and m.KH in (1, 3, 5, 7) and m.stride in (1, 2)
 
 
 def _grad_inplace(p: torch.Tensor) -> bool:

@@ -36,6 +36,7 @@ CONV_CASES = [
     (2, 3, [6], 8, 50, 50, 3, 2, 1, 1),                # stride 2, even size
     (1, 2, [8], 16, 25, 25, 3, 2, 1, 1),               # stride 2, odd size 25 -> 13
     (1, 1, [9], 32, 38, 38, 7, 1, 0, 0),               # 7x7 valid
+    (2, 1, [32], 3, 30, 37, 7, 1, 3, 0),               # 7x7 padded, two input-channel tiles (weight gradient: kernel rows in two launches)
     (2, 1, [256], 3, 16, 16, 1, 1, 0, 3),              # 1x1 + sigmoid
     (1, 24, [12, 12], 48, 26, 26, 3, 1, 1, 0),         # LSTM-like shape as a plain conv
     (1, 2, [96, 48], 48, 13, 13, 3, 1, 1, 1),
@@ -143,9 +144,9 @@ def test_conv2d_bf16_matrix_core_modes(case, mode):
         assert (err > 2 * tol * sc).double().mean().item() <= 2e-3, "dgrad source at %d" % off
         assert err.max().item() <= 8e-3 * sc, "dgrad source at %d" % off
         off += c
-    # weight gradient: bf16 matrix cores for 1x1 / 3x3 / 5x5 layers in "bf16" mode (x and dz rounded), the
+    # weight gradient: bf16 matrix cores for 1x1 / 3x3 / 5x5 / 7x7 layers in "bf16" mode (x and dz rounded), the
     # exact fp32 kernel otherwise -- either way it must match the float64 reference of what was rounded.
-    if mode == "bf16" and k not in (1, 3, 5):
+    if mode == "bf16" and k not in (1, 3, 5, 7):
         gw = torch.autograd.grad(F.conv2d(torch.cat([t.double().view(N, G, c, H, W) for t, c in zip(srcs, cins)], 2)
                                           .reshape(N, G * Cin, H, W), wr, None, stride=s, padding=p, groups=G),
                                  wr, dz)[0]
