@@ -998,6 +998,9 @@ extern "C" int jaf_convlstm_gates_bwd_packed_dt(jaf_stream_t s, int32_t N, int32
 // Minimum resident workgroups per CU the register allocator must leave room for (256 threads = one wave per SIMD each, so
 // k workgroups = k waves per SIMD = at most 512 / k registers per lane).  Without it the allocator spreads: <4,4> plain took
 // 148 registers (3 waves per SIMD) where 110 do.
+#ifndef CD_FORCE_SPLIT
+#define CD_FORCE_SPLIT 0      // probe builds: the CD_FORCE_* hooks apply to the split-bf16 plans instead of the bf16 ones
+#endif
 #ifndef CD_WS_CAND
 #define CD_WS_CAND 3      // k-steps per weight sub-load the planner may choose (jaf_conv_plan.pf)
 #endif
@@ -1296,15 +1299,15 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 const int nsteps = jaf_cdiv(taps * NG, 4);
                 const int nsteps_last = jaf_cdiv(taps * ng_last, 4);
 #ifdef CD_FORCE_NG
-                if (!split && d->G == 1 && M >= 64 && groups >= 4 && NG != CD_FORCE_NG) continue;
+                if (split == (CD_FORCE_SPLIT != 0) && d->G == 1 && M >= 64 && groups >= 4 && NG != CD_FORCE_NG) continue;
 #endif
                 // WS: k-steps of weights resident at a time (0: the whole chunk).  Sub-loads keep the LDS of a chunk with many channel
                 // groups (no padded half k-step: 3 x 3 taps x 4 groups = 9 exact steps) at that of a small one.
                 for (int wi = 0; wi < 2; ++wi) {
                 const int WS = wi == 0 ? 0 : CD_WS_CAND;
-                if (WS && (split || WS >= nsteps)) continue;
+                if (WS && WS >= nsteps) continue;
 #ifdef CD_FORCE_WSUB
-                if (!split && d->G == 1 && M >= 64 && groups >= 4 && WS != ((CD_FORCE_WSUB) < nsteps ? (CD_FORCE_WSUB) : 0)) continue;
+                if (split == (CD_FORCE_SPLIT != 0) && d->G == 1 && M >= 64 && groups >= 4 && WS != ((CD_FORCE_WSUB) < nsteps ? (CD_FORCE_WSUB) : 0)) continue;
 #endif
                 const int wl = WS ? WS : nsteps;
                 const long lds = (long)sb * NG * plane + (long)sb * wl * MT * 1024 + 2L * 16 * nsteps * 4 + 64;
@@ -1320,7 +1323,9 @@ extern "C" int jaf_conv2d_plan_packed_ex(const jaf_conv_desc* d, int lstm, int f
                 // the 256 -> 256 layer add up): where a launch has at least 4 workgroups per CU to run, 4 resident ones on half-size
                 // chunks beat 2 on full-size chunks by 2-11 % in spite of 10 % of padded k-steps (measured, 64 x 64 .. 256 x 256
                 // layers); with fewer workgroups than that the larger chunks win by 15-19 % (32 x 32 layers)
-                const double pen2 = 1.25;
+                // (split-bf16: three matrix-core instructions per operand pair, so the phases a resident neighbour hides weigh less --
+                // profiles/experiments/round5_weight_subloads.txt)
+                const double pen2 = split ? 1.15 : 1.25;
                 const double nblocks0 = (double)tiles_x * tiles_p * jaf_cdiv(M, 16 * MT) * d->N * d->G;
                 const bool big = nblocks0 >= 1024.0;
                 const double occ_pen = bl >= 4 ? 1.0 : (bl == 3 ? (big ? 0.5 * (1.0 + pen2) : 1.0) : (bl == 2 ? (big ? pen2 : 1.1) : 1.4));
@@ -1413,7 +1418,7 @@ static bool cd_plan_ok(const jaf_conv_desc* d, const jaf_conv_plan* p) {
     }
     if (p->PH < (rows_span - 1) * d->stride + d->KH) return false;
     if (p->PW < (p->TWIN - 1) * d->stride + d->KW) return false;
-    if (p->pf < 0 || p->pf > p->nsteps || (p->pf && sb != 1)) return false;
+    if (p->pf < 0 || p->pf > p->nsteps) return false;
     if (p->lds_bytes < sb * p->NG * p->plane + sb * (p->pf ? p->pf : p->nsteps) * p->MT * 1024 + 2 * 16 * p->nsteps * 4) return false;
     if (p->lds_bytes > 160 * 1024) return false;
     if ((long)d->H * d->W * 16 >= CD_OOB) return false;

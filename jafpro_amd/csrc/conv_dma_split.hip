@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
     const int PWq = PWp >> lg;
 
     const int lo_patch = NG * plane;                    // lo planes behind the hi planes
-    const int lo_w = P.nsteps * MT * 1024;              // lo weight image behind the hi one
+    const int lo_w = (P.pf > 0 ? P.pf : P.nsteps) * MT * 1024;              // lo weight image behind the hi one
     unsigned char* s_patch = smem;
     unsigned char* s_w = smem + a.off_w;
     int* s_tab = (int*)(smem + a.off_tab);
@@ -146,60 +146,67 @@ __global__ __launch_bounds__(256) void conv_dma_split_kernel(const ConvDArgs a) 
     const long wimg_bytes = (long)P.nsteps * MT * 1024;
     const unsigned char* wbase = a.wpk + ((long)(g * P.mblocks + mb) * P.nchunks) * 2 * wimg_bytes;
 
+    // plan.pf > 0: the chunk's weights pass through LDS `pf` k-steps at a time (conv_dma.hip)
+    const int wsub = P.pf > 0 ? P.pf : P.nsteps;
     for (int chunk = 0; chunk < P.nchunks; ++chunk) {
         const bool last = (chunk == P.nchunks - 1);
         const int ngc = last ? P.ng_last : NG;
         const int nst = last ? P.nsteps_last : P.nsteps;
-        __syncthreads();   // previous chunk consumed (first pass: slot table visible)
-        {
-            const unsigned char* wsrc = wbase + (long)chunk * 2 * wimg_bytes;
-            for (int e = wave; e < nst * MT; e += 4) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + e * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + wimg_bytes + e * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(s_w + lo_w + e * 1024), 16, 0, 0);
-            }
-            const unsigned char* cbase = xbase + (long)(chunk * NG) * 2 * plane_bytes;
-            for (int grp = 0; grp < ngc; ++grp) {
+        const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
+        for (int s0 = 0; s0 < nst; s0 += wsub) {
+            const int s1 = s0 + wsub < nst ? s0 + wsub : nst;
+            __syncthreads();   // previous (sub-)chunk consumed (first pass: slot table visible)
+            {
+                const unsigned char* wsrc = wbase + (long)chunk * 2 * wimg_bytes + (long)s0 * MT * 1024;
+                for (int e = wave; e < (s1 - s0) * MT; e += 4) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + e * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(s_w + e * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + wimg_bytes + e * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(s_w + lo_w + e * 1024), 16, 0, 0);
+                }
+                if (s0 == 0) {
+                    const unsigned char* cbase = xbase + (long)(chunk * NG) * 2 * plane_bytes;
+                    for (int grp = 0; grp < ngc; ++grp) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const __amdgpu_buffer_rsrc_t rs =
-                        __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)(2 * grp + h) * plane_bytes), 0, plane_bytes, 0x00020000);
+                        for (int h = 0; h < 2; ++h) {
+                            const __amdgpu_buffer_rsrc_t rs =
+                                __builtin_amdgcn_make_buffer_rsrc((void*)(cbase + (long)(2 * grp + h) * plane_bytes), 0, plane_bytes, 0x00020000);
 #pragma unroll
-                    for (int j = 0; j < CD_RPW; ++j) {
-                        const int round = wave + 4 * j;
-                        if (round < nrounds)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                rs, (__attribute__((address_space(3))) void*)(s_patch + h * lo_patch + grp * plane + round * 1024), 16, dvoff[j], 0, 0, 0);
+                            for (int j = 0; j < CD_RPW; ++j) {
+                                const int round = wave + 4 * j;
+                                if (round < nrounds)
+                                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                        rs, (__attribute__((address_space(3))) void*)(s_patch + h * lo_patch + grp * plane + round * 1024), 16, dvoff[j], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
-        }
-        __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
-        __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0);      // vmcnt(0): the DMAs of this wave have landed
+            __syncthreads();
 
-        const int* tab = s_tab + (last ? 16 * P.nsteps : 0) + q * 4;
-        u32x4 tnext = *(const u32x4*)tab;
-        for (int st = 0; st < nst; ++st) {
-            const u32x4 t4 = tnext;
-            tnext = *(const u32x4*)(tab + 16 * (st + 1 < nst ? st + 1 : st));
-            const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
-            bf16x8 bh[NT], bl[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
-                bl[nt] = *(const bf16x8*)(s_patch + lo_patch + off[nt] + boff[nt]);
-            }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const bf16x8 ah = *(const bf16x8*)(s_w + (st * MT + mt) * 1024 + lane * 16);
-                const bf16x8 al = *(const bf16x8*)(s_w + lo_w + (st * MT + mt) * 1024 + lane * 16);
+            u32x4 tnext = *(const u32x4*)(tab + 16 * s0);
+            for (int st = s0; st < s1; ++st) {
+                const u32x4 t4 = tnext;
+                tnext = *(const u32x4*)(tab + 16 * (st + 1 < s1 ? st + 1 : st));
+                const int off[4] = {(int)t4.x, (int)t4.y, (int)t4.z, (int)t4.w};
+                bf16x8 bh[NT], bl[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    // the two cross terms first: they are 2^-8 of the main one and the sum stays fp32 either way
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                    bh[nt] = *(const bf16x8*)(s_patch + off[nt] + boff[nt]);
+                    bl[nt] = *(const bf16x8*)(s_patch + lo_patch + off[nt] + boff[nt]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const bf16x8 ah = *(const bf16x8*)(s_w + ((st - s0) * MT + mt) * 1024 + lane * 16);
+                    const bf16x8 al = *(const bf16x8*)(s_w + lo_w + ((st - s0) * MT + mt) * 1024 + lane * 16);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        // the two cross terms first: they are 2^-8 of the main one and the sum stays fp32 either way
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[mt][nt], 0, 0, 0);
+                    }
                 }
             }
         }

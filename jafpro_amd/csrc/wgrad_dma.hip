@@ -14,6 +14,7 @@
 //   unswizzled (position, half) -> global offset (cdna_hip_programming.md rule 21);
 // * out-of-image positions / pixels get an out-of-range buffer offset and arrive as zeros.
 #include "conv_internal.h"
+#include "jaf_fdiv.h"
 #include <stdlib.h>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,6 +50,7 @@ struct WgDArgs {
     float* ws;             // conv_wgrad_fast_kernel: split-K partials [nsplit][dW layout] (plain stores) instead of atomics into dw; NULL: atomics
     long ws_stride;        // floats of one partial = G * Cout * w_cin_tot * 9
     int off_lo;            // SPLIT: byte offset of the lo tiles from the hi tiles inside a tile buffer (patch and dz alike)
+    jaf_fdiv dv_tiles, dv_tiles_x;     // conv_wgrad_dma_kernel: tile index -> (image, tile row, tile column) without integer divisions
     int ky0, kyn;          // 7 x 7: the kernel rows [ky0, ky0 + kyn) this launch accumulates (49 accumulator tiles do not fit the
                            // register file: two launches of 4 + 3 rows); other sizes: 0, KS
     int xmul;              // !SPLIT: 2 when the x image is a split-bf16 image of which only the hi planes are read ("mixed" mode:
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
 
     // DMA of one tile (image, pixel tile) into the buffer at byte offset `boff`
     auto issue = [&](int item, int boff) {
-        const int n = item / tiles;
+        const int n = (int)jaf_fdiv_q((unsigned)item, a.dv_tiles);
         const int tile = item - n * tiles;
-        const int ty = tile / a.tiles_x;
+        const int ty = (int)jaf_fdiv_q((unsigned)tile, a.dv_tiles_x);
         const int tx = tile - ty * a.tiles_x;
         const int oy0 = ty * WD_TH, ox0 = tx * WD_TW;
         const int iy0 = oy0 * s - d.pad_t;
@@ -887,6 +889,8 @@ static int wgd_core(jaf_stream_t s_, const jaf_conv_desc* d, const void* packed_
     a.ciblocks = jaf_cdiv(d->Cin, 16 * a.WC);
     a.tiles_x = jaf_cdiv(d->OW, WD_TW);
     a.tiles_y = jaf_cdiv(d->OH, WD_TH);
+    a.dv_tiles = jaf_fdiv_make((uint32_t)(a.tiles_x * a.tiles_y));
+    a.dv_tiles_x = jaf_fdiv_make((uint32_t)a.tiles_x);
     if (jaf_cdiv(a.WC * a.nx, 4) > WD_XI) return JAF_EUNSUPPORTED;
     a.off_dz = a.WC * a.xplane;
     a.ngin8 = jaf_cdiv(d->Cin, 8);

@@ -1342,7 +1342,8 @@ class _ConvLSTMFn(Function):
         ctx.set_materialize_grads(False)
         # on the packed bf16 path the saved gates are bf16 (they are the dominant traffic of the cell epilogue
         # and of the gate backward, which reads them exactly once)
-        g16 = _USE_PACKED and _PRECISION == PREC_BF16 and C % 4 == 0
+        # ("mixed": the forward pass is split-bf16, but the gates are saved for a bf16 backward pass -- bf16 gates there too)
+        g16 = _USE_PACKED and (_PRECISION == PREC_BF16 or _MIXED) and C % 4 == 0
         # bf16 storage: the cell state (written once, read by the next step and twice by the gate backward) in bf16 too -- whenever
         # it stays inside this node (zero initial state, c_T not handed out)
         st16 = g16 and bf16_storage_active() and h0 is None and not want_c
