@@ -64,11 +64,48 @@ __global__ void avgpool_bwd_kernel(const float* dy, float* dx, int H, int W, int
     dx[(nc * H + iy) * W + ix] = acc * inv;
 }
 
+// stride-2 pools (VGG: 2 x 2 / 2, the discriminators: 3 x 3 / 2 pad 1) with 4 consecutive input pixels per lane: one 16-byte store, the
+// window bounds by shifts (the general kernel spends two integer divisions and a 4-byte store per pixel: 1.7 TB/s)
+template <int K>
+__global__ void avgpool_bwd_s2_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int OH, int OW, int pad) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int ix0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int iy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (ix0 >= W || iy >= H) return;
+    const long nc = blockIdx.z;
+    const float* p = dy + nc * OH * OW;
+    const int ty = iy + pad - K + 2;                      // oy_lo = ceil((iy + pad - K + 1) / 2)
+    const int oy_lo = ty <= 0 ? 0 : ty >> 1;
+    int oy_hi = (iy + pad) >> 1;
+    if (oy_hi > OH - 1) oy_hi = OH - 1;
+    f4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ix = ix0 + j;
+        const int tx = ix + pad - K + 2;
+        const int ox_lo = tx <= 0 ? 0 : tx >> 1;
+        int ox_hi = (ix + pad) >> 1;
+        if (ox_hi > OW - 1) ox_hi = OW - 1;
+        float acc = 0.f;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) acc += p[oy * OW + ox];
+        o[j] = acc * (1.0f / (float)(K * K));
+    }
+    *(f4*)(dx + (nc * H + iy) * W + ix0) = o;
+}
+
 extern "C" int jaf_avgpool_bwd(jaf_stream_t s, const float* dy, float* dx, int32_t NC, int32_t H, int32_t W,
                                int32_t OH, int32_t OW, int32_t k, int32_t stride, int32_t pad) {
     JAF_REQUIRE(dy && dx && NC >= 1 && H >= 1 && W >= 1 && k >= 1 && stride >= 1 && pad >= 0);
     JAF_REQUIRE(OH == (H + 2 * pad - k) / stride + 1 && OW == (W + 2 * pad - k) / stride + 1);
     JAF_REQUIRE(H <= 65535 && NC <= 65535);
+    if (stride == 2 && (k == 2 || k == 3) && W % 4 == 0 && (((uintptr_t)dx) & 15) == 0) {
+        const dim3 b = block2d(W / 4);
+        const dim3 g(jaf_cdiv(W / 4, b.x), jaf_cdiv(H, b.y), NC);
+        if (k == 2) hipLaunchKernelGGL(avgpool_bwd_s2_kernel<2>, g, b, 0, (hipStream_t)s, dy, dx, H, W, OH, OW, pad);
+        else hipLaunchKernelGGL(avgpool_bwd_s2_kernel<3>, g, b, 0, (hipStream_t)s, dy, dx, H, W, OH, OW, pad);
+        return jaf_launch_status();
+    }
     const dim3 b = block2d(W);
     hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(jaf_cdiv(W, b.x), jaf_cdiv(H, b.y), NC), b, 0, (hipStream_t)s, dy, dx, H, W, OH, OW, k, stride, pad);
     return jaf_launch_status();
@@ -319,6 +356,9 @@ __global__ void resize_bwd_kernel(const DT* dy, float* dx, ResizeArgs a) {
 // Block (tx, ty) = one tile of tx x ty input pixels of one plane; the region is the union of the candidates of
 // the tile's first and last pixel (candidate ranges are monotonic in the pixel index).
 // DT: element type of dy (fp32, or bf16: the gradient of a bf16-stored handle, e.g. a decoder's lazily up-sampled input).
+#ifndef JAF_RB_ROWS8_MIN_H
+#define JAF_RB_ROWS8_MIN_H 50
+#endif
 template <typename DT>
 __global__ void resize_bwd_lds_kernel(const DT* __restrict__ dy, float* __restrict__ dx, ResizeArgs a) {
     extern __shared__ float s_reg[];
@@ -403,6 +443,45 @@ __global__ void resize_bwd_lds_kernel(const DT* __restrict__ dy, float* __restri
             }
         }
     }
+    if (fast) {
+        // up-sampling by <= 2.2x with align_corners (every decoder of the path).  Row streaming: a lane owns a.rows CONTIGUOUS rows of one
+        // input column; it walks the dy rows o that reach them once, takes the horizontal adjoint h(o) of its column (5 taps, weights
+        // hoisted above) and adds (1 - f) h to row floor(sy o), f h to the row below -- two running accumulators, flushed as the source
+        // row advances.  10 LDS reads + 14 fma per input pixel instead of the 25 + 25 of the per-pixel 5 x 5 gather (the kernel was
+        // vector-instruction bound); o, the source row and the flushes are wave-uniform (a wave is one row of the block).
+        const int r0 = gy0 + (int)threadIdx.y * a.rows;
+        int r1 = r0 + a.rows;                                  // owned rows [r0, r1)
+        if (r1 > a.H) r1 = a.H;
+        float* out = dx + (nc * a.H) * a.W + gx;
+        int cur = r0;                                          // next owned row to store
+        for (; cur < r1 && cur < a.y0; ++cur) out[(long)cur * a.W] = 0.f;      // rows above the crop window
+        int crow = cur - a.y0;                                 // crop row of `cur`
+        const int cend = (r1 - a.y0 < a.ch ? r1 - a.y0 : a.ch);   // crop rows [crow, cend) are owned and inside the window
+        float a0 = 0.f, a1 = 0.f;
+        if (any && crow < cend) {
+            int o = (int)floorf((float)(crow - 1) * a.inv_sy) - 1;
+            if (o < ry0) o = ry0;
+            for (; o <= ry1; ++o) {
+                const float src = a.sy * (float)o;
+                int i0 = (int)src;
+                if (i0 > a.ch - 1) i0 = a.ch - 1;
+                if (i0 < crow - 1) continue;
+                if (i0 >= cend) break;
+                while (crow < i0) {                            // rows above the source row are complete
+                    out[(long)(crow + a.y0) * a.W] = a0;
+                    a0 = a1; a1 = 0.f; ++crow;
+                }
+                const float l = (i0 < a.ch - 1) ? src - (float)i0 : 0.f;      // (the last row takes the whole weight: resize_src)
+                const float* row = s_reg + (o - ry0) * a.rw;
+                const float h = (wx[0] * row[cx[0]] + wx[1] * row[cx[1]]) + (wx[2] * row[cx[2]] + wx[3] * row[cx[3]]) + wx[4] * row[cx[4]];
+                if (i0 == crow - 1) a0 += l * h;
+                else { a0 += (1.f - l) * h; a1 += l * h; }
+            }
+        }
+        for (; crow < cend; ++crow) { out[(long)(crow + a.y0) * a.W] = a0; a0 = a1; a1 = 0.f; }
+        for (cur = (crow + a.y0 > cur ? crow + a.y0 : cur); cur < r1; ++cur) out[(long)cur * a.W] = 0.f;      // rows below the window
+        return;
+    }
     for (int rr = 0; rr < a.rows; ++rr) {
     const int gy = gy0 + threadIdx.y + (int)blockDim.y * rr;
     if (gy >= a.H) return;
@@ -410,22 +489,6 @@ __global__ void resize_bwd_lds_kernel(const DT* __restrict__ dy, float* __restri
     float acc = 0.f;
     if (ix >= 0 && iy >= 0 && ix < a.cw && iy < a.ch) {
         int ylo, yhi, xlo, xhi;
-        if (fast) {
-            // up-sampling by <= 2.2x with align_corners (every decoder of the path): the tent max(0, 1 - |s*o - i|)
-            // is non-zero on at most 5 consecutive outputs per axis, o > (i-1)/s: 25 taps, no candidate margins.
-            // Taps past the support carry weight 0; their index is clamped into the staged region.
-            int yl = (int)floorf((float)(iy - 1) * a.inv_sy) + 1;
-            if (yl < ry0) yl = ry0;
-#pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int o = yl + r;
-                const float wy = o <= ry1 ? fmaxf(0.f, 1.f - fabsf(a.sy * (float)o - (float)iy)) : 0.f;
-                const float* row = s_reg + ((o <= ry1 ? o : ry1) - ry0) * a.rw;
-                acc += wy * ((wx[0] * row[cx[0]] + wx[1] * row[cx[1]]) + (wx[2] * row[cx[2]] + wx[3] * row[cx[3]]) + wx[4] * row[cx[4]]);
-            }
-            dx[(nc * a.H + gy) * a.W + gx] = acc;
-            continue;
-        }
         resize_cand(iy, a.sy, a.OH, a.align, ylo, yhi);
         resize_cand(ix, a.sx, a.OW, a.align, xlo, xhi);
         if (xhi - xlo + 1 <= RB_MAXC) {
@@ -481,7 +544,7 @@ extern "C" int jaf_resize_bwd_dt(jaf_stream_t s, const void* dy, int dy_bf16, fl
     // rows per lane: as many (<= 8, tile no taller than the plane) as keep the region within 40 KB and leave the launch >= 2048 workgroups
     long rw = 0, rh = 0;
     // 8 rows per lane on planes of at least 50 rows: -5..13 % against 4 on the 50 -> 100 .. 128 -> 256 adjoints (32 -> 64: +30 %)
-    int rows = H >= 50 ? 8 : 4;
+    int rows = H >= JAF_RB_ROWS8_MIN_H ? 8 : 4;
     for (;; rows >>= 1) {
         rw = a.sx > 0.f ? (long)ceilf(((float)b.x + 1.f) / a.sx) + 4 : OW;
         rh = a.sy > 0.f ? (long)ceilf(((float)(b.y * rows) + 1.f) / a.sy) + 4 : OH;

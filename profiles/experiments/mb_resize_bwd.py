@@ -1,7 +1,7 @@
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from jafpro_amd import ops
-for (N, C, s, S) in ((8, 256, 128, 256), (8, 512, 64, 128), (8, 512, 32, 64), (8, 576, 100, 200), (8, 1152, 50, 100), (8, 2304, 25, 50)):
+for (N, C, s, S) in ((8, 256, 128, 256), (8, 512, 64, 128), (8, 512, 32, 64), (8, 512, 16, 32), (8, 512, 8, 16), (8, 576, 100, 200), (8, 1152, 50, 100), (8, 2304, 25, 50)):
     x = torch.randn(N, C, s, s, device="cuda", requires_grad=True)
     y = ops.resize(x, (S, S), align_corners=True)
     g = torch.randn_like(y)
