@@ -93,7 +93,7 @@ typedef struct jaf_conv_plan {
     int32_t plane;              /* bytes of one (split, group) patch plane, multiple of 256 */
     int32_t PWp_slots_unused;   /* reserved */
     int32_t ilv;                /* packed path: a lane's NT tiles are NT consecutive pixels (vector epilogue) */
-    int32_t pf;                 /* reserved */
+    int32_t pf;                 /* packed-input kernels: k-steps of a chunk's weights staged in LDS at a time (0: the whole chunk) */
 } jaf_conv_plan;
 
 enum { JAF_PACK_FWD = 0, JAF_PACK_DGRAD = 1, JAF_PACK_LSTM = 2, JAF_PACK_DGRAD_LSTM = 3 };
