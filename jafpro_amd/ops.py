@@ -7,6 +7,7 @@ CHECK_CONTIGUOUS, rasterize_cuda.cpp:66-68).
 """
 from __future__ import annotations
 
+import collections
 import ctypes
 import math
 import os
@@ -680,6 +681,46 @@ def set_wgrad_stream(stream):
 _WGRAD_PENDING = [False, None]      # [enqueued on the weight-gradient stream since the last join, the stream that joined last]
 _LAZY_JOIN = True
 
+# Operands of a weight-gradient launch (packed input, packed dz) are allocated on the main stream and read on the side stream.
+# `record_stream` would hand their blocks back only when the GPU has passed the launch -- with the host up to one and a half steps
+# ahead that is ~75 ms later, and every step in flight keeps its own copy of all of them (the caching allocator reserved 2.2 x the
+# peak allocation).  Instead the tensors are kept alive on the host until the allocating stream has WAITED for an event recorded
+# behind the launch -- at most _WGRAD_KEEP_LAG launches later (by then the side stream has long passed it: the wait costs nothing), or
+# at the next join -- and are then freed in stream order like any other tensor: reusable at once, no deferred frees.
+_WGRAD_KEEP = collections.deque()       # (event, tensors, allocating stream)
+_WGRAD_KEEP_LAG = 12
+_KEEP_EVENTS: list = []                 # recycled events
+
+
+def _wgrad_keep(tensors, ws) -> None:
+    if torch.cuda.is_current_stream_capturing():       # (a captured step allocates from the graph's private pool: the old rule)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(ws)
+        return
+    cur = torch.cuda.current_stream()
+    ev = _KEEP_EVENTS.pop() if _KEEP_EVENTS else torch.cuda.Event()
+    ev.record(ws)
+    _WGRAD_KEEP.append((ev, [t for t in tensors if t is not None], cur))
+    while len(_WGRAD_KEEP) > _WGRAD_KEEP_LAG:
+        ev0, ts0, st0 = _WGRAD_KEEP.popleft()
+        st0.wait_event(ev0)
+        ts0.clear()
+        _KEEP_EVENTS.append(ev0)
+
+
+def _wgrad_keep_release(cur) -> None:
+    """After `cur` has joined the weight-gradient stream: everything kept for launches whose operands `cur` allocated is free."""
+    if not _WGRAD_KEEP:
+        return
+    rest = [e for e in _WGRAD_KEEP if e[2] != cur]
+    for ev0, ts0, st0 in _WGRAD_KEEP:
+        if st0 == cur:
+            ts0.clear()
+            _KEEP_EVENTS.append(ev0)
+    _WGRAD_KEEP.clear()
+    _WGRAD_KEEP.extend(rest)
+
 
 def wgrad_stream():
     """The stream set by set_wgrad_stream (None: weight gradients run on the current stream)."""
@@ -698,6 +739,7 @@ def join_wgrad_stream():
     cur.wait_stream(_WGRAD_STREAM)
     _WGRAD_PENDING[0] = False
     _WGRAD_PENDING[1] = cur
+    _wgrad_keep_release(cur)
 
 
 _WGRAD_WATCH = [None]       # (ids of the weights still to come, callback): see watch_wgrads
@@ -1102,9 +1144,7 @@ class _ConvFn(Function):
             ws.wait_stream(torch.cuda.current_stream())
             _WGRAD_PENDING[0] = True
             _conv_wgrad(ctx, m, weight, srcs, dz, dzp, True, stream=ws)
-            for t in (ctx.xp, dzp, dz) + tuple(srcs):
-                if t is not None:
-                    t.record_stream(ws)
+            _wgrad_keep((ctx.xp, dzp, dz) + tuple(srcs), ws)
             wgrad_done = True
         dsrcs: List[Optional[torch.Tensor]] = []
         pad_d = m.KH - 1 - m.pad
@@ -1525,8 +1565,7 @@ class _ConvLSTMFn(Function):
                     if ev is not None:
                         _PROF.end(_launched(), 2.0 * N * G * 4 * C * Cin * 9 * H * W, ev)
                 if wst is not None:
-                    gtp.record_stream(wst)
-                    ctx.xps[t].record_stream(wst)
+                    _wgrad_keep((gtp, ctx.xps[t]), wst)
             else:
                 # gt is overwritten with the pre-activation gate gradients
                 check(L.jaf_convlstm_gates_bwd(_s(), N, G, C, H * W, _p(dht), _p(dc), _p(gt),

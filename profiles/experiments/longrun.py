@@ -5,9 +5,10 @@ from jafpro_amd import ops, synth
 from jafpro_amd.step import Stage4Trainer, _to_dev
 ops.set_precision(sys.argv[2] if len(sys.argv) > 2 else "bf16")
 _, fidx = synth.body_mesh()
-M, mods = bench.build_models(fidx); M = M.cuda()
+SIZE = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+M, mods = bench.build_models(fidx, SIZE); M = M.cuda()
 tr = Stage4Trainer(M)
-batch = _to_dev(synth.stage4_batch(1300, 8), "cuda")
+batch = _to_dev(synth.stage4_batch(1300, 8, S=SIZE), "cuda")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 for i in range(n + 1):
     out = tr.train_step(batch, next_batch=batch)
