@@ -498,3 +498,63 @@ def test_graphed_step_trains_on_the_clip_it_is_given():
     for k, v in g.cur.items():
         if isinstance(v, torch.Tensor):
             assert torch.equal(v, clips[0][k]), k
+
+
+def test_weight_gradient_operands_outlive_their_side_stream_reads():
+    """ops._wgrad_keep (memory across streams): a tensor allocated on the main stream and read on the side stream is
+    dropped by its owner right after the side-stream launch; the main stream then allocates and overwrites same-sized blocks at once.
+    The side stream is parked now and then so that it runs far behind.  Every side-stream result must still be the one computed from
+    the original contents, the list of kept tensors must stay bounded, and a join must empty it."""
+    from jafpro_amd import ops
+    side = torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    outs = []
+    n = 3 * ops._WGRAD_KEEP_LAG + 5
+    for i in range(n):
+        x = torch.full((1 << 20,), float(i), device="cuda")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if i % 8 == 0:
+                torch.cuda._sleep(int(3.0e8))
+            y = x * 2.0
+        ops._wgrad_keep((x, None), side)
+        del x
+        z = torch.full((1 << 20,), -1.0, device="cuda")      # would land in x's block if that had been released
+        del z
+        outs.append(y)
+        assert len(ops._WGRAD_KEEP) <= ops._WGRAD_KEEP_LAG
+    main.wait_stream(side)
+    ops._wgrad_keep_release(main)
+    assert len(ops._WGRAD_KEEP) == 0
+    torch.cuda.synchronize()
+    for i, y in enumerate(outs):
+        assert bool((y == 2.0 * i).all()), i
+
+
+def test_allocator_reserve_stays_near_the_peak_allocation():
+    """after a dozen bf16 steps with the next step enqueued ahead, the caching allocator must not hold more than 1.5 x
+    the peak allocation (2.2 x before the weight-gradient operands went from record_stream to the event-ordered keep-alive; measured
+    1.2 x at B = 8, profiles/experiments/round5_longrun_keepalive.log), and it must have stopped growing."""
+    import gc
+    from jafpro_amd import ops
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    M, tr, orc, batch, dbatch, mods = build(2)
+    prev = ops.set_precision("bf16")
+    try:
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_reserved()
+        for _ in range(8):
+            tr.train_step(dbatch, next_batch=dbatch)
+        torch.cuda.synchronize()
+        r8 = torch.cuda.memory_reserved()
+        for _ in range(6):
+            tr.train_step(dbatch, next_batch=dbatch)
+        torch.cuda.synchronize()
+        r14, peak = torch.cuda.memory_reserved(), torch.cuda.max_memory_allocated()
+    finally:
+        ops.set_precision(prev)
+    assert r14 <= 1.5 * peak, (r14 / 1e9, peak / 1e9)
+    assert r14 - r8 <= 0.05 * peak, ((r14 - r8) / 1e9, base / 1e9)
