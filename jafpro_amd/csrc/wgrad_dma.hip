@@ -210,13 +210,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
             (void*)(a.xp + ((long)n * d.G + g) * (long)xbytes), 0, xbytes, 0x00020000);
         const jaf_u32x4 rxa = jaf_make_rsrc(a.xp + ((long)n * d.G + g) * (long)xbytes, (unsigned)xbytes);
         const int tbase = (iy0 * d.W + ix0) * 16;
+        // (uniform) the whole patch and the whole pixel tile lie inside the image: no per-lane bounds logic -- a dead slot's offset is the
+        // out-of-range constant itself and stays out of range when the tile base is added (32-bit unsigned buffer offsets)
+        const bool interior = iy0 >= 0 && ix0 >= 0 && iy0 + a.PH <= d.H && ix0 + a.PW <= d.W && oy0 + WD_TH <= d.OH && ox0 + WD_TW <= d.OW;
 #pragma unroll
         for (int j = 0; j < XI; ++j) {
             const int i = wave + 4 * j;
             if (i < nxi) {
-                const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
-                const int iy = iy0 + r, ix = ix0 + c;
-                const bool ok = (x_rc[j] >= 0) && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
+                bool ok = x_rc[j] >= 0;
+                if (!interior) {
+                    const int r = x_rc[j] >> 16, c = x_rc[j] & 0xffff;
+                    const int iy = iy0 + r, ix = ix0 + c;
+                    ok = ok && (iy >= 0) && (ix >= 0) && (iy < d.H) && (ix < d.W);
+                }
                 const int tci = i / a.nx;
 #pragma unroll
                 for (int h = 0; h < (SPLIT ? 2 : 1); ++h) {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
             (void*)(a.dzp + ((long)n * d.G + g) * (long)zbytes), 0, zbytes, 0x00020000);
         const jaf_u32x4 rza = jaf_make_rsrc(a.dzp + ((long)n * d.G + g) * (long)zbytes, (unsigned)zbytes);
         const int y = z_yx >> 16, x = z_yx & 0xffff;
-        const bool okp = (oy0 + y < d.OH) && (ox0 + x < d.OW);
+        const bool okp = interior || ((oy0 + y < d.OH) && (ox0 + x < d.OW));
         const int zb = z_goff + (oy0 * d.OW + ox0) * 16;
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
@@ -364,21 +370,33 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
             }
         }
     } else if constexpr (PAIR) {
+        // enc_0 (5 x 5, 3 -> 12 channels per part): dW is 21 600 floats and 2 304 workgroups add to all of it; straight from the
+        // accumulators a lane's taps are 100 bytes from its neighbour's (every lane its own cache line, 8.6 M lane-atomics per launch
+        // at ~40 G/s = 0.2 ms of a kernel that nothing overlaps).  As for 7 x 7: the four waves' k-step partials are summed in LDS and
+        // the workgroup walks its (row, channel, tap) block in memory order -- a quarter of the atomics, 25-float runs.
+        static_assert(MTW == 1, "one 16-row tile per workgroup");
         const int ci = li & 7, hb = li >> 3;
+        float* s_ep = (float*)smem;
+        const int nrow = d.Cout - co0 < 16 ? d.Cout - co0 : 16;
+        const int per = nrow * 8 * NTAP;
+        __syncthreads();            // every wave is done with the tile buffers
+        for (int e = tid; e < per; e += 256) s_ep[e] = 0.f;
+        __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
+        for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < nrow && ci < d.Cin) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int co = co0 + mt * 16 + q * 4 + j;
-                if (co < d.Cout && ci < d.Cin) {
-                    float* p = a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + ci) * NTAP;
-#pragma unroll
-                    for (int pr = 0; pr < NACC; ++pr) {
-                        const int t = 2 * pr + hb;
-                        if (t < NTAP) atomicAdd(p + t, acc[mt][pr][j]);
-                    }
+                for (int pr = 0; pr < NACC; ++pr) {
+                    const int t = 2 * pr + hb;
+                    if (t < NTAP) atomicAdd(&s_ep[((q * 4 + j) * 8 + ci) * NTAP + t], acc[0][pr][j]);
                 }
             }
+        __syncthreads();
+        for (int e = tid; e < per; e += 256) {
+            const int row = e / (8 * NTAP), r1 = e - row * (8 * NTAP);
+            const int cil = r1 / NTAP, t = r1 - cil * NTAP;
+            if (cil < d.Cin)
+                atomicAdd(a.dw + (((long)(g * d.Cout + co0 + row) * d.w_cin_tot) + d.w_cin_off + cil) * NTAP + t, s_ep[e]);
         }
     } else if constexpr (KS == 7) {
         // 7 x 7 (the propagater's first and last layers: dW is a few thousand floats, every workgroup adds to all of it).  A lane's
@@ -387,23 +405,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_dma_kernel(const WgDArgs a)
         // second).  The waves' k-step partials are summed in LDS first ([tile][row][channel][tap], ds_add_f32) and the
         // workgroup then walks dW in memory order: a quarter of the atomics, 16 lanes per cache line.
         static_assert(MTW == 1, "one 16-row tile per workgroup");
+        // (only the rows that exist: the propagater's last layer has ONE output channel, its first layer 9 input channels)
         float* s_ep = (float*)smem;
-        const int per_tile = 16 * 16 * NACC;
+        const int nrow = d.Cout - co0 < 16 ? d.Cout - co0 : 16;
+        const int per_tile = nrow * 16 * NACC;
         __syncthreads();            // every wave is done with the tile buffers
         for (int e = tid; e < WC * per_tile; e += 256) s_ep[e] = 0.f;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j)
+            if (q * 4 + j < nrow && cit + li < d.Cin) {
 #pragma unroll
-            for (int t = 0; t < NACC; ++t) atomicAdd(&s_ep[((wc * 16 + q * 4 + j) * 16 + li) * NACC + t], acc[0][t][j]);
+                for (int t = 0; t < NACC; ++t) atomicAdd(&s_ep[((wc * nrow + q * 4 + j) * 16 + li) * NACC + t], acc[0][t][j]);
+            }
         __syncthreads();
         const int ntap = a.kyn * KS;
         for (int e = tid; e < WC * per_tile; e += 256) {
-            const int tci = e / per_tile, r0 = e - tci * per_tile;
+            const int tci = e >= per_tile ? 1 : 0, r0 = e - tci * per_tile;            // (WC <= 2 for 7 x 7: wgd_core)
             const int row = r0 / (16 * NACC), r1 = r0 - row * (16 * NACC);
             const int cil = r1 / NACC, t = r1 - cil * NACC;
             const int co = co0 + row, ci = ci0 + tci * 16 + cil;
-            if (co < d.Cout && ci < d.Cin && t < ntap)
+            if (ci < d.Cin && t < ntap)
                 atomicAdd(a.dw + (((long)(g * d.Cout + co) * d.w_cin_tot) + d.w_cin_off + ci) * NTAP + a.ky0 * KS + t, s_ep[e]);
         }
     } else {
