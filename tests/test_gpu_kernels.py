@@ -965,3 +965,55 @@ def test_bf16_storage_crn_block_and_convlstm_agree_with_fp32_storage():
         print("convlstm result %d: rel-L2 %.3e" % (i, _rel(a, b)))
         assert _rel(a, b) <= 8e-2, ("convlstm", i, _rel(a, b))
     assert any(not torch.equal(a, b) for a, b in zip(o1, o0)), "bf16 storage left every ConvLSTM result bit-identical: it did not run"
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16x3"])
+def test_batched_weight_repack_equals_a_fresh_pack(mode):
+    """ops.refresh_packed_weights re-makes the cached weight images of a module in ONE launch whose threads take all taps of 8 channels of
+    a row (csrc/conv_pack_weights.hip: jafb_repack_rows) and rely on the zero padding the first pack left.  After the weights have
+    changed, every re-made image -- forward, data-gradient and both ConvLSTM forms, ragged channel counts, grouped, 1x1 / 3x3 / 5x5 / 7x7 --
+    must equal, byte for byte, an image packed from scratch by jaf_conv2d_pack."""
+    import ctypes
+    ops = _ops()
+    from jafpro_amd._lib import lib
+    prev = ops.set_precision(mode)
+    try:
+        ws = []
+        cases = [(2, 1, 5, 7, 12, 3), (1, 1, 70, 128, 16, 3), (2, 3, 4, 12, 10, 5), (1, 1, 9, 32, 20, 7), (1, 1, 256, 3, 8, 1), (1, 24, 24, 6, 12, 3),
+                 (1, 1, 515, 512, 4, 3)]
+        for i, (N, G, Cin, Cout, S, k) in enumerate(cases):
+            x = dev(R(20 + i, N, G * Cin, S, S)).requires_grad_(True)
+            w = dev(R(40 + i, G * Cout, Cin, k, k, lo=-0.3, hi=0.3)).requires_grad_(True)
+            b = dev(R(60 + i, G * Cout)).requires_grad_(True)
+            y = ops.conv2d(x, w, b, stride=1, pad=k // 2, act=1, slope=0.2, groups=G)
+            y.sum().backward()
+            ws.append(w)
+        T, N, G, C, S = 2, 1, 2, 12, 10
+        xl = dev(R(80, T, N, G * C, S, S)).requires_grad_(True)
+        wl = dev(R(81, G * 4 * C, 2 * C, 3, 3, lo=-0.3, hi=0.3)).requires_grad_(True)
+        bl = dev(R(82, G * 4 * C)).requires_grad_(True)
+        h, _ = ops.convlstm(xl, wl, bl, groups=G)
+        h.sum().backward()
+        ws.append(wl)
+        n_entries = 0
+        with torch.no_grad():
+            for w in ws:
+                w.mul_(1.37).add_(0.011)
+        ops.refresh_packed_weights(ws)
+        torch.cuda.synchronize()
+        L = lib()
+        for w in ws:
+            for ck in ops._PACK_KEYS_BY_ID.get(id(w), ()):
+                e = ops._PACK_CACHE.get(ck)
+                if e is None or e.ref() is not w:
+                    continue
+                fresh = torch.empty_like(e.buf)
+                fresh.fill_(float("nan"))
+                ops.check(L.jaf_conv2d_pack(ops._s(), ctypes.byref(e.d), ctypes.byref(e.pl), e.mode, ops._p(w), e.rows, ops._p(fresh)), "jaf_conv2d_pack")
+                torch.cuda.synchronize()
+                assert torch.equal(e.buf.view(torch.int32), fresh.view(torch.int32)), (tuple(w.shape), e.mode)
+                n_entries += 1
+        assert n_entries >= 2 * len(cases)          # forward + data-gradient image of every convolution (+ the ConvLSTM's)
+    finally:
+        ops.set_precision(prev)
+        ops.invalidate_packed_weights()
