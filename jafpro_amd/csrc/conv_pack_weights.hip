@@ -90,13 +90,98 @@ int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, 
     return jaf_launch_status();
 }
 
+// The same image, tile by tile through LDS: a tile = 16 rows x one channel group of 8 x all taps of one (group, row block, chunk, MT
+// slice).  Item by item (jafb_pack_item8) a lane reads 8 floats that lie `sch` apart and the other taps of the same cache lines belong
+// to far-away threads: the re-packing of a module fetched every weight ~6 times (profiles/round5_g_pmc_hbm_traffic.txt: 230 MB per
+// launch for ~38 MB of weights) and ran at a sixth of the HBM floor.  Here the tile's source floats are read ONCE along their memory
+// order -- 8 x taps contiguous floats per row (forward / ConvLSTM images) or 16 x taps per channel (data-gradient images) -- and the
+// 16-byte items leave in the image's order.  Writes every item jafb_pack_item8 writes (zeros for rows / channels / slots that do not
+// exist), so the two kernels make identical images (tests/test_gpu_kernels.py::test_batched_weight_repack_equals_a_fresh_pack).
+#define JAFB_TILE_FLOATS (16 * 8 * 49)       // 25 KB: one group of a 7 x 7 layer, or all four groups of a 3 x 3 chunk
+__device__ __forceinline__ void jafb_pack_tile(const PackBArgs& a, long tile, int GT, float* s_t /* [16][GT * 8][taps] */) {
+    const int tid = threadIdx.x;
+    const int gblocks = (a.NG + GT - 1) / GT;
+    long t = tile;
+    const int gb = (int)(t % gblocks); t /= gblocks;
+    const int mt = (int)(t % a.MT); t /= a.MT;
+    const int chunk = (int)(t % a.nchunks); t /= a.nchunks;
+    const int mb = (int)(t % a.mblocks); t /= a.mblocks;
+    const int g = (int)t;
+    const int ngc = (chunk == a.nchunks - 1) ? a.ng_last : a.NG;
+    const int grp0 = gb * GT;
+    if (grp0 >= ngc) return;                             // (uniform)
+    const int ng = ngc - grp0 < GT ? ngc - grp0 : GT;    // channel groups of this tile
+    const int nch = 8 * ng;
+    const int taps = a.taps;
+    const int r0 = mb * 16 * a.MT + mt * 16;
+    const int ch0 = (chunk * a.NG + grp0) * 8;
+    const float* wg = a.w + a.base + g * a.sg;
+    const int n = 16 * nch * taps;
+    __syncthreads();                                     // the previous tile's items have been read out of s_t
+    const bool rowmajor = a.sch < a.srow;                // forward-like: a row's nch x taps floats are contiguous (channel stride = taps);
+    const int span = rowmajor ? nch * taps : 16 * taps;  // data-gradient-like: for one channel the 16 rows x taps floats are
+    for (int e = tid; e < n; e += 256) {
+        const int hi = e / span, k = e - hi * span;
+        const int lo = k / taps, tp = k - lo * taps;
+        const int row = rowmajor ? hi : lo, j = rowmajor ? lo : hi;
+        const int r = r0 + row, ch = ch0 + j;
+        float v = 0.f;
+        if (r < a.M && ch < a.Cred) {
+            const int srow = a.lstmC > 0 ? (r & 3) * a.lstmC + (r >> 2) : r;
+            const int chs = a.redC > 0 ? (ch & 3) * a.redC + (ch >> 2) : ch;
+            v = wg[(long)srow * a.srow + (long)chs * a.sch + tp];
+        }
+        s_t[(row * nch + j) * taps + tp] = v;
+    }
+    __syncthreads();
+    typedef unsigned int pk_u32x4 __attribute__((ext_vector_type(4)));
+    typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+    const long ibase = ((((long)g * a.mblocks + mb) * a.nchunks + chunk) * a.nimg) * a.nsteps;
+    // items (tap, group of this tile, row), plus (first group block) the chunk's padding slots past taps x groups
+    const int nslot = taps * ng;
+    const int npad = gb == 0 ? 4 * a.nsteps - taps * ngc : 0;
+    for (int e = tid; e < 16 * (nslot + npad); e += 256) {
+        const int row = e & 15, si = e >> 4;
+        const bool pad = si >= nslot;
+        const int ti = pad ? 0 : si / ng, gi = pad ? 0 : si - ti * ng;
+        const int s = pad ? taps * ngc + (si - nslot) : ti * ngc + grp0 + gi;
+        const int st = s >> 2, q = s & 3;
+        float v[8];
+        const int stap = a.flip ? (taps - 1 - ti) : ti;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = pad ? 0.f : s_t[(row * nch + gi * 8 + j) * taps + stap];
+        for (int img = 0; img < a.nimg; ++img) {
+            pk_u32x4 w;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float x0 = v[2 * u], x1 = v[2 * u + 1];
+                if (img == 1) {          // residual image of the split-bf16 mode: v - bf16(v)
+                    x0 = x0 - (float)(__bf16)x0;
+                    x1 = x1 - (float)(__bf16)x1;
+                }
+                const pk_f32x2 p2 = {x0, x1};
+                w[u] = __builtin_bit_cast(unsigned int, __builtin_convertvector(p2, pk_bf16x2));
+            }
+            const long item = ((((ibase + (long)img * a.nsteps + st) * a.MT + mt) * 4 + q) << 4) + row;
+            *(pk_u32x4*)(a.out + item * 8) = w;
+        }
+    }
+}
+
 // Many weight images in ONE launch (the re-packing after an optimiser step: ~40 images per module): blockIdx.y picks
 // the image's argument block out of a device-resident table.
-__global__ void conv_pack_bf16_batch_kernel(const PackBArgs* __restrict__ table) {
+__global__ __launch_bounds__(256) void conv_pack_bf16_batch_kernel(const PackBArgs* __restrict__ table) {
+    __shared__ float s_t[JAFB_TILE_FLOATS];
     const PackBArgs a = table[blockIdx.y];
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (a.total >> 3); e += (long)gridDim.x * blockDim.x) {
-        jafb_pack_item8(a, e);
+    int GT = JAFB_TILE_FLOATS / (16 * 8 * a.taps);       // channel groups per tile
+    if (GT < 1) {                                        // (no such layer; kept correct)
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (a.total >> 3); e += (long)gridDim.x * blockDim.x) jafb_pack_item8(a, e);
+        return;
     }
+    if (GT > a.NG) GT = a.NG;
+    const long ntiles = (long)a.G * a.mblocks * a.nchunks * a.MT * ((a.NG + GT - 1) / GT);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) jafb_pack_tile(a, tile, GT, s_t);
 }
 
 extern "C" int64_t jaf_conv2d_pack_item_bytes(void) { return (int64_t)sizeof(PackBArgs); }
