@@ -320,7 +320,7 @@ def test_batchnorm_act(act, res, training, shape):
         assert maxerr(rd.grad, rr.grad) <= 1e-6
 
 
-@pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 16, 16), (3, 2, 1, 9, 7), (2, 2, 0, 8, 12)])
+@pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 16, 16), (3, 2, 1, 9, 7), (2, 2, 0, 8, 12), (2, 2, 0, 10, 24), (3, 2, 1, 12, 20)])
 def test_avgpool(k, s, p, H, W):
     ops = _ops()
     x = R(1, 2, 5, H, W)
