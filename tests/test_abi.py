@@ -107,6 +107,42 @@ def test_lstm_plan_requires_gate_interleaved_tiles():
     assert L.jaf_conv2d_plan(ctypes.byref(d), 1, ctypes.byref(_lib.ConvPlan())) == -1
 
 
+def test_packed_plan_invariants_and_weight_subloads():
+    """jaf_conv2d_plan_packed (host code, no GPU): the LDS layout it promises the kernels, for every stage-4 layer in bf16 and
+    split-bf16; and the round-5 weight sub-loads (jaf_conv_plan.pf): the wide layers with enough workgroups take 4-group chunks
+    (9 exact k-steps of a 3 x 3 layer) three k-steps at a time inside 40 KB of LDS (four workgroups per CU), the small-grid layers keep
+    the whole chunk resident."""
+    L = _lib.lib()
+    for prec in (_lib.PREC_BF16, _lib.PREC_BF16X3):
+        sb = 2 if prec == _lib.PREC_BF16X3 else 1
+        for (G, cins, Cout, H, k, s, p) in LAYERS:
+            for N in (1, 8, 32):
+                d = _desc(N, G, cins, Cout, H, H, k, s, p)
+                d.precision = prec
+                pl = _lib.ConvPlan()
+                assert L.jaf_conv2d_plan_packed(ctypes.byref(d), 0, ctypes.byref(pl)) == 0, (G, cins, Cout, H, k, s)
+                groups = (sum(cins) + 7) // 8
+                assert 1 <= pl.NG <= 4 and pl.nchunks == -(-groups // pl.NG) and pl.ng_last == groups - (pl.nchunks - 1) * pl.NG
+                assert pl.nsteps == -(-(k * k * pl.NG) // 4) and 0 <= pl.pf <= pl.nsteps
+                wl = pl.pf if pl.pf else pl.nsteps
+                assert pl.lds_bytes >= sb * pl.NG * pl.plane + sb * wl * pl.MT * 1024 + 2 * 16 * pl.nsteps * 4
+                assert pl.lds_bytes <= 160 * 1024 and pl.plane % 1024 == 0 and pl.plane >= pl.npos * 16
+                assert pl.mblocks * 16 * pl.MT >= Cout and pl.tiles_x * pl.tiles_p * 64 * pl.NT >= d.OH * d.OW
+    # bf16: the CRN's 256 -> 256 at 256 x 256 (8192 workgroups) vs its 3 + 512 + 256 -> 512 at 32 x 32 (256 workgroups)
+    d = _desc(8, 1, [256], 256, 256, 256, 3, 1, 1); d.precision = 1
+    pl = _lib.ConvPlan()
+    assert L.jaf_conv2d_plan_packed(ctypes.byref(d), 0, ctypes.byref(pl)) == 0
+    assert (pl.MT, pl.NT, pl.NG, pl.nsteps, pl.pf) == (4, 4, 4, 9, 3) and pl.lds_bytes <= 40 * 1024
+    d = _desc(8, 1, [3, 512, 256], 512, 32, 32, 3, 1, 1); d.precision = 1
+    assert L.jaf_conv2d_plan_packed(ctypes.byref(d), 0, ctypes.byref(pl)) == 0
+    assert pl.NG == 4 and pl.pf == 0
+    # the ConvLSTM plans keep gate-interleaved tiles
+    for C, H in ((12, 200), (24, 100), (24, 50), (48, 25), (96, 13)):
+        d = _desc(8, 24, [C, C], 4 * C, H, H, 3, 1, 1); d.precision = 1
+        assert L.jaf_conv2d_plan_packed(ctypes.byref(d), 1, ctypes.byref(pl)) == 0
+        assert (4 * C) % (16 * pl.MT) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_LIB", None)
     monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(os.path.dirname(_lib.LIB_PATH), "nope.so"))
