@@ -97,7 +97,7 @@ int jafb_pack(hipStream_t s, const jaf_conv_desc* d, const jaf_conv_plan* plan, 
 // order -- 8 x taps contiguous floats per row (forward / ConvLSTM images) or 16 x taps per channel (data-gradient images) -- and the
 // 16-byte items leave in the image's order.  Writes every item jafb_pack_item8 writes (zeros for rows / channels / slots that do not
 // exist), so the two kernels make identical images (tests/test_gpu_kernels.py::test_batched_weight_repack_equals_a_fresh_pack).
-#define JAFB_TILE_FLOATS (16 * 8 * 49)       // 25 KB: one group of a 7 x 7 layer, or all four groups of a 3 x 3 chunk
+#define JAFB_TILE_FLOATS (16 * 8 * 49 + 16)  // 25 KB: one group of a 7 x 7 layer, or all four groups of a 3 x 3 chunk (+ an odd row pitch)
 __device__ __forceinline__ void jafb_pack_tile(const PackBArgs& a, long tile, int GT, float* s_t /* [16][GT * 8][taps] */) {
     const int tid = threadIdx.x;
     const int gblocks = (a.NG + GT - 1) / GT;
@@ -117,12 +117,15 @@ __device__ __forceinline__ void jafb_pack_tile(const PackBArgs& a, long tile, in
     const int ch0 = (chunk * a.NG + grp0) * 8;
     const float* wg = a.w + a.base + g * a.sg;
     const int n = 16 * nch * taps;
+    const int rs = (nch * taps) | 1;                     // row pitch in LDS, odd: the 16 rows of an item column fall into 16 banks
     __syncthreads();                                     // the previous tile's items have been read out of s_t
     const bool rowmajor = a.sch < a.srow;                // forward-like: a row's nch x taps floats are contiguous (channel stride = taps);
     const int span = rowmajor ? nch * taps : 16 * taps;  // data-gradient-like: for one channel the 16 rows x taps floats are
+    // (index decoding with reciprocals: e < 6 272, exact for the + 0.5 form; two integer divisions per element were most of the loop)
+    const float inv_span = 1.0f / (float)span, inv_taps = 1.0f / (float)taps;
     for (int e = tid; e < n; e += 256) {
-        const int hi = e / span, k = e - hi * span;
-        const int lo = k / taps, tp = k - lo * taps;
+        const int hi = (int)(((float)e + 0.5f) * inv_span), k = e - hi * span;
+        const int lo = (int)(((float)k + 0.5f) * inv_taps), tp = k - lo * taps;
         const int row = rowmajor ? hi : lo, j = rowmajor ? lo : hi;
         const int r = r0 + row, ch = ch0 + j;
         float v = 0.f;
@@ -131,7 +134,7 @@ __device__ __forceinline__ void jafb_pack_tile(const PackBArgs& a, long tile, in
             const int chs = a.redC > 0 ? (ch & 3) * a.redC + (ch >> 2) : ch;
             v = wg[(long)srow * a.srow + (long)chs * a.sch + tp];
         }
-        s_t[(row * nch + j) * taps + tp] = v;
+        s_t[row * rs + j * taps + tp] = v;
     }
     __syncthreads();
     typedef unsigned int pk_u32x4 __attribute__((ext_vector_type(4)));
@@ -140,17 +143,18 @@ __device__ __forceinline__ void jafb_pack_tile(const PackBArgs& a, long tile, in
     const long ibase = ((((long)g * a.mblocks + mb) * a.nchunks + chunk) * a.nimg) * a.nsteps;
     // items (tap, group of this tile, row), plus (first group block) the chunk's padding slots past taps x groups
     const int nslot = taps * ng;
+    const float inv_ng = 1.0f / (float)ng;
     const int npad = gb == 0 ? 4 * a.nsteps - taps * ngc : 0;
     for (int e = tid; e < 16 * (nslot + npad); e += 256) {
         const int row = e & 15, si = e >> 4;
         const bool pad = si >= nslot;
-        const int ti = pad ? 0 : si / ng, gi = pad ? 0 : si - ti * ng;
+        const int ti = pad ? 0 : (int)(((float)si + 0.5f) * inv_ng), gi = pad ? 0 : si - ti * ng;
         const int s = pad ? taps * ngc + (si - nslot) : ti * ngc + grp0 + gi;
         const int st = s >> 2, q = s & 3;
         float v[8];
         const int stap = a.flip ? (taps - 1 - ti) : ti;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = pad ? 0.f : s_t[(row * nch + gi * 8 + j) * taps + stap];
+        for (int j = 0; j < 8; ++j) v[j] = pad ? 0.f : s_t[row * rs + (gi * 8 + j) * taps + stap];
         for (int img = 0; img < a.nimg; ++img) {
             pk_u32x4 w;
 #pragma unroll
@@ -174,7 +178,7 @@ __device__ __forceinline__ void jafb_pack_tile(const PackBArgs& a, long tile, in
 __global__ __launch_bounds__(256) void conv_pack_bf16_batch_kernel(const PackBArgs* __restrict__ table) {
     __shared__ float s_t[JAFB_TILE_FLOATS];
     const PackBArgs a = table[blockIdx.y];
-    int GT = JAFB_TILE_FLOATS / (16 * 8 * a.taps);       // channel groups per tile
+    int GT = (JAFB_TILE_FLOATS - 16) / (16 * 8 * a.taps);       // channel groups per tile
     if (GT < 1) {                                        // (no such layer; kept correct)
         for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (a.total >> 3); e += (long)gridDim.x * blockDim.x) jafb_pack_item8(a, e);
         return;
