@@ -279,10 +279,11 @@ __global__ __launch_bounds__(256) void conv_pack_input_lazy_lds_kernel(const Pac
             int i0, i1; float l;
             cd_resize_src(yl, a.sy[s], a.sh[s], a.align[s], i0, i1, l);
             cnt[s] = (i1 - ys0[s] + 1) * tw[s];
+            const float inv_tw = 1.0f / (float)tw[s];          // (e < 512: the reciprocal form is exact; six integer divisions per lane before)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int e = tid + 256 * u;
-                const int r = e / tw[s], q = e - r * tw[s];
+                const int r = (int)(((float)e + 0.5f) * inv_tw), q = e - r * tw[s];
                 soff[s][u] = (ys0[s] + r) * a.sw[s] + xs0[s] + q;
             }
         }
